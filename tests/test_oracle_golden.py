@@ -1,0 +1,128 @@
+"""Pin the oracle: restatement (oracle/*.py) vs committed reference outputs (tests/golden, produced by
+oracle/make_golden.py from the real reference) and vs the reference's own known-answer tests."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vsa_oracle as V
+from oracle import wan_oracle as W
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    return torch.load(os.path.join(golden_dir, "wan_tiny.pt"), weights_only=False)
+
+
+def test_wan_tiny_forward_bit_exact(tiny):
+    o = W.WanOracle(tiny["state_dict"], num_heads=tiny["config"]["num_heads"])
+    for case in tiny["cases"]:
+        trace = {}
+        with torch.no_grad():
+            y = o.forward(case["latent"], case["ctx"], case["timestep"], trace)
+        assert y.dtype == torch.bfloat16
+        for i, b in enumerate(case["blocks"]):
+            assert torch.equal(trace[f"blocks.{i}.out"], b), f"block {i}"
+        assert torch.equal(y, case["out"])
+
+
+def test_rope_tables(golden_dir):
+    g = torch.load(os.path.join(golden_dir, "rope.pt"), weights_only=False)
+    for key, ref in g.items():
+        grid = tuple(int(v) for v in key.split("x"))
+        cos, sin = W.rope_tables(grid, 128)
+        assert cos.shape == (math.prod(grid), 128) and cos.dtype == torch.float32
+        assert torch.equal(cos[ref["rows"]], ref["cos"]) and torch.equal(sin[ref["rows"]], ref["sin"])
+        assert cos.double().sum().item() == ref["cos_sum"] and sin.double().sum().item() == ref["sin_sum"]
+
+
+def test_vsa_metadata_golden(golden_dir):
+    z = np.load(os.path.join(golden_dir, "vsa_meta.npz"))
+    lats = sorted({k.split("/")[0] for k in z.files})
+    assert len(lats) >= 6
+    for lat in lats:
+        md = V.build_metadata(tuple(int(v) for v in lat.split("x")))
+        assert np.array_equal(md["tile_partition_indices"], z[lat + "/perm"])
+        assert np.array_equal(md["reverse_tile_partition_indices"], z[lat + "/rev"])
+        assert np.array_equal(md["variable_block_sizes"], z[lat + "/vbs"])
+        assert np.array_equal(md["non_pad_index"], z[lat + "/non_pad"])
+        assert np.array_equal(md["untile_combined_index"], z[lat + "/untile"])
+        assert tuple(z[lat + "/num_tiles"]) == md["num_tiles"]
+
+
+# ---- known-answer tests restated from fastvideo-kernel/tests/test_vsa_utils.py ----
+def test_kat_identity_perm():  # :65-69
+    assert V.tile_partition_indices((2, 2, 2), (2, 2, 2)).tolist() == list(range(8))
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 16), (9, 10, 7), (5, 7, 3)])
+def test_kat_perm_inverse(shape):  # :52-63, :86-95
+    f, r = V.tile_partition_indices(shape), V.reverse_tile_partition_indices(shape)
+    n = math.prod(shape)
+    assert sorted(f.tolist()) == list(range(n))
+    assert np.array_equal(r[f], np.arange(n)) and np.array_equal(f[r], np.arange(n))
+
+
+def test_kat_block_sizes():  # :99-153
+    assert V.variable_block_sizes((8, 16, 16)).sum() == 8 * 16 * 16
+    assert (V.variable_block_sizes((8, 8, 8)) == 64).all()
+    assert V.variable_block_sizes((9, 8, 8), (3, 2, 2)).min() < 64
+    assert (V.variable_block_sizes((6, 8, 16), (3, 2, 2), (2, 4, 8)) == 64).all()
+    assert V.num_tiles_of((9, 10, 7)) == (3, 3, 2)  # :210-213
+
+
+def test_kat_non_pad_index():  # :158-182
+    idx = V.non_pad_index(np.array([20, 40]), 64)
+    assert idx[0] == 0 and idx[20] == 64 and len(idx) == 60
+    assert np.array_equal(V.non_pad_index(np.array([64, 64]), 64), np.arange(128))
+
+
+def test_kat_topk_count_uses_padded_blocks():  # fastvideo/tests/attention/test_video_sparse_attention_metadata.py:68-111
+    assert V.compute_topk(0.8, 624) == 125 and V.compute_topk(0.9, 624) == 63
+    assert V.compute_topk(1.0, 10) == 1 and V.compute_topk(-1.0, 10) == 10
+
+
+def test_kat_topk_mask_ties_and_exact_k():  # fastvideo-kernel/tests/test_fused_compress_topk.py:30-109
+    rng = np.random.default_rng(0)
+    s = rng.standard_normal((2, 3, 7, 50)).astype(np.float32)
+    m = V.topk_mask_bisect(s, 9)
+    assert (m.sum(-1) == 9).all()
+    ref = np.zeros_like(m)
+    np.put_along_axis(ref, np.argsort(-s, axis=-1, kind="stable")[..., :9], True, axis=-1)
+    assert np.array_equal(m, ref)
+    # all-equal row: first-come tie break selects the lowest indices
+    t = np.zeros((1, 1, 1, 16), np.float32)
+    assert V.topk_mask_bisect(t, 5)[0, 0, 0].tolist() == [True] * 5 + [False] * 11
+    # bf16-valued scores with many ties
+    b = torch.from_numpy(s).bfloat16().float().numpy().round(1)
+    mb = V.topk_mask_bisect(b, 9)
+    assert (mb.sum(-1) == 9).all()
+    order = np.argsort(-b, axis=-1, kind="stable")[..., :9]
+    refb = np.zeros_like(mb)
+    np.put_along_axis(refb, order, True, axis=-1)
+    assert np.array_equal(mb, refb)
+
+
+def test_map_to_index_ascending():
+    rng = np.random.default_rng(1)
+    bm = rng.random((1, 2, 5, 12)) < 0.4
+    idx, num = V.map_to_index(bm)
+    for h in range(2):
+        for q in range(5):
+            n = num[0, h, q]
+            assert idx[0, h, q, :n].tolist() == np.nonzero(bm[0, h, q])[0].tolist()
+
+
+def test_sta_mask_matches_tile_lists():
+    canvas, tile, kern = (6, 8, 16), (3, 4, 4), (3, 1, 3)
+    ct = tuple(c // t for c, t in zip(canvas, tile))
+    mask = V.sta_mask(canvas, kern, tile)
+    lists = V.sta_tile_lists(ct, kern)
+    tv = math.prod(tile)
+    for qt, kvs in enumerate(lists):
+        row = mask[qt * tv]
+        got = sorted(set((torch.nonzero(row).flatten() // tv).tolist()))
+        assert got == kvs
+        assert len(kvs) == min(kern[0], ct[0]) * min(kern[1], ct[1]) * min(kern[2], ct[2])
