@@ -1,0 +1,89 @@
+"""ctypes binding of libfvk_amd.so (the C ABI declared in include/fvk_amd.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised
+(the reference's convention for a refused backend is ValueError/ImportError at selection time and
+TORCH_CHECK -> RuntimeError at call time; fastvideo/platforms/cuda.py:149-154,
+fastvideo-kernel/csrc/attention/st_attn_h100.cu:386-411)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfvk_amd.so")
+ABI_VERSION = 1
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("o", vp), ("lse", vp),
+                ("B", i32), ("H", i32), ("Sq", i32), ("Skv", i32), ("Skv_pad", i32),
+                ("q_bs", i64), ("q_ss", i64), ("q_hs", i64), ("k_bs", i64), ("k_ss", i64), ("k_hs", i64),
+                ("o_bs", i64), ("o_ss", i64), ("o_hs", i64), ("scale", f32)]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "fvk_last_error": [],
+    "fvk_abi_version": [],
+    "fvk_device_arch": [C.c_char_p, i32],
+    "fvk_ln_modulate_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
+    "fvk_scale_residual_bf16": [vp, vp, vp, vp, i32, i32, i32, vp],
+    "fvk_rmsnorm_rope_bf16": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, i32, i32, i32, i32, i64, i64, f32, vp],
+    "fvk_v_transpose_bf16": [vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp],
+    "fvk_gemm_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i32, vp, vp, i32, vp],
+    "fvk_gemm_bf16_batched": [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i64, i32, f32, vp],
+    "fvk_attn_dense_bf16": [C.POINTER(AttnArgs), vp],
+    "fvk_attn_block_sparse_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, vp],
+    "fvk_attn_sta_bf16": [C.POINTER(AttnArgs), i32, i32, i32, i32, C.POINTER(C.c_int32), vp],
+    "fvk_vsa_build_metadata_host": [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp],
+    "fvk_gather_rows_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, vp],
+    "fvk_block_mean_bf16": [vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, vp],
+    "fvk_topk_mask": [vp, i32, vp, i32, i32, i32, vp],
+    "fvk_map_to_index": [vp, vp, vp, i32, i32, vp],
+    "fvk_softmax_rows_bf16": [vp, vp, i32, i32, vp],
+    "fvk_vsa_combine_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, vp],
+    "fvk_patchify_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "fvk_unpatchify_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
+    "fvk_timestep_embedding_bf16": [vp, vp, i32, i32, f32, vp],
+    "fvk_silu_bf16": [vp, vp, i64, vp],
+}
+_RESTYPES = {"fvk_last_error": C.c_char_p}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the library.  Raises RuntimeError when it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(hipcc --offload-arch=gfx950).  fastvideo_amd has no CPU / eager fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    if lib.fvk_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libfvk_amd.so ABI {lib.fvk_abi_version()} != expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().fvk_last_error()
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

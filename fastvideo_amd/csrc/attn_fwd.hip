@@ -1,0 +1,341 @@
+// Flash-style attention forward for head_dim 128 on gfx950 (v_mfma_f32_32x32x16_bf16), with three KV-tile
+// iterators sharing one body: dense, block-sparse (VSA sparse branch) and sliding-tile (STA).
+//
+// Structure (per workgroup = NW waves x 32 query rows; KV tile = 64 keys):
+//   * "Swapped" products so the softmax row is lane-local (guide T12 idea, taken one step further):
+//       S^T = K · Q^T   : A = K tile rows (ds_read_b128 from LDS), B = Q rows (registers, loaded once)
+//                         -> lane (q = lane&31, hi = lane>>5) holds 32 of the 64 scores of query row q;
+//                         the other 32 sit in lane^32, so a row max/sum is an in-lane reduction + ONE
+//                         cross-half exchange.
+//       O^T = V^T · P^T : B = P^T is *exactly* the bf16-packed S^T accumulator registers — no LDS round trip and
+//                         no lane exchange — because V^T is stored (by fvk_v_transpose_bf16) with the keys
+//                         of every 16-group permuted into the accumulator's row order ((r&3)+8(r>>2)+4hi).
+//                         A = V^T tile rows (ds_read_b128).  The O rescale factor is a per-lane scalar.
+//   * K / V^T tiles: global -> registers -> LDS, double-buffered, next tile's loads issued before this tile's
+//     MFMAs and written after them (guide T14), one barrier per tile.  16-B chunk XOR swizzles make every
+//     fragment read conflict-free (K rows are 256 B: chunk ^= row&15; V^T rows are 128 B: chunk ^= (row>>1)&7).
+//   * fp32 online softmax in the exp2 domain; the accumulator rescale is skipped (exactly) when no row's
+//     running max moved in this tile; P is rounded to bf16 (RNE) before P·V, like the reference kernels
+//     (block_sparse_attn_triton.py:152, st_attn_triton.py:84).
+#include "fvk_common.h"
+
+namespace {
+
+enum { MODE_DENSE = 0, MODE_BLOCKS = 1, MODE_STA = 2 };
+
+struct ModeArgs {
+    // block-sparse
+    const int32_t* q2k_idx;
+    const int32_t* q2k_num;
+    const int32_t* kv_block_sizes;
+    int max_kv;
+    // STA
+    int ct, ch, cw, tile_tokens;
+    int win[3 * 64];
+};
+
+constexpr int K_TILE_BYTES = 64 * 128 * 2;   // 16 KiB
+constexpr int STAGE_BYTES = 2 * K_TILE_BYTES;  // K + V^T
+
+template <int NW, int MODE>
+__global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fvk_attn_args a, ModeArgs ma) {
+    constexpr int NT = NW * 64;
+    constexpr int BMQ = NW * 32;
+    constexpr int CPT = 1024 / NT;  // 16-B chunks per thread per tile (K and V^T each)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nqb = (a.Sq + BMQ - 1) / BMQ;
+    const int qb = blockIdx.x % nqb;
+    const int h = (blockIdx.x / nqb) % a.H;
+    const int b = blockIdx.x / (nqb * a.H);
+
+    const bf16_t* qp = (const bf16_t*)a.q + (long)b * a.q_bs + (long)h * a.q_hs;
+    const bf16_t* kp = (const bf16_t*)a.k + (long)b * a.k_bs + (long)h * a.k_hs;
+    const bf16_t* vtp = (const bf16_t*)a.vt + ((long)b * a.H + h) * 128L * a.Skv_pad;
+    bf16_t* op = (bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs;
+
+    // ---- KV-tile iterator -------------------------------------------------------------------------------
+    int n_tiles;
+    const int32_t* blk_list = nullptr;
+    int sta_t0 = 0, sta_h0 = 0, sta_w0 = 0, sta_nh = 1, sta_nw = 1, sta_sub = 1;
+    if (MODE == MODE_DENSE) {
+        n_tiles = (a.Skv + 63) >> 6;
+    } else if (MODE == MODE_BLOCKS) {
+        const long meta = ((long)b * a.H + h) * nqb + qb;
+        n_tiles = ma.q2k_num[meta];
+        blk_list = ma.q2k_idx + meta * ma.max_kv;
+    } else {
+        const int qt = (qb * BMQ) / ma.tile_tokens;
+        const int qt_t = qt / (ma.ch * ma.cw), qt_h = (qt / ma.cw) % ma.ch, qt_w = qt % ma.cw;
+        const int kt = ma.win[3 * h], kh = ma.win[3 * h + 1], kw = ma.win[3 * h + 2];
+        auto win = [](int q, int n, int k, int& s0, int& cnt) {
+            int c = q < k / 2 ? k / 2 : q;
+            const int hi_c = (n - 1) - k / 2;
+            c = c > hi_c ? hi_c : c;
+            int s = c - k / 2, e = c + k / 2 + 1;
+            s = s < 0 ? 0 : s;
+            e = e > n ? n : e;
+            s0 = s;
+            cnt = e - s;
+        };
+        int nt_, nh_, nw_;
+        win(qt_t, ma.ct, kt, sta_t0, nt_);
+        win(qt_h, ma.ch, kh, sta_h0, nh_);
+        win(qt_w, ma.cw, kw, sta_w0, nw_);
+        sta_nh = nh_;
+        sta_nw = nw_;
+        sta_sub = ma.tile_tokens >> 6;
+        n_tiles = nt_ * nh_ * nw_ * sta_sub;
+    }
+    auto get_tile = [&](int j, int& kv0, int& valid) {
+        if (MODE == MODE_DENSE) {
+            kv0 = j << 6;
+            const int rem = a.Skv - kv0;
+            valid = rem < 64 ? rem : 64;
+        } else if (MODE == MODE_BLOCKS) {
+            const int id = blk_list[j];
+            kv0 = id << 6;
+            valid = ma.kv_block_sizes[id];
+        } else {
+            const int sub = j % sta_sub;
+            int wi = j / sta_sub;
+            const int w = wi % sta_nw; wi /= sta_nw;
+            const int hh = wi % sta_nh;
+            const int t = wi / sta_nh;
+            const int tile = ((sta_t0 + t) * ma.ch + (sta_h0 + hh)) * ma.cw + (sta_w0 + w);
+            kv0 = tile * ma.tile_tokens + (sub << 6);
+            valid = 64;
+        }
+    };
+
+    // ---- Q fragments (B operand): row q0 + l31, d = 16*ks + 8*hi .. +8 -----------------------------------
+    const int q0 = qb * BMQ + wave * 32;
+    int qrow = q0 + l31;
+    const bool q_ok = qrow < a.Sq;
+    qrow = q_ok ? qrow : a.Sq - 1;
+    bf16x8 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = ld_bf16x8(qp + (long)qrow * a.q_ss + ks * 16 + hi * 8);
+
+    // ---- staging assignment ------------------------------------------------------------------------------
+    int k_row[CPT], k_goff[CPT], k_soff[CPT], v_soff[CPT];
+    long v_goff[CPT];
+#pragma unroll
+    for (int i = 0; i < CPT; ++i) {
+        const int c = tid + NT * i;
+        const int kr = c >> 4, kc = c & 15;
+        k_row[i] = kr;
+        k_goff[i] = kc * 8;
+        k_soff[i] = kr * 256 + ((kc ^ (kr & 15)) << 4);
+        const int vr = c >> 3, vc = c & 7;
+        v_goff[i] = (long)vr * a.Skv_pad + vc * 8;
+        v_soff[i] = K_TILE_BYTES + vr * 128 + ((vc ^ ((vr >> 1) & 7)) << 4);
+    }
+    // fragment read bases
+    const int kx = l31 & 15;
+    const int k_rbase = l31 * 256;
+    const int vx = (l31 >> 1) & 7;
+    const int v_rbase = K_TILE_BYTES + l31 * 128;
+
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const float c2 = a.scale * 1.4426950408889634f;
+
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 rk[CPT], rv[CPT];
+#define ISSUE_LOADS(KV0)                                                                         \
+    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                            \
+        int kr_ = (KV0) + k_row[i];                                                              \
+        kr_ = kr_ < a.Skv ? kr_ : a.Skv - 1;                                                     \
+        rk[i] = *reinterpret_cast<const u32x4*>(kp + (long)kr_ * a.k_ss + k_goff[i]);           \
+        rv[i] = *reinterpret_cast<const u32x4*>(vtp + v_goff[i] + (KV0));                        \
+    }
+#define WRITE_STAGE(ST)                                                                          \
+    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                            \
+        *reinterpret_cast<u32x4*>((ST) + k_soff[i]) = rk[i];                                     \
+        *reinterpret_cast<u32x4*>((ST) + v_soff[i]) = rv[i];                                     \
+    }
+
+    int kv0 = 0, valid = 64, kv0_n = 0, valid_n = 64;
+    if (n_tiles > 0) {
+        get_tile(0, kv0, valid);
+        ISSUE_LOADS(kv0)
+        WRITE_STAGE(smem)
+    }
+    __syncthreads();
+
+    for (int j = 0; j < n_tiles; ++j) {
+        const unsigned char* cur = smem + (j & 1) * STAGE_BYTES;
+        const bool more = (j + 1) < n_tiles;
+        if (more) {
+            get_tile(j + 1, kv0_n, valid_n);
+            ISSUE_LOADS(kv0_n)
+        }
+        // ---- S^T = K · Q^T  (2 key blocks of 32 x 8 k-steps of 16) --------------------------------------
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cur + k_rbase + kb * 32 * 256 + (((2 * ks + hi) ^ kx) << 4));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            }
+        }
+        // ---- online softmax (row q = lane&31; this lane holds 32 of its 64 scores) ------------------------
+        if (valid < 64) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= valid) s[kb][r] = -INFINITY;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        if (!__all(m_new == m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            m_run = m_new;
+        }
+        const float mc = m_run * c2;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -mc));
+                s[kb][r] = p;
+                psum += p;
+            }
+        l_run += psum;
+        // ---- O^T += V^T · P^T  (4 d-blocks of 32 x 4 k-steps of 16 keys) ---------------------------------
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 pf;
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)s[kk >> 1][(kk & 1) * 8 + jj];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cur + v_rbase + d * 32 * 128 + (((2 * kk + hi) ^ vx) << 4));
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
+            }
+        }
+        if (more) {
+            unsigned char* nxt = smem + ((j + 1) & 1) * STAGE_BYTES;
+            WRITE_STAGE(nxt)
+            kv0 = kv0_n;
+            valid = valid_n;
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (q_ok) {
+        bf16_t* orow = op + (long)qrow * a.o_ss;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(o[d][g * 4 + e] * inv);
+                *reinterpret_cast<bf16x4*>(orow + d * 32 + g * 8 + hi * 4) = v4;
+            }
+        if (a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow] = m_run * c2 + log2f(l_tot);
+    }
+}
+
+int check_common(const fvk_attn_args* a, const char* fn) {
+    FVK_CHECK(a && a->q && a->k && a->vt && a->o, FVK_ERR_ARG, "%s: null pointer", fn);
+    FVK_CHECK(a->B > 0 && a->H > 0 && a->Sq > 0 && a->Skv > 0, FVK_ERR_ARG, "%s: empty shape B=%d H=%d Sq=%d Skv=%d", fn,
+              a->B, a->H, a->Sq, a->Skv);
+    FVK_CHECK(a->Skv_pad % 64 == 0 && a->Skv_pad >= a->Skv, FVK_ERR_ARG, "%s: Skv_pad=%d must be a multiple of 64 >= Skv=%d", fn,
+              a->Skv_pad, a->Skv);
+    FVK_CHECK(a->q_ss % 8 == 0 && a->k_ss % 8 == 0 && a->o_ss % 4 == 0 && a->q_hs % 8 == 0 && a->k_hs % 8 == 0 &&
+                  a->o_hs % 4 == 0 && a->q_bs % 8 == 0 && a->k_bs % 8 == 0 && a->o_bs % 4 == 0,
+              FVK_ERR_ARG, "%s: strides must keep 16-byte alignment of head rows", fn);
+    return FVK_OK;
+}
+
+template <int NW, int MODE>
+int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                2 * STAGE_BYTES) != hipSuccess) {
+            fvk_set_error("fvk_attn: cannot set dynamic LDS size");
+            return FVK_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    const int bmq = NW * 32;
+    const long nblk = (long)((a->Sq + bmq - 1) / bmq) * a->H * a->B;
+    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE>), dim3((unsigned)nblk), dim3(NW * 64), 2 * STAGE_BYTES, s, *a, ma);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+}  // namespace
+
+extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
+    int rc = check_common(a, "fvk_attn_dense_bf16");
+    if (rc) return rc;
+    ModeArgs ma{};
+    return launch<4, MODE_DENSE>(a, ma, (hipStream_t)stream);
+}
+
+extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
+                                          const int32_t* kv_block_sizes, int max_kv, void* stream) {
+    int rc = check_common(a, "fvk_attn_block_sparse_bf16");
+    if (rc) return rc;
+    FVK_CHECK(q2k_idx && q2k_num && kv_block_sizes && max_kv > 0, FVK_ERR_ARG, "fvk_attn_block_sparse_bf16: null index arrays");
+    FVK_CHECK(a->Sq % 64 == 0 && a->Skv % 64 == 0, FVK_ERR_ARG,
+              "fvk_attn_block_sparse_bf16: Sq=%d and Skv=%d must be multiples of the 64-token block", a->Sq, a->Skv);
+    ModeArgs ma{};
+    ma.q2k_idx = q2k_idx;
+    ma.q2k_num = q2k_num;
+    ma.kv_block_sizes = kv_block_sizes;
+    ma.max_kv = max_kv;
+    return launch<2, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
+}
+
+extern "C" int fvk_attn_sta_bf16(const fvk_attn_args* a, int ct, int ch, int cw, int tile_tokens, const int32_t* win_host,
+                                 void* stream) {
+    int rc = check_common(a, "fvk_attn_sta_bf16");
+    if (rc) return rc;
+    FVK_CHECK(win_host && a->H <= 64, FVK_ERR_ARG, "fvk_attn_sta_bf16: need window list and H <= 64 (H=%d)", a->H);
+    FVK_CHECK(ct > 0 && ch > 0 && cw > 0 && tile_tokens > 0 && tile_tokens % 128 == 0, FVK_ERR_ARG,
+              "fvk_attn_sta_bf16: tile_tokens=%d must be a positive multiple of 128", tile_tokens);
+    FVK_CHECK((long)ct * ch * cw * tile_tokens == a->Sq && a->Sq == a->Skv, FVK_ERR_ARG,
+              "fvk_attn_sta_bf16: canvas %dx%dx%d tiles x %d tokens != Sq=%d / Skv=%d", ct, ch, cw, tile_tokens, a->Sq, a->Skv);
+    ModeArgs ma{};
+    ma.ct = ct; ma.ch = ch; ma.cw = cw; ma.tile_tokens = tile_tokens;
+    for (int i = 0; i < 3 * a->H; ++i) {
+        FVK_CHECK(win_host[i] >= 1 && (win_host[i] & 1), FVK_ERR_ARG, "fvk_attn_sta_bf16: window sizes must be odd and >= 1");
+        ma.win[i] = win_host[i];
+    }
+    return launch<4, MODE_STA>(a, ma, (hipStream_t)stream);
+}

@@ -1,0 +1,31 @@
+// Error plumbing + introspection for libfvk_amd.so (host only).
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "fvk_common.h"
+
+static thread_local char g_err[512] = "";
+
+void fvk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* fvk_last_error(void) { return g_err; }
+extern "C" int fvk_abi_version(void) { return 1; }
+
+extern "C" int fvk_device_arch(char* buf, int len) {
+    if (!buf || len <= 0) return FVK_ERR_ARG;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+        fvk_set_error("fvk_device_arch: no HIP device");
+        return FVK_ERR_LAUNCH;
+    }
+    strncpy(buf, prop.gcnArchName, len - 1);
+    buf[len - 1] = 0;
+    return FVK_OK;
+}

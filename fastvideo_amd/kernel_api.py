@@ -1,0 +1,155 @@
+"""Drop-in for the public surface of the reference's separate kernel wheel ``fastvideo_kernel``
+(fastvideo-kernel/python/fastvideo_kernel/__init__.py:40-62) — same names, argument meaning and error
+behaviour, MI355X HIP kernels underneath.  With ``sys.modules['fastvideo_kernel'] = fastvideo_amd.kernel_api``
+ the reference's unmodified ``VideoSparseAttentionBackend`` runs on gfx950
+(fastvideo/attention/backends/video_sparse_attn.py:8-15 imports these names at module import).
+
+Layouts: ``[B, H, S, D]`` as in the reference functions.  bf16 only (the reference kernels are bf16 only:
+fastvideo-kernel/csrc/attention/st_attn_h100.cu:386-411, block_sparse_h100.cu:700-717)."""
+from __future__ import annotations
+
+import functools
+import math
+
+import torch
+
+from . import ops
+
+VSA_TILE_SIZE = (4, 4, 4)  # ref: fastvideo_kernel/vsa_utils.py / video_sparse_attn.py:28
+
+
+# ------------------------------------------------------------------ index helpers (ref: vsa_utils.py:30-156)
+@functools.lru_cache(maxsize=16)
+def _meta(dit_seq_shape, tile_size):
+    return ops.vsa_build_metadata_host(tuple(dit_seq_shape), tuple(tile_size))
+
+
+def get_tile_partition_indices(dit_seq_shape, tile_size=VSA_TILE_SIZE, device="cpu"):
+    return _meta(tuple(dit_seq_shape), tuple(tile_size))["tile_partition_indices"].long().to(device)
+
+
+def get_reverse_tile_partition_indices(dit_seq_shape, tile_size=VSA_TILE_SIZE, device="cpu"):
+    return _meta(tuple(dit_seq_shape), tuple(tile_size))["reverse_tile_partition_indices"].long().to(device)
+
+
+def construct_variable_block_sizes(dit_seq_shape, num_tiles=None, device="cpu", tile_size=VSA_TILE_SIZE):
+    m = _meta(tuple(dit_seq_shape), tuple(tile_size))
+    if num_tiles is not None and tuple(num_tiles) != m["num_tiles"]:
+        raise ValueError(f"num_tiles {tuple(num_tiles)} inconsistent with shape/tile ({m['num_tiles']})")
+    return m["variable_block_sizes"].to(device)
+
+
+def get_non_pad_index(variable_block_sizes, max_block_size):
+    vbs = variable_block_sizes
+    n = vbs.shape[0]
+    pad = torch.arange(n, device=vbs.device)[:, None] * max_block_size + torch.arange(max_block_size, device=vbs.device)[None, :]
+    return pad[torch.arange(max_block_size, device=vbs.device)[None, :] < vbs[:, None]]
+
+
+def build_vsa_metadata(dit_seq_shape, tile_size=VSA_TILE_SIZE, device="cpu"):
+    """ref: vsa_utils.py build_vsa_metadata — same keys; volumes other than 64/128/256 are refused."""
+    vol = math.prod(tile_size)
+    if vol not in (64, 128, 256):
+        raise ValueError(f"Unsupported VSA tile volume {vol}")
+    m = _meta(tuple(dit_seq_shape), tuple(tile_size))
+    return {
+        "tile_partition_indices": m["tile_partition_indices"].long().to(device),
+        "reverse_tile_partition_indices": m["reverse_tile_partition_indices"].long().to(device),
+        "variable_block_sizes": m["variable_block_sizes"].to(device),
+        "non_pad_index": m["non_pad_index"].long().to(device),
+        "num_tiles": m["num_tiles"],
+        "max_block_size": vol,
+    }
+
+
+# ------------------------------------------------------------------ attention entry points
+def _check_bf16(*ts):
+    for t in ts:
+        if t.dtype != torch.bfloat16:
+            raise RuntimeError(f"fastvideo_amd kernels are bf16 only, got {t.dtype}")
+
+
+def block_sparse_attn_from_indices(q, k, v, q2k_idx, q2k_num, variable_block_sizes):
+    """ref: fastvideo_kernel/block_sparse_attn.py (``block_sparse_attn_from_indices``) -> (o, lse)."""
+    _check_bf16(q, k, v)
+    return ops.attn_block_sparse(q, k, v, q2k_idx.int(), q2k_num.int(), variable_block_sizes.int(), layout="bhsd",
+                                 return_lse=True)
+
+
+def block_sparse_attn(q, k, v, block_map, variable_block_sizes):
+    """ref: fastvideo_kernel/block_sparse_attn.py:103-145 — bool block map [B,H,Nq,Nkv] -> (o, lse)."""
+    idx, num = ops.map_to_index(block_map)
+    return block_sparse_attn_from_indices(q, k, v, idx, num, variable_block_sizes)
+
+
+def video_sparse_attn(q, k, v, variable_block_sizes, q_variable_block_sizes, topk, block_size=64,
+                      compress_attn_weight=None, return_intermediates=False):
+    """ref: fastvideo_kernel/ops.py:65-133.  q,k,v(,gate) [B,H,S_pad,D] bf16, tile-major, zero padded."""
+    if isinstance(block_size, int):
+        block_size = (block_size, block_size, block_size)
+    block_elements = block_size[0] * block_size[1] * block_size[2]
+    batch, heads, q_seq_len, dim = q.shape
+    kv_seq_len = k.shape[2]
+    if k.shape[0] != batch or v.shape[0] != batch or k.shape[1] != heads or v.shape[1] != heads:
+        raise ValueError("Expected q/k/v to have the same batch and head dimensions.")
+    if v.shape[2] != kv_seq_len:
+        raise ValueError(f"Expected k and v to have the same sequence length, got k.shape[2]={kv_seq_len}, "
+                         f"v.shape[2]={v.shape[2]}")
+    if block_elements != 64:
+        raise ValueError(f"fastvideo_amd implements the 64-token VSA block only (got block_elements={block_elements})")
+    if q_seq_len % block_elements != 0 or kv_seq_len % block_elements != 0:
+        raise ValueError(f"q_seq_len and kv_seq_len must be divisible by block_elements={block_elements}, "
+                         f"got q_seq_len={q_seq_len}, kv_seq_len={kv_seq_len}")
+    q_num_blocks, kv_num_blocks = q_seq_len // block_elements, kv_seq_len // block_elements
+    if variable_block_sizes.numel() != kv_num_blocks:
+        raise ValueError(f"variable_block_sizes must have length kv_num_blocks={kv_num_blocks}, got {variable_block_sizes.numel()}")
+    if q_variable_block_sizes.numel() != q_num_blocks:
+        raise ValueError(f"q_variable_block_sizes must have length q_num_blocks={q_num_blocks}, got {q_variable_block_sizes.numel()}")
+    _check_bf16(q, k, v)
+    vbs = variable_block_sizes.to(device=q.device, dtype=torch.int32)
+    qvbs = q_variable_block_sizes.to(device=q.device, dtype=torch.int32)
+
+    # compression branch (ops.py:108-118): block means, coarse scores (bf16, /sqrt(D)), coarse attention
+    q_c = ops.block_mean(q, qvbs, block_elements)
+    k_c = ops.block_mean(k, vbs, block_elements)
+    v_c = ops.block_mean(v, vbs, block_elements)
+    scores = ops.gemm_batched(q_c.view(batch * heads, q_num_blocks, dim), k_c.view(batch * heads, kv_num_blocks, dim),
+                              epilogue=ops.EPI_DIV, scalar=dim**0.5).view(batch, heads, q_num_blocks, kv_num_blocks)
+    out_c = ops.attn_dense(q_c, k_c, v_c, scale=dim**-0.5, layout="bhsd")
+    # sparse branch (ops.py:120-128): exact top-k mask -> ascending index lists -> block-sparse attention
+    mask = ops.topk_mask(scores, min(int(topk), kv_num_blocks))
+    idx, num = ops.map_to_index(mask)
+    out_s = ops.attn_block_sparse(q, k, v, idx, num, vbs, layout="bhsd")
+    out = ops.vsa_combine(out_c, out_s, compress_attn_weight, block_elements, layout="bhsd")
+    if return_intermediates:
+        return out, dict(q_c=q_c, k_c=k_c, v_c=v_c, scores=scores, mask=mask, q2k_idx=idx, q2k_num=num, out_c=out_c,
+                         out_s=out_s)
+    return out
+
+
+_STA_CANVAS = {"30x48x80": (30, 48, 80), "36x48x48": (36, 48, 48), "18x48x80": (18, 48, 80)}
+
+
+def sliding_tile_attention(q, k, v, window_size, text_length=0, has_text=False, seq_shape="18x48x80",
+                           tile_size=(6, 8, 8)):
+    """ref: fastvideo_kernel/ops.py:21-62.  q,k,v [B,H,S,D] bf16, tokens in tile-major order; ``window_size`` is a
+    per-head list of (t,h,w) windows in tiles.  ``seq_shape`` is "TxHxW" (the reference's three canvases or any
+    other canvas divisible by ``tile_size`` — the reference kernels hard-code theirs).
+    Text tokens (HunyuanVideo/StepVideo variants) are not part of the Wan path and are refused."""
+    if has_text or text_length:
+        raise NotImplementedError("sliding_tile_attention: text tokens are not supported on the Wan T2V path")
+    _check_bf16(q, k, v)
+    canvas = _STA_CANVAS.get(seq_shape) or tuple(int(x) for x in seq_shape.split("x"))
+    if any(c % t for c, t in zip(canvas, tile_size)):
+        raise ValueError(f"canvas {canvas} is not divisible by tile {tile_size}")
+    tiles = tuple(c // t for c, t in zip(canvas, tile_size))
+    if len(window_size) != q.shape[1]:
+        raise ValueError(f"window_size must list one (t,h,w) per head ({q.shape[1]}), got {len(window_size)}")
+    return ops.attn_sta(q, k, v, tiles, math.prod(tile_size), window_size, layout="bhsd")
+
+
+__all__ = [
+    "sliding_tile_attention", "video_sparse_attn", "block_sparse_attn", "block_sparse_attn_from_indices", "VSA_TILE_SIZE",
+    "get_tile_partition_indices", "get_reverse_tile_partition_indices", "construct_variable_block_sizes",
+    "get_non_pad_index", "build_vsa_metadata",
+]

@@ -1,0 +1,353 @@
+"""torch.Tensor front-ends of the C ABI (include/fvk_amd.h).  PyTorch is plumbing here: device memory,
+the current HIP stream, and output allocation; every computation below is a hand-written gfx950 kernel in
+libfvk_amd.so.  All functions require ROCm tensors and raise on anything else — no eager fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import AttnArgs
+
+BF16 = torch.bfloat16
+EPI_NONE, EPI_GELU_TANH, EPI_SILU, EPI_RESIDUAL_GATE, EPI_DIV = 0, 1, 2, 3, 4
+LN_ROUND_RESIDUAL, LN_ROUND_NORM = 1, 2
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t: torch.Tensor, dtype, name: str):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"fastvideo_amd: {name} must be a ROCm device tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"fastvideo_amd: {name} must be {dtype}, got {t.dtype}")
+    return t
+
+
+def _f32(t, name):
+    if t is None:
+        return None
+    return _chk(t, torch.float32, name).contiguous()
+
+
+# ------------------------------------------------------------------ norm / modulate
+def ln_modulate(x, *, residual=None, gate=None, ln_w=None, ln_b=None, mul=None, add=None, eps=1e-6,
+                round_residual=False, round_norm=False, want_residual=False, rows_per_batch=None):
+    """See fvk_ln_modulate_bf16.  x/residual bf16 [..., d]; gate/mul/add fp32 [B, d] (or [B,1,d])."""
+    _chk(x, BF16, "x")
+    d = x.shape[-1]
+    x2 = x.contiguous().view(-1, d)
+    M = x2.shape[0]
+    res2 = None
+    if residual is not None:
+        res2 = _chk(residual, BF16, "residual").contiguous().view(-1, d)
+    B = 1
+    for t in (gate, mul, add):
+        if t is not None:
+            B = max(B, t.numel() // d)
+    if rows_per_batch is None:
+        rows_per_batch = max(M // B, 1)
+    out = torch.empty_like(x2)
+    res_out = torch.empty_like(x2) if want_residual else None
+    flags = (LN_ROUND_RESIDUAL if round_residual else 0) | (LN_ROUND_NORM if round_norm else 0)
+    gate, mul, add, ln_w, ln_b = (_f32(t, n) for t, n in ((gate, "gate"), (mul, "mul"), (add, "add"),
+                                                          (ln_w, "ln_w"), (ln_b, "ln_b")))
+    _lib.call("fvk_ln_modulate_bf16", _p(x2), _p(res2), _p(gate), _p(ln_w), _p(ln_b), _p(mul), _p(add), _p(res_out),
+              _p(out), M, d, rows_per_batch, float(eps), flags, _stream())
+    out = out.view(x.shape)
+    return (out, res_out.view(x.shape)) if want_residual else out
+
+
+def scale_residual(residual, x, gate=None, rows_per_batch=None):
+    _chk(x, BF16, "x"), _chk(residual, BF16, "residual")
+    d = x.shape[-1]
+    x2, r2 = x.contiguous().view(-1, d), residual.contiguous().view(-1, d)
+    M = x2.shape[0]
+    gate = _f32(gate, "gate")
+    B = 1 if gate is None else gate.numel() // d
+    out = torch.empty_like(x2)
+    _lib.call("fvk_scale_residual_bf16", _p(r2), _p(x2), _p(gate), _p(out), M, d, rows_per_batch or max(M // B, 1), _stream())
+    return out.view(x.shape)
+
+
+def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_len=None, eps=1e-6, outs=None):
+    """tensors: list (<=3) of bf16 2-D views [M, width] sharing one row stride (e.g. q,k column slices of a fused
+    QKV buffer).  Returns a list of new contiguous [M, width] tensors (or writes `outs`)."""
+    n = len(tensors)
+    M, width = tensors[0].shape
+    stride = tensors[0].stride(0)
+    for t in tensors:
+        _chk(t, BF16, "tensor")
+        if t.shape != (M, width) or t.stride(1) != 1 or t.stride(0) != stride:
+            raise RuntimeError("rmsnorm_rope: tensors must be [M,width] views with unit column stride and a common row stride")
+    if outs is None:
+        outs = [torch.empty((M, width), dtype=BF16, device=tensors[0].device) for _ in range(n)]
+    ostride = outs[0].stride(0)
+    arr = C.c_void_p * n
+    ins = arr(*[t.data_ptr() for t in tensors])
+    os_ = arr(*[t.data_ptr() for t in outs])
+    ws = None
+    keep = []
+    if weights is not None:
+        keep = [None if w is None else _chk(w, BF16, "weight").contiguous() for w in weights]
+        ws = arr(*[0 if w is None else w.data_ptr() for w in keep])
+    cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
+    _lib.call("fvk_rmsnorm_rope_bf16", ins, os_, ws, n, _p(cos), _p(sin), M, width, head_dim, seq_len or M, stride, ostride,
+              float(eps), _stream())
+    return outs
+
+
+def v_transpose(v):
+    """v: bf16 [B,S,H,128] view (any strides with unit stride on D).  -> Vt [B,H,128,S_pad] (keys permuted, pad 0)."""
+    _chk(v, BF16, "v")
+    B, S, H, D = v.shape
+    if v.stride(3) != 1:
+        v = v.contiguous()
+    S_pad = (S + 63) // 64 * 64
+    vt = torch.empty((B, H, D, S_pad), dtype=BF16, device=v.device)
+    _lib.call("fvk_v_transpose_bf16", _p(v), _p(vt), B, S, H, D, v.stride(1), v.stride(0), v.stride(2), S_pad, _stream())
+    return vt
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm(x, w, bias=None, epilogue=EPI_NONE, residual=None, gate=None, rows_per_batch=None, out=None):
+    """out[..., N] = epilogue(x[..., K] @ w[N, K]^T + bias).  x may be a 2-D view with a row stride."""
+    _chk(x, BF16, "x"), _chk(w, BF16, "w")
+    K = x.shape[-1]
+    N = w.shape[0]
+    if x.dim() == 2 and x.stride(1) == 1:
+        x2 = x
+    else:
+        x2 = x.contiguous().view(-1, K)
+    M = x2.shape[0]
+    w = w.contiguous()
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=x.device)
+    res2 = None
+    if residual is not None:
+        res2 = _chk(residual, BF16, "residual").contiguous().view(-1, N)
+    gate = _f32(gate, "gate")
+    if rows_per_batch is None:
+        B = 1 if gate is None else gate.numel() // N
+        rows_per_batch = max(M // B, 1)
+    if bias is not None:
+        bias = _chk(bias, BF16, "bias").contiguous()
+    _lib.call("fvk_gemm_bf16", _p(x2), _p(w), _p(bias), _p(out), M, N, K, x2.stride(0), out.stride(0), epilogue, _p(res2),
+              _p(gate), rows_per_batch, _stream())
+    return out.view(*x.shape[:-1], N) if x.dim() != 2 else out
+
+
+def gemm_batched(x, w, epilogue=EPI_NONE, scalar=1.0):
+    """x [Bt, M, K], w [Bt, N, K] contiguous bf16 -> [Bt, M, N]."""
+    _chk(x, BF16, "x"), _chk(w, BF16, "w")
+    x, w = x.contiguous(), w.contiguous()
+    Bt, M, K = x.shape
+    N = w.shape[1]
+    out = torch.empty((Bt, M, N), dtype=BF16, device=x.device)
+    _lib.call("fvk_gemm_bf16_batched", _p(x), _p(w), _p(out), Bt, M, N, K, K, N, M * K, N * K, M * N, epilogue, float(scalar),
+              _stream())
+    return out
+
+
+# ------------------------------------------------------------------ attention
+def _attn_args(q, k, vt, o, scale, layout, lse=None):
+    """layout 'bshd': q [B,S,H,D]; 'bhsd': q [B,H,S,D]."""
+    for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (o, "o")):
+        _chk(t, BF16, n)
+    if q.stride(-1) != 1 or k.stride(-1) != 1 or o.stride(-1) != 1:
+        raise RuntimeError("attention: head_dim must be the unit-stride dimension")
+    if layout == "bshd":
+        B, Sq, H, D = q.shape
+        Skv = k.shape[1]
+        st = lambda t: (t.stride(0), t.stride(1), t.stride(2))
+    else:
+        B, H, Sq, D = q.shape
+        Skv = k.shape[2]
+        st = lambda t: (t.stride(0), t.stride(2), t.stride(1))
+    if D != 128:
+        raise RuntimeError(f"attention: head_dim {D} != 128")
+    a = AttnArgs()
+    a.q, a.k, a.vt, a.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
+    a.lse = None if lse is None else lse.data_ptr()
+    a.B, a.H, a.Sq, a.Skv, a.Skv_pad = B, H, Sq, Skv, vt.shape[-1]
+    a.q_bs, a.q_ss, a.q_hs = st(q)
+    a.k_bs, a.k_ss, a.k_hs = st(k)
+    a.o_bs, a.o_ss, a.o_hs = st(o)
+    a.scale = float(scale)
+    return a
+
+
+def _vt_of(v, layout):
+    return v_transpose(v if layout == "bshd" else v.transpose(1, 2))
+
+
+def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None):
+    """Dense non-causal attention.  Pass v (same layout as k) or a precomputed vt = v_transpose(v)."""
+    scale = q.shape[-1]**-0.5 if scale is None else scale
+    if vt is None:
+        vt = _vt_of(v, layout)
+    o = torch.empty_like(q) if out is None else out
+    a = _attn_args(q, k, vt, o, scale, layout)
+    _lib.call("fvk_attn_dense_bf16", C.byref(a), _stream())
+    return o
+
+
+def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, layout="bhsd", return_lse=False):
+    scale = q.shape[-1]**-0.5 if scale is None else scale
+    vt = _vt_of(v, layout)
+    o = torch.empty_like(q)
+    B, H = (q.shape[0], q.shape[2]) if layout == "bshd" else (q.shape[0], q.shape[1])
+    Sq = q.shape[1] if layout == "bshd" else q.shape[2]
+    lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device) if return_lse else None
+    a = _attn_args(q, k, vt, o, scale, layout, lse)
+    q2k_idx = _chk(q2k_idx, torch.int32, "q2k_idx").contiguous()
+    q2k_num = _chk(q2k_num, torch.int32, "q2k_num").contiguous()
+    kv_block_sizes = _chk(kv_block_sizes, torch.int32, "kv_block_sizes").contiguous()
+    _lib.call("fvk_attn_block_sparse_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), q2k_idx.shape[-1], _stream())
+    return (o, lse) if return_lse else o
+
+
+def attn_sta(q, k, v, canvas_tiles, tile_tokens, windows, scale=None, layout="bhsd"):
+    """windows: list of (t,h,w) per head, in tiles."""
+    scale = q.shape[-1]**-0.5 if scale is None else scale
+    vt = _vt_of(v, layout)
+    o = torch.empty_like(q)
+    a = _attn_args(q, k, vt, o, scale, layout)
+    flat = [int(x) for w in windows for x in w]
+    arr = (C.c_int32 * len(flat))(*flat)
+    _lib.call("fvk_attn_sta_bf16", C.byref(a), int(canvas_tiles[0]), int(canvas_tiles[1]), int(canvas_tiles[2]), int(tile_tokens),
+              arr, _stream())
+    return o
+
+
+# ------------------------------------------------------------------ VSA pieces
+def vsa_build_metadata_host(dit_seq_shape, tile_size=(4, 4, 4)):
+    """Pure-integer metadata through the C ABI (CPU).  Returns dict of int32 torch CPU tensors."""
+    T, H, W = dit_seq_shape
+    n = T * H * W
+    nt = [math.ceil(s / t) for s, t in zip(dit_seq_shape, tile_size)]
+    perm, rev, npi, unt = (torch.empty(n, dtype=torch.int32) for _ in range(4))
+    vbs = torch.empty(nt[0] * nt[1] * nt[2], dtype=torch.int32)
+    _lib.call("fvk_vsa_build_metadata_host", T, H, W, *tile_size, _p(perm), _p(rev), _p(vbs), _p(npi), _p(unt))
+    return dict(tile_partition_indices=perm, reverse_tile_partition_indices=rev, variable_block_sizes=vbs,
+                non_pad_index=npi, untile_combined_index=unt, num_tiles=tuple(nt))
+
+
+def gather_rows(src, n_dst_rows, src_index=None, dst_index=None, zero_init=False):
+    """src bf16 [B, Ns, ...row...] -> dst [B, n_dst_rows, ...row...]; dst[:, dst_index[i]] = src[:, src_index[i]]."""
+    _chk(src, BF16, "src")
+    src = src.contiguous()
+    B = src.shape[0]
+    row = src[0, 0].numel()
+    alloc = torch.zeros if zero_init else torch.empty
+    dst = alloc((B, n_dst_rows, *src.shape[2:]), dtype=BF16, device=src.device)
+    any_index = src_index if src_index is not None else dst_index
+    n = n_dst_rows if any_index is None else any_index.numel()
+    si = None if src_index is None else _chk(src_index, torch.int32, "src_index")
+    di = None if dst_index is None else _chk(dst_index, torch.int32, "dst_index")
+    _lib.call("fvk_gather_rows_bf16", _p(src), _p(dst), _p(si), _p(di), B, n, row, src.stride(0), dst.stride(0), _stream())
+    return dst
+
+
+def block_mean(x, vbs, block=64, layout="bhsd"):
+    """x [B,H,S_pad,D] (or bshd) -> [B,H,Nblk,D]."""
+    _chk(x, BF16, "x")
+    if layout == "bhsd":
+        B, H, S, D = x.shape
+        bs, hs, ss = x.stride(0), x.stride(1), x.stride(2)
+    else:
+        B, S, H, D = x.shape
+        bs, ss, hs = x.stride(0), x.stride(1), x.stride(2)
+    nb = S // block
+    out = torch.empty((B, H, nb, D), dtype=BF16, device=x.device)
+    vbs = _chk(vbs, torch.int32, "vbs").contiguous()
+    _lib.call("fvk_block_mean_bf16", _p(x), _p(out), _p(vbs), B, H, nb, block, D, bs, ss, hs, _stream())
+    return out
+
+
+def topk_mask(scores, topk):
+    if scores.dtype not in (BF16, torch.float32) or not scores.is_cuda:
+        raise RuntimeError("topk_mask: scores must be a bf16/fp32 device tensor")
+    s = scores.contiguous()
+    n = s.shape[-1]
+    mask = torch.empty(s.shape, dtype=torch.uint8, device=s.device)
+    _lib.call("fvk_topk_mask", _p(s), int(s.dtype == torch.float32), _p(mask), s.numel() // n, n, int(topk), _stream())
+    return mask.view(torch.bool)
+
+
+def map_to_index(mask):
+    m = mask.contiguous().view(torch.uint8)
+    n = m.shape[-1]
+    idx = torch.empty(m.shape, dtype=torch.int32, device=m.device)
+    num = torch.empty(m.shape[:-1], dtype=torch.int32, device=m.device)
+    _lib.call("fvk_map_to_index", _p(m), _p(idx), _p(num), m.numel() // n, n, _stream())
+    return idx, num
+
+
+def softmax_rows(x):
+    _chk(x, BF16, "x")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _lib.call("fvk_softmax_rows_bf16", _p(x), _p(out), x.numel() // x.shape[-1], x.shape[-1], _stream())
+    return out
+
+
+def vsa_combine(out_c, out_s, gate=None, block=64, layout="bhsd"):
+    """out_c [B,H,Nblk,D] contiguous; out_s / gate [B,H,S,D] (bhsd) or [B,S,H,D] (bshd)."""
+    _chk(out_c, BF16, "out_c"), _chk(out_s, BF16, "out_s")
+    out_c = out_c.contiguous()
+    out_s = out_s.contiguous()
+    if gate is not None:
+        gate = _chk(gate, BF16, "gate").contiguous()
+    if layout == "bhsd":
+        B, H, S, D = out_s.shape
+        bs, hs, ss = out_s.stride(0), out_s.stride(1), out_s.stride(2)
+    else:
+        B, S, H, D = out_s.shape
+        bs, ss, hs = out_s.stride(0), out_s.stride(1), out_s.stride(2)
+    out = torch.empty_like(out_s)
+    _lib.call("fvk_vsa_combine_bf16", _p(out_c), _p(out_s), _p(gate), _p(out), B, S, H, D, block, bs, ss, hs, _stream())
+    return out
+
+
+# ------------------------------------------------------------------ glue
+def patchify(latent, patch=(1, 2, 2)):
+    _chk(latent, BF16, "latent")
+    latent = latent.contiguous()
+    B, Cc, T, Hh, W = latent.shape
+    pt, ph, pw = patch
+    out = torch.empty((B, (T // pt) * (Hh // ph) * (W // pw), Cc * pt * ph * pw), dtype=BF16, device=latent.device)
+    _lib.call("fvk_patchify_bf16", _p(latent), _p(out), B, Cc, T, Hh, W, pt, ph, pw, _stream())
+    return out
+
+
+def unpatchify(x, latent_shape, patch=(1, 2, 2)):
+    _chk(x, BF16, "x")
+    x = x.contiguous()
+    B, Cc, T, Hh, W = latent_shape
+    out = torch.empty(latent_shape, dtype=BF16, device=x.device)
+    _lib.call("fvk_unpatchify_bf16", _p(x), _p(out), B, Cc, T, Hh, W, *patch, _stream())
+    return out
+
+
+def timestep_embedding(t, dim, max_period=10000.0):
+    t = t.to(device="cuda", dtype=torch.float32).contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
+    _lib.call("fvk_timestep_embedding_bf16", _p(t), _p(out), t.shape[0], dim, float(max_period), _stream())
+    return out
+
+
+def silu(x):
+    _chk(x, BF16, "x")
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    _lib.call("fvk_silu_bf16", _p(x), _p(out), x.numel(), _stream())
+    return out

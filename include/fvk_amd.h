@@ -1,0 +1,169 @@
+/* fvk_amd.h — C ABI of libfvk_amd.so: the MI355X (gfx950 / CDNA4) kernels behind FastVideo's
+ * per-step Wan video-DiT path.
+ *
+ * Drop-in boundary.  The reference's compiled boundary is the pybind11 module
+ * `fastvideo_kernel._C.fastvideo_kernel_ops` (fastvideo-kernel/csrc/common_extension.cpp:42-69,
+ * functions over torch::Tensor) plus eager PyTorch layer code (fastvideo/layers, fastvideo/attention).
+ * This library replaces what is underneath both with plain pointers + sizes: no torch types, no
+ * allocation, no host synchronisation; every call enqueues on the caller's `hipStream_t` (passed as
+ * `void* stream`, NULL = default stream) and is re-entrant per stream.  All pointers are DEVICE
+ * pointers unless the name ends in `_host`.  Each function returns 0 on success or a negative FVK_ERR_*;
+ * `fvk_last_error()` returns a thread-local message (the Python host raises RuntimeError from it —
+ * the analogue of TORCH_CHECK in fastvideo-kernel/csrc/attention/st_attn_h100.cu:386-411).
+ *
+ * bf16 tensors are raw 16-bit storage (`void*`), fp32 tensors `float*`, indices `int32_t*`.
+ * Citations `ref:` are into /root/reference.
+ */
+#ifndef FVK_AMD_H
+#define FVK_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FVK_OK 0
+#define FVK_ERR_ARG (-1)     /* unsupported shape / null pointer / bad flag   */
+#define FVK_ERR_LAUNCH (-2)  /* hipLaunch / hip runtime error                  */
+
+const char* fvk_last_error(void);
+int fvk_abi_version(void);                 /* bumps when a signature changes */
+int fvk_device_arch(char* buf, int len);   /* gcnArchName of the current device ("gfx950...") */
+
+/* ------------------------------------------------------------------ norm / modulate family (HBM-bound)
+ * ref: fastvideo/layers/layernorm.py:115-125 (FP32LayerNorm), :128-213 (ScaleResidualLayerNormScaleShift),
+ *      :216-273 (LayerNormScaleShift), :91-109 (ScaleResidual); call sites fastvideo/models/dits/wanvideo.py:393,
+ *      :414-431, :746-756.  One fused pass:
+ *          r   = residual ? residual + x * gate : x          (fp32; gate NULL = 1)
+ *          r   = bf16(r)            if FVK_LN_ROUND_RESIDUAL  (bf16+bf16 add of the cross-attn path)
+ *          n   = LayerNorm_fp32(r) [* ln_w + ln_b]
+ *          n   = bf16(n)            if FVK_LN_ROUND_NORM      (FP32LayerNorm on a bf16 input casts back)
+ *          out = bf16(n * mul + add)                          (mul = 1+scale, add = shift; NULL = identity)
+ *          res_out = bf16(r)                                  (optional)
+ * x, residual, out, res_out: bf16 [M, d] contiguous.  gate, mul, add: fp32 [M / rows_per_batch, d].
+ * ln_w, ln_b: fp32 [d].  d % 8 == 0, d <= 8192. */
+#define FVK_LN_ROUND_RESIDUAL 1
+#define FVK_LN_ROUND_NORM 2
+int fvk_ln_modulate_bf16(const void* x, const void* residual, const float* gate, const float* ln_w,
+                         const float* ln_b, const float* mul, const float* add, void* res_out, void* out,
+                         int M, int d, int rows_per_batch, float eps, int flags, void* stream);
+
+/* out = bf16(residual + x * gate) — ScaleResidual (ref: layernorm.py:91-109). gate fp32 [M/rows_per_batch, d]. */
+int fvk_scale_residual_bf16(const void* residual, const void* x, const float* gate, void* out, int M, int d,
+                            int rows_per_batch, void* stream);
+
+/* QK-RMSNorm-across-heads and/or 3-D RoPE on rows of `width` = n_heads*head_dim bf16 elements.
+ * ref: fastvideo/layers/layernorm.py:48-83 (RMSNorm.forward_native: fp32 normalise -> cast bf16 -> * weight),
+ *      fastvideo/layers/rotary_embedding.py:105-135 (_apply_rotary_emb, interleaved pairs, fp32, cast back),
+ *      call sites wanvideo.py:398-401 and fastvideo/attention/layer.py:130-132.
+ * Processes `n_tensors` (1..3) tensors per launch: in[i]/out[i] rows start `in_stride`/`out_stride`
+ * elements apart (so q,k slices of a fused [M,3d] QKV buffer work in place of separate tensors).
+ * weight[i]: bf16 [width] or NULL (skip norm).  cos/sin: fp32 [seq_len, head_dim] or NULL (skip RoPE);
+ * row m uses position m % seq_len.  head_dim % 8 == 0. */
+int fvk_rmsnorm_rope_bf16(const void* const* in, void* const* out, const void* const* weight, int n_tensors,
+                          const float* cos, const float* sin, int M, int width, int head_dim, int seq_len,
+                          long in_stride, long out_stride, float eps, void* stream);
+
+/* V[b, s, h, :] at v + b*in_batch_stride + s*in_stride + h*in_head_stride (elements) -> Vt [B, H, D, S_pad] bf16,
+ * S_pad = round_up(S, 64), pad columns zero.  Within every aligned group of 16 keys the key order is
+ * permuted by swapping bits 2 and 3 of the in-group index (the MFMA-B-operand order of fvk_attn_*; see
+ * DESIGN.md "Vt layout").  D == 128. */
+int fvk_v_transpose_bf16(const void* v, void* vt, int B, int S, int H, int D, long in_stride, long in_batch_stride,
+                         long in_head_stride, int S_pad, void* stream);
+
+/* ------------------------------------------------------------------ dense GEMM (MFMA-bound)
+ * ref: fastvideo/layers/linear.py:146-156 (UnquantizedLinearMethod.apply = F.linear), mlp.py:47-51,
+ *      wanvideo.py:394-396, :411, :430-431.
+ *   y   = bf16( sum_k x[m,k] * w[n,k] + bias[n] )        x bf16 [M,K] (row stride lda), w bf16 [N,K]
+ *   FVK_EPI_GELU_TANH : out = bf16(gelu_tanh(float(y)))
+ *   FVK_EPI_SILU      : out = bf16(silu(float(y)))
+ *   FVK_EPI_RESIDUAL_GATE : out = bf16(float(residual[m,n]) + float(y) * gate[m / rows_per_batch, n])
+ *                           (gate NULL = 1; = ScaleResidual fused into the out-projection)
+ * K % 64 == 0.  Any M, N (tails masked).  out row stride ldc. */
+#define FVK_EPI_NONE 0
+#define FVK_EPI_GELU_TANH 1
+#define FVK_EPI_SILU 2
+#define FVK_EPI_RESIDUAL_GATE 3
+#define FVK_EPI_DIV 4 /* out = bf16(float(y) / epi_scalar) — the `scores / dim**0.5` of fastvideo_kernel/ops.py:113 */
+int fvk_gemm_bf16(const void* x, const void* w, const void* bias, void* out, int M, int N, int K, long lda,
+                  long ldc, int epilogue, const void* residual, const float* gate, int rows_per_batch,
+                  void* stream);
+/* `batch` independent GEMMs (no bias): operand b at x + b*x_bstride etc.  Used for the VSA coarse scores
+ * q_c · k_c^T / sqrt(D) per (batch, head) (ref: fastvideo_kernel/ops.py:113).  epilogue NONE or DIV. */
+int fvk_gemm_bf16_batched(const void* x, const void* w, void* out, int batch, int M, int N, int K, long lda, long ldc,
+                          long x_bstride, long w_bstride, long out_bstride, int epilogue, float epi_scalar, void* stream);
+
+/* ------------------------------------------------------------------ attention (MFMA-bound)
+ * Flash-style forward, head_dim 128, non-causal, fp32 online softmax in the exp2 domain, P rounded to bf16
+ * before P·V (ref numerics: block_sparse_attn_triton.py:124-158; st_attn_triton.py:60-89).
+ * q [B, Sq, H, 128], k [B, Skv, H, 128] with explicit strides (elements): *_bs batch, *_ss sequence row,
+ * *_hs head — so both the backend layout [B,S,H,D] (ref: fastvideo/attention/backends/abstract.py AttentionImpl.forward)
+ * and the kernel-package layout [B,H,S,D] (ref: fastvideo_kernel/ops.py) are served without copies.
+ * vt = fvk_v_transpose_bf16 output [B, H, 128, Skv_pad].  o has q's shape with its own strides.
+ * lse: optional fp32 [B, H, Sq] = m*log2e*scale + log2(l) (block_sparse_attn_triton.py:155-157), or NULL. */
+typedef struct {
+    const void* q; const void* k; const void* vt; void* o; float* lse;
+    int B, H, Sq, Skv, Skv_pad;
+    long q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, o_bs, o_ss, o_hs;
+    float scale;
+} fvk_attn_args;
+
+/* dense: ref fastvideo/attention/backends/sdpa.py:122-147 / flash_attn.py:247-345 (the path replaced). */
+int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream);
+
+/* block-sparse (VSA sparse branch): query block i (64 rows) attends KV blocks q2k_idx[b,h,i,0..q2k_num[b,h,i])
+ * (64 keys each, of which the first kv_block_sizes[j] are valid).  ref: fastvideo-kernel/csrc/attention/
+ * block_sparse_h100.cu:66-272, triton_kernels/block_sparse_attn_triton.py:32-160.
+ * q2k_idx int32 [B,H,Nq,max_kv], q2k_num int32 [B,H,Nq], kv_block_sizes int32 [Nkv]. Sq, Skv multiples of 64. */
+int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
+                               const int32_t* kv_block_sizes, int max_kv, void* stream);
+
+/* sliding-tile attention: tokens in tile-major order, tile = tile_t*tile_h*tile_w tokens (multiple of 64),
+ * canvas of (ct,ch,cw) tiles; head h uses window (win[3h], win[3h+1], win[3h+2]) tiles with the clamped
+ * centre rule of ref: fastvideo-kernel/tests/support_flex_sta.py:29-59 ≡ st_attn_triton.py:158-176.
+ * win_host: HOST int32 [3*H].  No text tokens (Wan T2V self-attention has none). */
+int fvk_attn_sta_bf16(const fvk_attn_args* a, int ct, int ch, int cw, int tile_tokens, const int32_t* win_host,
+                      void* stream);
+
+/* ------------------------------------------------------------------ VSA coarse stage + index construction
+ * ref: fastvideo/attention/backends/video_sparse_attn.py:31-114, 170-189, 285-290;
+ *      fastvideo_kernel/triton_kernels/fused_compress_topk.py:22-60 (block mean), :211-277 (top-k mask);
+ *      triton_kernels/index.py:33-61 (map_to_index).  All integer outputs are bit-exact targets. */
+/* host-side metadata (CPU, pure integer): fills perm/rev/non_pad/untile [T*H*W] and vbs [n_tiles]; any may be NULL. */
+int fvk_vsa_build_metadata_host(int T, int H, int W, int tt, int th, int tw, int32_t* perm, int32_t* rev,
+                                int32_t* vbs, int32_t* non_pad, int32_t* untile);
+/* dst[b, dst_index[i], :] = src[b, src_index[i], :] for i < n (NULL index = identity); rows of `row_elems` bf16
+ * (multiple of 8).  tile(): dst zero-initialised buffer, dst_index=non_pad, src_index=perm.
+ * untile(): dst_index=NULL, src_index=untile_combined.  ref: video_sparse_attn.py:170-189, 285-290. */
+int fvk_gather_rows_bf16(const void* src, void* dst, const int32_t* src_index, const int32_t* dst_index, int B, int n,
+                         int row_elems, long src_batch_stride, long dst_batch_stride, void* stream);
+/* x [B,S_pad,H,D] with strides -> out [B,H,Nblk,D] bf16 = bf16(fp32 sum over 64 rows / vbs[blk]). */
+int fvk_block_mean_bf16(const void* x, void* out, const int32_t* vbs, int B, int H, int n_blocks, int block, int D,
+                        long x_bs, long x_ss, long x_hs, void* stream);
+/* scores bf16 or fp32 [rows, n] -> mask uint8 [rows, n] with exactly min(topk,n) ones per row (bisection + first-come ties). */
+int fvk_topk_mask(const void* scores, int scores_is_fp32, uint8_t* mask, int rows, int n, int topk, void* stream);
+/* mask uint8 [rows, n] -> idx int32 [rows, n] (ascending, tail zero), num int32 [rows]. */
+int fvk_map_to_index(const uint8_t* mask, int32_t* idx, int32_t* num, int rows, int n, void* stream);
+/* row softmax over the last dim: in/out bf16 [rows, n] (fp32 math, one rounding) — VSA coarse attn weights. */
+int fvk_softmax_rows_bf16(const void* in, void* out, int rows, int n, void* stream);
+/* out[b,s,h,:] = bf16( bf16(float(out_c[b,h,s/block,:]) * float(gate[b,s,h,:])) + float(out_s[b,s,h,:]) )
+ * ref: fastvideo_kernel/ops.py:120-133.  out_s/gate/out share strides (bs, ss, hs); out_c is [B,H,Nblk,D] contiguous. */
+int fvk_vsa_combine_bf16(const void* out_c, const void* out_s, const void* gate, void* out, int B, int S, int H, int D,
+                         int block, long bs, long ss, long hs, void* stream);
+
+/* ------------------------------------------------------------------ patch / time embedding glue
+ * ref: fastvideo/layers/visual_embedding.py:46-55 (PatchEmbed k=s=(1,2,2)), :136-157 (timestep_embedding),
+ *      wanvideo.py:689-690, :761-764. */
+int fvk_patchify_bf16(const void* latent, void* out, int B, int C, int T, int Hh, int W, int pt, int ph, int pw,
+                      void* stream);
+int fvk_unpatchify_bf16(const void* x, void* latent, int B, int C, int T, int Hh, int W, int pt, int ph, int pw,
+                        void* stream);
+/* out bf16 [B, dim] = bf16([cos(t*f) | sin(t*f)]), f_i = exp(-ln(max_period) * i / (dim/2)) in fp32; t fp32 [B]. */
+int fvk_timestep_embedding_bf16(const float* t, void* out, int B, int dim, float max_period, void* stream);
+/* y = bf16(silu(float(x))) elementwise, n % 8 == 0. */
+int fvk_silu_bf16(const void* x, void* y, long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FVK_AMD_H */

@@ -1,0 +1,78 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/fvk_amd.h declares; the pure-CPU
+entry point (VSA metadata) is bit-exact against the oracle and the golden fixtures.  No compute kernels are launched."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vsa_oracle as V
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as G
+    G.build()
+    from fastvideo_amd import _lib
+    return _lib
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "fvk_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(fvk_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    cdll = lib.load()
+    for name in sorted(declared):
+        assert hasattr(cdll, name), f"{name} declared in include/fvk_amd.h but not exported"
+    assert declared == set(lib.SIGNATURES), "ctypes SIGNATURES table out of sync with the header"
+    assert cdll.fvk_abi_version() == lib.ABI_VERSION
+
+
+def test_errors_surface_as_runtime_error(lib):
+    with pytest.raises(RuntimeError, match="bad shape"):
+        lib.call("fvk_vsa_build_metadata_host", 0, 1, 1, 4, 4, 4, None, None, None, None, None)
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 16), (9, 10, 7), (5, 7, 3), (2, 2, 2), (21, 30, 52)])
+def test_vsa_metadata_host_bit_exact(lib, shape):
+    from fastvideo_amd import ops
+    m = ops.vsa_build_metadata_host(shape)
+    ref = V.build_metadata(tuple(s * p for s, p in zip(shape, (1, 2, 2))))
+    for key in ("tile_partition_indices", "reverse_tile_partition_indices", "variable_block_sizes", "non_pad_index",
+                "untile_combined_index"):
+        assert np.array_equal(m[key].numpy(), ref[key]), key
+    assert m["num_tiles"] == ref["num_tiles"]
+
+
+def test_vsa_metadata_host_golden(lib, golden_dir):
+    from fastvideo_amd import ops
+    z = np.load(os.path.join(golden_dir, "vsa_meta.npz"))
+    for lat in sorted({k.split("/")[0] for k in z.files}):
+        t, h, w = (int(v) for v in lat.split("x"))
+        m = ops.vsa_build_metadata_host((t, h // 2, w // 2))
+        assert np.array_equal(m["tile_partition_indices"].numpy(), z[lat + "/perm"])
+        assert np.array_equal(m["untile_combined_index"].numpy(), z[lat + "/untile"])
+        assert np.array_equal(m["variable_block_sizes"].numpy(), z[lat + "/vbs"])
+
+
+def test_kernel_api_index_helpers(lib):
+    from fastvideo_amd import kernel_api as KA
+    assert KA.get_tile_partition_indices((2, 2, 2), (2, 2, 2)).tolist() == list(range(8))
+    md = KA.build_vsa_metadata((9, 10, 7))
+    assert md["num_tiles"] == (3, 3, 2) and md["max_block_size"] == 64
+    with pytest.raises(ValueError, match="Unsupported VSA tile volume 27"):
+        KA.build_vsa_metadata((6, 6, 6), tile_size=(3, 3, 3))
+    idx = KA.get_non_pad_index(torch.tensor([20, 40]), 64)
+    assert idx[0].item() == 0 and idx[20].item() == 64
+    f, r = KA.get_tile_partition_indices((9, 10, 7)), KA.get_reverse_tile_partition_indices((9, 10, 7))
+    assert torch.equal(r[f], torch.arange(630))
+
+
+def test_no_cpu_fallback(lib):
+    from fastvideo_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16))

@@ -1,0 +1,336 @@
+"""Parity of every HIP kernel (called through the C ABI via fastvideo_amd.ops) against the CPU oracle on the same
+seeded inputs.  Integer/index outputs: bit-exact.  bf16 activations: the reference's own fused-op tolerance
+atol=rtol=1e-2 (fastvideo-kernel/tests/test_turbodiffusion.py:143, test_fused_compress_topk.py:138); attention:
+max |Δ| < 4e-2 as in fastvideo-kernel/tests/test_sta.py:88-91 plus a mean-error bound."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vsa_oracle as V
+from oracle import wan_oracle as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fastvideo_amd import ops as o
+    return o
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):
+    return (torch.randn(shape, generator=g(seed)) * scale).to(dtype)
+
+
+def close(a, b, atol=1e-2, rtol=1e-2, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    bad = err > atol + rtol * b.abs()
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements off; max abs err {err.max().item():.4g} "
+                           f"at {np.unravel_index(int(err.argmax()), tuple(err.shape))}, ref there "
+                           f"{b.flatten()[err.argmax()].item():.4g}")
+
+
+# ------------------------------------------------------------------ LN / modulate family
+@pytest.mark.parametrize("M,d,B", [(37, 256, 1), (70, 1536, 2), (5, 5120, 1)])
+def test_ln_scale_shift_block(ops, M, d, B):
+    x = rnd((B, M, d), 1, 2.0)
+    scale, shift = rnd((B, 1, d), 2, 0.3, torch.float32), rnd((B, 1, d), 3, 0.3, torch.float32)
+    ref = W.ln_scale_shift_block(x, scale, shift)
+    out = ops.ln_modulate(x.to(DEV), mul=(1 + scale).to(DEV), add=shift.to(DEV), eps=1e-6)
+    close(out, ref, what="norm1")
+
+
+@pytest.mark.parametrize("M,d,B", [(33, 256, 1), (64, 1536, 2)])
+def test_scale_residual_ln_self_attn(ops, M, d, B):
+    res, x = rnd((B, M, d), 1, 2.0), rnd((B, M, d), 2)
+    gate = rnd((B, 1, d), 3, 0.5, torch.float32)
+    w, b = rnd((d, ), 4).float() * 0.1 + 1, rnd((d, ), 5).float() * 0.1
+    null = torch.tensor([0])
+    mod, ro = W.scale_residual_ln_scale_shift(res, x, gate, null, null, w, b)
+    out, rout = ops.ln_modulate(x.to(DEV), residual=res.to(DEV), gate=gate.to(DEV), ln_w=w.to(DEV), ln_b=b.to(DEV),
+                                want_residual=True)
+    close(rout, ro.bfloat16(), what="residual_out")
+    close(out, mod.bfloat16(), what="normed")
+
+
+@pytest.mark.parametrize("M,d,B", [(33, 256, 1), (64, 1536, 2)])
+def test_scale_residual_ln_cross_attn(ops, M, d, B):
+    res, x = rnd((B, M, d), 1, 2.0), rnd((B, M, d), 2)
+    scale, shift = rnd((B, 1, d), 2, 0.3, torch.float32), rnd((B, 1, d), 3, 0.3, torch.float32)
+    mod, ro = W.scale_residual_ln_scale_shift(res, x, 1, shift, scale)
+    out, rout = ops.ln_modulate(x.to(DEV), residual=res.to(DEV), mul=(1.0 + scale).to(DEV), add=shift.to(DEV),
+                                round_residual=True, round_norm=True, want_residual=True)
+    assert torch.equal(rout.cpu(), ro), "bf16 residual add must be bit exact"
+    close(out, mod.bfloat16(), what="normed")
+
+
+def test_ln_scale_shift_out_and_scale_residual(ops):
+    B, M, d = 2, 50, 1536
+    x = rnd((B, M, d), 1, 2.0)
+    scale, shift = rnd((B, 1, d), 2, 0.3), rnd((B, 1, d), 3, 0.3)  # bf16 like the model's norm_out
+    ref = W.ln_scale_shift_out(x, shift, scale)
+    out = ops.ln_modulate(x.to(DEV), mul=(1.0 + scale).float().to(DEV), add=shift.float().to(DEV), round_norm=True)
+    close(out, ref, what="norm_out")
+    gate = rnd((B, 1, d), 4, 0.5, torch.float32)
+    y = rnd((B, M, d), 5)
+    ref2 = W.scale_residual(x, y, gate).bfloat16()
+    out2 = ops.scale_residual(x.to(DEV), y.to(DEV), gate.to(DEV))
+    assert torch.equal(out2.cpu(), ref2), "gated residual is two exactly-rounded fp32 ops + one bf16 rounding"
+
+
+@pytest.mark.parametrize("grid,H", [((3, 4, 4), 2), ((3, 5, 7), 12)])
+def test_rmsnorm_rope(ops, grid, H):
+    S, D = math.prod(grid), 128
+    d = H * D
+    qkv = rnd((S, 3 * d), 1, 1.5)
+    wq, wk = (rnd((d, ), 2).float() * 0.2 + 1).bfloat16(), (rnd((d, ), 3).float() * 0.2 + 1).bfloat16()
+    cos, sin = W.rope_tables(grid, D)
+    refs = []
+    for i, w in enumerate((wq, wk)):
+        n = W.rms_norm(qkv[:, i * d:(i + 1) * d].unsqueeze(0), w)
+        refs.append(W.apply_rotary_emb(n.view(1, S, H, D), cos, sin).view(S, d))
+    dq = qkv.to(DEV)
+    outs = ops.rmsnorm_rope([dq[:, :d], dq[:, d:2 * d]], [wq.to(DEV), wk.to(DEV)], cos.to(DEV), sin.to(DEV), head_dim=D,
+                            seq_len=S)
+    for o, r, n in zip(outs, refs, "qk"):
+        close(o, r, what=f"rmsnorm+rope {n}")
+    # norm only / rope only must compose to the same thing
+    n_only = ops.rmsnorm_rope([dq[:, :d]], [wq.to(DEV)], head_dim=D, seq_len=S)[0]
+    close(n_only, W.rms_norm(qkv[:, :d].unsqueeze(0), wq)[0], what="rmsnorm only")
+    r_only = ops.rmsnorm_rope([n_only], None, cos.to(DEV), sin.to(DEV), head_dim=D, seq_len=S)[0]
+    assert torch.equal(r_only, outs[0]), "norm->rope split must equal the fused kernel bit for bit"
+
+
+def test_v_transpose_layout(ops):
+    B, S, H, D = 2, 150, 3, 128
+    v = rnd((B, S, H, D), 1)
+    vt = ops.v_transpose(v.to(DEV)).cpu()
+    S_pad = 192
+    assert vt.shape == (B, H, D, S_pad)
+    p = torch.arange(S_pad)
+    key = (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)
+    ref = torch.zeros(B, H, D, S_pad, dtype=torch.bfloat16)
+    vpad = torch.zeros(B, S_pad, H, D, dtype=torch.bfloat16)
+    vpad[:, :S] = v
+    ref[:] = vpad[:, key].permute(0, 2, 3, 1)
+    assert torch.equal(vt, ref)
+    # strided (bhsd) source
+    v2 = v.permute(0, 2, 1, 3).contiguous().to(DEV)  # [B,H,S,D]
+    assert torch.equal(ops.v_transpose(v2.transpose(1, 2)).cpu(), ref)
+
+
+# ------------------------------------------------------------------ GEMM
+def _lin_ref(x, w, b):
+    return (x.float() @ w.float().t() + (0 if b is None else b.float())).bfloat16()
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1, 1536, 256), (257, 64, 1536), (130, 8960, 192)])
+def test_gemm_bias(ops, M, N, K):
+    x, w, b = rnd((M, K), 1), rnd((N, K), 2, K**-0.5), rnd((N, ), 3)
+    out = ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV))
+    close(out, _lin_ref(x, w, b), what=f"gemm {M}x{N}x{K}")
+    out_nb = ops.gemm(x.to(DEV), w.to(DEV), None)
+    close(out_nb, _lin_ref(x, w, None), what="gemm no bias")
+
+
+def test_gemm_identity_asymmetric(ops):
+    """A = I with an asymmetric B catches a transposed C write (guide: 'Always A=I-check with ASYMMETRIC B')."""
+    K = 128
+    x = torch.eye(K).bfloat16()
+    w = (torch.arange(K * K).view(K, K) % 251).float().bfloat16()  # exactly representable
+    out = ops.gemm(x.to(DEV), w.to(DEV), None).cpu()
+    assert torch.equal(out, w.t().contiguous())
+
+
+def test_gemm_epilogues(ops):
+    M, N, K, B = 200, 256, 128, 2
+    x, w, b = rnd((M, K), 1), rnd((N, K), 2, K**-0.5), rnd((N, ), 3)
+    y = _lin_ref(x, w, b)
+    close(ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), epilogue=ops.EPI_GELU_TANH), W.gelu_tanh(y), what="gelu")
+    close(ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), epilogue=ops.EPI_SILU), torch.nn.functional.silu(y), what="silu")
+    res, gate = rnd((M, N), 4, 2.0), rnd((B, N), 5, 0.5, torch.float32)
+    ref = W.scale_residual(res.view(B, M // B, N), y.view(B, M // B, N), gate.view(B, 1, N)).bfloat16().view(M, N)
+    out = ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), epilogue=ops.EPI_RESIDUAL_GATE, residual=res.to(DEV), gate=gate.to(DEV))
+    close(out, ref, what="residual+gate")
+    # strided A (column slice of a wider buffer) and batched DIV
+    wide = rnd((M, 3 * K), 6)
+    close(ops.gemm(wide.to(DEV)[:, K:2 * K], w.to(DEV), b.to(DEV)), _lin_ref(wide[:, K:2 * K], w, b), what="strided A")
+    xb, wb = rnd((3, 70, 128), 7), rnd((3, 90, 128), 8)
+    refb = (torch.matmul(xb, wb.transpose(-1, -2)) / (128**0.5))
+    close(ops.gemm_batched(xb.to(DEV), wb.to(DEV), ops.EPI_DIV, 128**0.5), refb, what="batched div")
+
+
+# ------------------------------------------------------------------ attention
+def _attn_check(out, ref, what):
+    err = (out.float().cpu() - ref).abs()
+    assert torch.isfinite(out.float()).all(), f"{what}: non-finite output"
+    assert err.max().item() < 4e-2 and err.mean().item() < 2e-3, f"{what}: max {err.max().item():.4g} mean {err.mean().item():.4g}"
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 48, 48), (1, 2, 105, 105), (2, 3, 300, 77), (1, 1, 1000, 1000), (1, 12, 130, 512)])
+def test_attn_dense_bshd(ops, B, H, Sq, Skv):
+    q, k, v = rnd((B, Sq, H, 128), 1), rnd((B, Skv, H, 128), 2), rnd((B, Skv, H, 128), 3)
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    out = ops.attn_dense(q.to(DEV), k.to(DEV), v.to(DEV), layout="bshd")
+    _attn_check(out, ref, f"dense bshd {B},{H},{Sq},{Skv}")
+
+
+def test_attn_dense_bhsd_and_sta_distribution(ops):
+    """[B,H,S,D] layout with the input distribution of fastvideo-kernel/tests/test_sta.py:23-29."""
+    B, H, S = 1, 2, 400
+    def gen(seed):
+        d = torch.randn((B, H, S, 128), generator=g(seed))
+        d = d / d.norm(dim=-1, keepdim=True)
+        mag = (torch.randn((B, H, S, 1), generator=g(seed + 10)) * 10 + 0.1)
+        return (d * mag).bfloat16()
+    q, k, v = gen(1), gen(2), gen(3)
+    ref = W.attention_fp32_ref(q, k, v, 128**-0.5)
+    out = ops.attn_dense(q.to(DEV), k.to(DEV), v.to(DEV), layout="bhsd")
+    err = (out.float().cpu() - ref).abs()
+    assert err.max().item() < 4e-2 * max(1.0, ref.abs().max().item() / 4), f"max {err.max().item()}"
+
+
+def test_attn_dense_softmax_rescale_branch(ops):
+    """Force the running-max rescale at a late KV tile (guide §5.4 rule 26): one key spikes against one query."""
+    B, H, S = 1, 1, 320
+    q, k, v = rnd((B, S, H, 128), 1, 0.5), rnd((B, S, H, 128), 2, 0.5), rnd((B, S, H, 128), 3)
+    k[0, 250, 0] = q[0, 7, 0] * 6  # raw q.k >> other scores, inside tile 3
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    out = ops.attn_dense(q.to(DEV), k.to(DEV), v.to(DEV), layout="bshd")
+    _attn_check(out, ref, "rescale branch")
+
+
+def test_attn_block_sparse(ops):
+    B, H, nq, nk = 1, 2, 5, 7
+    q, k, v = rnd((B, H, nq * 64, 128), 1), rnd((B, H, nk * 64, 128), 2), rnd((B, H, nk * 64, 128), 3)
+    rng = np.random.default_rng(0)
+    bm = rng.random((B, H, nq, nk)) < 0.5
+    bm[..., 0] = True
+    vbs = np.array([64, 64, 48, 64, 1, 33, 24], dtype=np.int32)
+    ref = V.block_sparse_attn(q, k, v, bm, vbs)
+    idx, num = V.map_to_index(bm)
+    out, lse = ops.attn_block_sparse(q.to(DEV), k.to(DEV), v.to(DEV), torch.from_numpy(idx).to(DEV), torch.from_numpy(num).to(DEV),
+                                     torch.from_numpy(vbs).to(DEV), layout="bhsd", return_lse=True)
+    _attn_check(out, ref, "block sparse")
+    # lse (base 2, scaled) against the oracle's masked scores
+    s = torch.matmul(q.float(), k.float().transpose(-1, -2)) * 128**-0.5
+    bmf = torch.from_numpy(bm).view(B, H, nq, 1, nk, 1).expand(B, H, nq, 64, nk, 64)
+    col = (torch.arange(64)[None, :] < torch.from_numpy(vbs.astype(np.int64))[:, None]).view(1, 1, 1, 1, nk, 64)
+    s = s.masked_fill(~(bmf & col).reshape(B, H, nq * 64, nk * 64), float("-inf"))
+    lse_ref = torch.logsumexp(s, dim=-1) * 1.4426950408889634
+    assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("canvas,tile,win", [((4, 8, 16), (2, 8, 8), [(1, 1, 1), (3, 1, 3)]),
+                                             ((12, 16, 24), (6, 8, 8), [(3, 3, 3), (1, 3, 1), (3, 1, 5)])])
+def test_attn_sta(ops, canvas, tile, win):
+    tv = math.prod(tile)
+    S = math.prod(canvas)
+    B, H = 1, len(win)
+    q, k, v = rnd((B, H, S, 128), 1), rnd((B, H, S, 128), 2), rnd((B, H, S, 128), 3)
+    ct = tuple(c // t for c, t in zip(canvas, tile))
+    out = ops.attn_sta(q.to(DEV), k.to(DEV), v.to(DEV), ct, tv, win, layout="bhsd")
+    for h, w in enumerate(win):
+        mask = V.sta_mask(canvas, w, tile)
+        ref = W.attention_fp32_ref(q[:, h:h + 1], k[:, h:h + 1], v[:, h:h + 1], 128**-0.5, mask)
+        _attn_check(out[:, h:h + 1], ref, f"sta head {h} window {w}")
+
+
+# ------------------------------------------------------------------ VSA pieces (integer parts bit exact)
+@pytest.mark.parametrize("n,topk", [(50, 9), (624, 125), (624, 63), (1440, 288), (7, 7), (300, 1)])
+def test_topk_mask_bit_exact(ops, n, topk):
+    sc = rnd((3, 5, n), 1, 2.0)  # bf16 scores have many exact ties
+    sc[0, 0, :] = 0.5            # an all-equal row
+    ref = V.topk_mask_bisect(sc.float().numpy(), topk)
+    got = ops.topk_mask(sc.to(DEV), topk).cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert (got.sum(-1) == min(topk, n)).all()
+    got32 = ops.topk_mask(sc.float().to(DEV), topk).cpu().numpy()
+    assert np.array_equal(got32, ref)
+
+
+def test_map_to_index_and_gather(ops):
+    rng = np.random.default_rng(3)
+    bm = rng.random((2, 3, 9, 200)) < 0.3
+    idx, num = ops.map_to_index(torch.from_numpy(bm).to(DEV))
+    ri, rn = V.map_to_index(bm)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(num.cpu().numpy(), rn)
+    # tile / untile through the gather kernel == oracle scatter/gather
+    lat = (5, 14, 6)
+    md = V.build_metadata(lat)
+    S, S_pad = md["total_seq_length"], math.prod(md["num_tiles"]) * 64
+    x = rnd((2, S, 3, 128), 4)
+    t_ref = V.tile(x, md)
+    i32 = lambda a: torch.from_numpy(a.astype(np.int32)).to(DEV)
+    t_got = ops.gather_rows(x.to(DEV), S_pad, i32(md["tile_partition_indices"]), i32(md["non_pad_index"]), zero_init=True)
+    assert torch.equal(t_got.cpu(), t_ref)
+    u_got = ops.gather_rows(t_got, S, i32(md["untile_combined_index"]), None)
+    assert torch.equal(u_got.cpu(), x)
+
+
+def test_block_mean(ops):
+    vbs = np.array([64, 48, 1, 64, 24], dtype=np.int32)
+    x = rnd((2, 3, 5 * 64, 128), 1)
+    for b in range(5):
+        x[:, :, b * 64 + vbs[b]:(b + 1) * 64] = 0
+    ref = V.block_mean(x, vbs, 64)
+    got = ops.block_mean(x.to(DEV), torch.from_numpy(vbs).to(DEV), 64)
+    close(got, ref, atol=1e-2, rtol=1e-2, what="block mean")
+
+
+def test_video_sparse_attn_composite(ops):
+    from fastvideo_amd import kernel_api as KA
+    lat = (8, 20, 14)  # dit (8,10,7) -> tiles (2,3,2)=12 blocks, ragged
+    md = V.build_metadata(lat)
+    S = md["total_seq_length"]
+    B, H = 1, 2
+    q, k, v, gate = (rnd((B, S, H, 128), s) for s in (1, 2, 3, 4))
+    tq, tk, tv, tg = (V.tile(t, md).transpose(1, 2).contiguous() for t in (q, k, v, gate))
+    vbs = md["variable_block_sizes"]
+    topk = V.compute_topk(0.5, len(vbs))
+    ref, inter = V.video_sparse_attn(tq, tk, tv, vbs, vbs, topk, 64, tg)
+    tvbs = torch.from_numpy(vbs).to(DEV)
+    out, gi = KA.video_sparse_attn(tq.to(DEV), tk.to(DEV), tv.to(DEV), tvbs, tvbs, topk, (4, 4, 4), tg.to(DEV),
+                                   return_intermediates=True)
+    close(gi["q_c"], inter["q_c"], what="q_c")
+    close(gi["scores"], inter["scores"], atol=2e-2, rtol=2e-2, what="coarse scores")
+    # the mask must be the exact top-k of *our* scores (bit-exact selection rule) ...
+    assert np.array_equal(gi["mask"].cpu().numpy(), V.topk_mask_bisect(gi["scores"].float().cpu().numpy(), topk))
+    # ... and, given the same mask, the sparse branch must match the oracle
+    ref_s = V.block_sparse_attn(tq, tk, tv, gi["mask"].cpu().numpy(), vbs)
+    valid_rows = torch.from_numpy(md["non_pad_index"])
+    _attn_check(gi["out_s"][:, :, valid_rows], ref_s[:, :, valid_rows], "vsa sparse branch")
+    if np.array_equal(gi["mask"].cpu().numpy(), inter["mask"]):
+        _attn_check(out[:, :, valid_rows], ref.float()[:, :, valid_rows], "vsa composite")
+
+
+# ------------------------------------------------------------------ glue
+def test_patchify_unpatchify_time_silu(ops):
+    lat = rnd((2, 16, 3, 10, 14), 1)
+    assert torch.equal(ops.patchify(lat.to(DEV)).cpu(), W.patchify(lat))
+    x = rnd((2, 3 * 5 * 7, 64), 2)
+    assert torch.equal(ops.unpatchify(x.to(DEV), (2, 16, 3, 10, 14)).cpu(), W.unpatchify(x, (3, 5, 7), (1, 2, 2), 16))
+    t = torch.tensor([500.0, 3.0, 999.0])
+    close(ops.timestep_embedding(t, 256), W.timestep_embedding(t, 256).bfloat16(), atol=8e-3, rtol=8e-3, what="t-emb")
+    s = rnd((4, 256), 3, 3.0)
+    close(ops.silu(s.to(DEV)), torch.nn.functional.silu(s), what="silu")
+
+
+def test_errors_are_loud(ops):
+    x = rnd((4, 100), 1).to(DEV)
+    with pytest.raises(RuntimeError):
+        ops.gemm(x, rnd((8, 100), 2).to(DEV))  # K % 64 != 0
+    with pytest.raises(RuntimeError):
+        ops.ln_modulate(rnd((4, 100), 1))  # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        ops.attn_dense(rnd((1, 8, 1, 64), 1).to(DEV), rnd((1, 8, 1, 64), 2).to(DEV), rnd((1, 8, 1, 64), 3).to(DEV))
