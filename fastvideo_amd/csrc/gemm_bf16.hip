@@ -92,16 +92,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nt = a.K / BK;
-    uint4 ra[4], rb[4];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ra[4], rb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const uint4*>(ga[i]);
-        rb[i] = *reinterpret_cast<const uint4*>(gb[i]);
+        ra[i] = *reinterpret_cast<const u32x4*>(ga[i]);
+        rb[i] = *reinterpret_cast<const u32x4*>(gb[i]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<uint4*>(smem + soff[i]) = ra[i];
-        *reinterpret_cast<uint4*>(smem + BM * BK * 2 + soff[i]) = rb[i];
+        *reinterpret_cast<u32x4*>(smem + soff[i]) = ra[i];
+        *reinterpret_cast<u32x4*>(smem + BM * BK * 2 + soff[i]) = rb[i];
     }
     __syncthreads();
 
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
             const int koff = (t + 1) * BK;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                ra[i] = *reinterpret_cast<const uint4*>(ga[i] + koff);
-                rb[i] = *reinterpret_cast<const uint4*>(gb[i] + koff);
+                ra[i] = *reinterpret_cast<const u32x4*>(ga[i] + koff);
+                rb[i] = *reinterpret_cast<const u32x4*>(gb[i] + koff);
             }
         }
 #pragma unroll
@@ -134,8 +135,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
         if (more) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                *reinterpret_cast<uint4*>(nxt + soff[i]) = ra[i];
-                *reinterpret_cast<uint4*>(nxt + BM * BK * 2 + soff[i]) = rb[i];
+                *reinterpret_cast<u32x4*>(nxt + soff[i]) = ra[i];
+                *reinterpret_cast<u32x4*>(nxt + BM * BK * 2 + soff[i]) = rb[i];
             }
         }
         __syncthreads();

@@ -142,7 +142,7 @@ struct RmsArgs {
     const bf16_t* w[3];
     const float* cos;
     const float* sin;
-    int M, width, head_dim, seq_len;
+    int M, width, head_dim, seq_len, pos_offset;
     long in_stride, out_stride;
     float eps;
 };
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs a) {
             }
         }
     }
-    const long pos = (long)(row % a.seq_len) * a.head_dim;
+    const long pos = (long)((row + a.pos_offset) % a.seq_len) * a.head_dim;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int c = lane + 64 * i;
@@ -323,12 +323,12 @@ extern "C" int fvk_scale_residual_bf16(const void* residual, const void* x, cons
 
 extern "C" int fvk_rmsnorm_rope_bf16(const void* const* in, void* const* out, const void* const* weight, int n_tensors,
                                      const float* cos, const float* sin, int M, int width, int head_dim, int seq_len,
-                                     long in_stride, long out_stride, float eps, void* stream) {
+                                     int pos_offset, long in_stride, long out_stride, float eps, void* stream) {
     FVK_CHECK(in && out && n_tensors >= 1 && n_tensors <= 3, FVK_ERR_ARG, "fvk_rmsnorm_rope_bf16: n_tensors=%d", n_tensors);
     FVK_CHECK(width > 0 && width % 8 == 0 && head_dim > 0 && head_dim % 8 == 0 && width % head_dim == 0, FVK_ERR_ARG,
               "fvk_rmsnorm_rope_bf16: width=%d head_dim=%d", width, head_dim);
     FVK_CHECK((cos == nullptr) == (sin == nullptr), FVK_ERR_ARG, "fvk_rmsnorm_rope_bf16: cos/sin must both be set");
-    FVK_CHECK(seq_len > 0 && in_stride % 8 == 0 && out_stride % 8 == 0, FVK_ERR_ARG, "fvk_rmsnorm_rope_bf16: strides must be multiples of 8");
+    FVK_CHECK(pos_offset >= 0 && seq_len > 0 && in_stride % 8 == 0 && out_stride % 8 == 0, FVK_ERR_ARG, "fvk_rmsnorm_rope_bf16: strides must be multiples of 8");
     if (M <= 0) return FVK_OK;
     RmsArgs a{};
     for (int i = 0; i < n_tensors; ++i) {
@@ -337,7 +337,7 @@ extern "C" int fvk_rmsnorm_rope_bf16(const void* const* in, void* const* out, co
         a.out[i] = (bf16_t*)out[i];
         a.w[i] = weight ? (const bf16_t*)weight[i] : nullptr;
     }
-    a.cos = cos; a.sin = sin; a.M = M; a.width = width; a.head_dim = head_dim; a.seq_len = seq_len;
+    a.cos = cos; a.sin = sin; a.M = M; a.width = width; a.head_dim = head_dim; a.seq_len = seq_len; a.pos_offset = pos_offset;
     a.in_stride = in_stride; a.out_stride = out_stride; a.eps = eps;
     int rc = dispatch_vpl(width, [&](auto vpl) {
         hipLaunchKernelGGL((rmsnorm_rope_kernel<decltype(vpl)::value>), dim3((M + 3) / 4, n_tensors), dim3(256), 0,

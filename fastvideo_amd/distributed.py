@@ -1,0 +1,135 @@
+"""Sequence parallelism for the Wan DiT on one MI355X node: one process per GPU, ``torch.distributed``
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for the world_size-2 tests).
+
+Reference being replaced: Ulysses SP — ``sequence_model_parallel_shard / all_to_all_4D / all_gather_with_unpad``
+(fastvideo/distributed/communication_op.py:28-91, device_communicators/base_device_communicator.py:123-193,
+fastvideo/distributed/utils.py:63-146) driven by ``DistributedAttention.forward`` (fastvideo/attention/layer.py:82-164).
+The reference needs ``num_heads % sp_size == 0`` (wanvideo.py:606-607), so Wan2.1-1.3B (12 heads) cannot use 8 GPUs.
+
+MI355X-first redesign — **2-D Ulysses**: the P ranks form a G x U grid, G = gcd(H, P) head groups x U = P/G query
+blocks.  xGMI is a full point-to-point mesh (every pair of GPUs owns a link), so an all-to-all with per-peer
+messages is not ring-bound; we use exactly that:
+    exchange #1  K, V : every rank sends its token shard's head-group g slice to all U ranks of column g
+                 Q    : ... only to the rank (g, u) whose query block u contains the shard
+    attention    rank (g, u): queries of block u (G shards), heads of group g, ALL keys
+    exchange #2  O    : rank (g, u) returns each shard's rows to the shard's owner
+U = 1 is plain Ulysses (P | H).  For 12 heads on 8 GPUs: G = 4, U = 2 — perfectly balanced (3 heads x half the
+queries per GPU) at 1.5x the K/V traffic, instead of the reference's hard failure.
+RoPE and QK-norm are token-local, so they are applied *before* exchange #1 with global positions (the reference
+applies RoPE after its all-to-all, layer.py:130-132 — same values, one fewer pass over the gathered tensor).
+
+All functions work on CPU tensors too (layout code is plain torch), which is how the gloo tests exercise them;
+the attention itself is injected (``attn_fn``): the product passes the HIP kernel, tests pass the oracle.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+
+
+@dataclass
+class SPLayout:
+    P: int      # SP world size
+    rank: int   # rank in the SP group
+    H: int      # attention heads
+    G: int      # head groups  (gcd(H, P))
+    U: int      # query blocks (P // G)
+
+    @property
+    def g(self):
+        return self.rank % self.G
+
+    @property
+    def u(self):
+        return self.rank // self.G
+
+    @property
+    def heads_per_group(self):
+        return self.H // self.G
+
+
+class SequenceParallel:
+
+    def __init__(self, num_heads: int, group=None):
+        self.group = group
+        if dist.is_available() and dist.is_initialized():
+            P, rank = dist.get_world_size(group), dist.get_rank(group)
+        else:
+            P, rank = 1, 0
+        G = math.gcd(num_heads, P)
+        self.lay = SPLayout(P=P, rank=rank, H=num_heads, G=G, U=P // G)
+
+    # -- sharding with zero padding (ref: distributed/utils.py:63-123, communication_op.py:61-91) ---------------
+    def padded_len(self, S: int) -> int:
+        return (S + self.lay.P - 1) // self.lay.P * self.lay.P
+
+    def shard(self, x: torch.Tensor, dim: int = 1) -> torch.Tensor:
+        """Zero-pad ``dim`` to a multiple of P and return this rank's contiguous shard."""
+        P, r = self.lay.P, self.lay.rank
+        if P == 1:
+            return x
+        S = x.shape[dim]
+        Sp = self.padded_len(S)
+        if Sp != S:
+            pad_shape = list(x.shape)
+            pad_shape[dim] = Sp - S
+            x = torch.cat([x, x.new_zeros(pad_shape)], dim=dim)
+        Sl = Sp // P
+        return x.narrow(dim, r * Sl, Sl).contiguous()
+
+    def all_gather_unpad(self, x: torch.Tensor, S: int, dim: int = 1) -> torch.Tensor:
+        """ref: sequence_model_parallel_all_gather_with_unpad (communication_op.py:75-91)."""
+        P = self.lay.P
+        if P == 1:
+            return x
+        xm = x.movedim(dim, 0).contiguous()
+        out = xm.new_empty((P * xm.shape[0], *xm.shape[1:]))
+        dist.all_gather_into_tensor(out, xm, group=self.group)
+        return out[:S].movedim(0, dim).contiguous()
+
+    # -- the exchanges ------------------------------------------------------------------------------------------
+    def _a2a(self, send: torch.Tensor, in_splits, out_splits, out_rows: int) -> torch.Tensor:
+        recv = send.new_empty((out_rows, *send.shape[1:]))
+        dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+        return recv
+
+    def scatter_heads_gather_seq(self, q, k, v):
+        """q,k,v: this rank's shard [Sl, H, D] (batch 1).  Returns (q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all)."""
+        L = self.lay
+        Sl, H, D = q.shape
+        hg = L.heads_per_group
+        # chunk for destination rank r' = u'*G + g' is heads group g' : [G, Sl, hg, D]
+        def by_group(t):
+            return t.reshape(Sl, L.G, hg, D).permute(1, 0, 2, 3)
+        kv_splits = [Sl] * L.P
+        k_all = self._a2a(by_group(k).repeat(L.U, 1, 1, 1).reshape(L.P * Sl, hg, D), kv_splits, kv_splits, L.P * Sl)
+        v_all = self._a2a(by_group(v).repeat(L.U, 1, 1, 1).reshape(L.P * Sl, hg, D), kv_splits, kv_splits, L.P * Sl)
+        # q goes only to the rank row u == my block; comes only from the G shards of my block
+        q_in = [Sl if (rp // L.G) == L.u else 0 for rp in range(L.P)]
+        q_out = [Sl if (s // L.G) == L.u else 0 for s in range(L.P)]
+        q_blk = self._a2a(by_group(q).reshape(L.G * Sl, hg, D), q_in, q_out, L.G * Sl)
+        return q_blk, k_all, v_all
+
+    def scatter_seq_gather_heads(self, o_blk: torch.Tensor, Sl: int) -> torch.Tensor:
+        """o_blk [G*Sl, hg, D] (query block u, head group g) -> this rank's shard [Sl, H, D]."""
+        L = self.lay
+        hg, D = o_blk.shape[1], o_blk.shape[2]
+        o_in = [Sl if (rp // L.G) == L.u else 0 for rp in range(L.P)]   # rows j*Sl.. go to shard owner u*G+j
+        o_out = [Sl if (s // L.G) == L.u else 0 for s in range(L.P)]    # from (g, u) for every g
+        recv = self._a2a(o_blk.contiguous(), o_in, o_out, L.G * Sl)      # [G(g), Sl, hg, D]
+        return recv.reshape(L.G, Sl, hg, D).permute(1, 0, 2, 3).reshape(Sl, L.H, D).contiguous()
+
+    def attention(self, q, k, v, S: int, attn_fn):
+        """Distributed self-attention for one batch element.
+        q,k,v: [Sl, H, D] shards (already normed + rotated).  S = true (unpadded) global sequence length.
+        attn_fn(q [Sq, h, D], k [Skv, h, D], v [Skv, h, D], kv_len) -> o [Sq, h, D]; keys >= kv_len are padding."""
+        L = self.lay
+        if L.P == 1:
+            return attn_fn(q, k, v, S)
+        Sl = q.shape[0]
+        q_blk, k_all, v_all = self.scatter_heads_gather_seq(q, k, v)
+        o_blk = attn_fn(q_blk, k_all, v_all, S)
+        return self.scatter_seq_gather_heads(o_blk, Sl)

@@ -78,7 +78,7 @@ def scale_residual(residual, x, gate=None, rows_per_batch=None):
     return out.view(x.shape)
 
 
-def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_len=None, eps=1e-6, outs=None):
+def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_len=None, eps=1e-6, outs=None, pos_offset=0):
     """tensors: list (<=3) of bf16 2-D views [M, width] sharing one row stride (e.g. q,k column slices of a fused
     QKV buffer).  Returns a list of new contiguous [M, width] tensors (or writes `outs`)."""
     n = len(tensors)
@@ -100,7 +100,7 @@ def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_le
         keep = [None if w is None else _chk(w, BF16, "weight").contiguous() for w in weights]
         ws = arr(*[0 if w is None else w.data_ptr() for w in keep])
     cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
-    _lib.call("fvk_rmsnorm_rope_bf16", ins, os_, ws, n, _p(cos), _p(sin), M, width, head_dim, seq_len or M, stride, ostride,
+    _lib.call("fvk_rmsnorm_rope_bf16", ins, os_, ws, n, _p(cos), _p(sin), M, width, head_dim, seq_len or M, int(pos_offset), stride, ostride,
               float(eps), _stream())
     return outs
 

@@ -1,0 +1,222 @@
+"""Host of the per-step Wan video-DiT forward on MI355X: the reference's ``WanTransformer3DModel.forward``
+(fastvideo/models/dits/wanvideo.py:656-766) and ``WanTransformerBlock.forward`` (``:361-434``; ``_VSA`` variant
+``:520-582``) re-expressed as a short chain of fused HIP kernels (fastvideo_amd.ops -> libfvk_amd.so).
+
+Same constructor inputs as the reference module needs at run time (a reference ``state_dict`` with the reference's
+parameter names, heads / head_dim / patch size / eps) and the same call signature
+``forward(hidden_states[B,C,T,H,W], encoder_hidden_states[B,L,text_dim], timestep[B]) -> [B,C_out,T,H,W]``.
+
+Kernel chain per block (S = tokens on this rank, d = model dim), with the reference op each replaces:
+    ln_modulate                 norm1 + (1+scale)·x+shift                        wanvideo.py:393
+    gemm [S,d]x[d,3d]           to_q | to_k | to_v fused (one pass over the activations)   :394-396
+    rmsnorm_rope (q,k)          RMSNorm across heads + 3-D RoPE                   :398-401, layer.py:130-132
+    v_transpose                 V -> MFMA-ready V^T                               (layout op, no reference equivalent)
+    attention                   dense / video-sparse / sliding-tile               layer.py:147, backends/*
+    gemm to_out                 + bias                                            :411
+    ln_modulate(residual,gate)  ScaleResidualLayerNormScaleShift (affine LN)      :414-421
+    gemm to_q(cross) -> rmsnorm; text K/V are projected once per forward for all layers
+    attention (512 text keys)   LocalAttention                                    :188-222
+    gemm to_out(cross)
+    ln_modulate(residual)       ScaleResidualLayerNormScaleShift (no affine)      :425-427
+    gemm fc_in + GELU-tanh epilogue;  gemm fc_out + gated-residual epilogue       :430-431
+No eager / CPU fallback exists: every tensor op on the token axis is a HIP kernel; torch is used only for the
+[B, 6, d]-sized modulation vectors, allocation and collectives."""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import kernel_api, ops, rope
+from .distributed import SequenceParallel
+
+BF16 = torch.bfloat16
+
+
+class WanTransformer3DModelHip:
+
+    def __init__(self, state_dict: dict, num_heads: int, head_dim: int = 128, patch_size=(1, 2, 2), eps: float = 1e-6,
+                 freq_dim: int = 256, attention: str = "dense", vsa_sparsity: float = 0.8, sta_window=(3, 3, 3),
+                 sta_tile=(6, 8, 8), sp_group=None, device="cuda"):
+        if head_dim != 128:
+            raise ValueError("the gfx950 attention kernels are specialised for head_dim 128 (Wan2.1 / Wan2.2)")
+        if attention not in ("dense", "vsa", "sta"):
+            raise ValueError(f"unknown attention mode {attention!r}")
+        self.H, self.D, self.d = num_heads, head_dim, num_heads * head_dim
+        self.patch, self.eps, self.freq_dim = tuple(patch_size), eps, freq_dim
+        self.attention, self.vsa_sparsity = attention, vsa_sparsity
+        self.sta_window, self.sta_tile = tuple(sta_window), tuple(sta_tile)
+        self.device = torch.device(device)
+        self.sp = SequenceParallel(num_heads, sp_group)
+        if attention != "dense" and self.sp.lay.P != 1:
+            raise NotImplementedError("sparse attention under sequence parallelism is wired in a later round")
+        self.num_layers = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
+        self._load(state_dict)
+        self._vsa_cache = {}
+
+    # ------------------------------------------------------------------ weights
+    def _load(self, sd):
+        dev = self.device
+        b16 = lambda t: t.detach().to(device=dev, dtype=BF16).contiguous()
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        g = lambda k: sd[k]
+        w = {}
+        pe = g("patch_embedding.proj.weight")
+        w["pe_w"], w["pe_b"] = b16(pe.reshape(pe.shape[0], -1)), b16(g("patch_embedding.proj.bias"))
+        for n in ("time_embedder.mlp.fc_in", "time_embedder.mlp.fc_out", "time_modulation.linear", "text_embedder.fc_in",
+                  "text_embedder.fc_out"):
+            w[n + ".w"], w[n + ".b"] = b16(g(f"condition_embedder.{n}.weight")), b16(g(f"condition_embedder.{n}.bias"))
+        w["proj_out.w"], w["proj_out.b"] = b16(g("proj_out.weight")), b16(g("proj_out.bias"))
+        self.out_table = b16(g("scale_shift_table"))  # [1,2,d] kept in the parameter dtype (bf16 math, wanvideo.py:754)
+        self.w = w
+        self.vsa_gate = any(k.endswith("to_gate_compress.weight") for k in sd)
+        L = self.num_layers
+        blocks = []
+        tables = []
+        kv_w, kv_b = [], []
+        for i in range(L):
+            p = f"blocks.{i}."
+            b = {}
+            qkv_names = ["to_q", "to_k", "to_v"] + (["to_gate_compress"] if self.vsa_gate and self.attention == "vsa" else [])
+            b["qkv_w"] = b16(torch.cat([g(p + n + ".weight") for n in qkv_names], 0))
+            b["qkv_b"] = b16(torch.cat([g(p + n + ".bias") for n in qkv_names], 0))
+            b["n_qkv"] = len(qkv_names)
+            b["nq_w"], b["nk_w"] = b16(g(p + "norm_q.weight")), b16(g(p + "norm_k.weight"))
+            b["o_w"], b["o_b"] = b16(g(p + "to_out.weight")), b16(g(p + "to_out.bias"))
+            b["ln2_w"], b["ln2_b"] = f32(g(p + "self_attn_residual_norm.norm.weight")), f32(g(p + "self_attn_residual_norm.norm.bias"))
+            b["cq_w"], b["cq_b"] = b16(g(p + "attn2.to_q.weight")), b16(g(p + "attn2.to_q.bias"))
+            b["cnq_w"], b["cnk_w"] = b16(g(p + "attn2.norm_q.weight")), b16(g(p + "attn2.norm_k.weight"))
+            b["co_w"], b["co_b"] = b16(g(p + "attn2.to_out.weight")), b16(g(p + "attn2.to_out.bias"))
+            b["f1_w"], b["f1_b"] = b16(g(p + "ffn.fc_in.weight")), b16(g(p + "ffn.fc_in.bias"))
+            b["f2_w"], b["f2_b"] = b16(g(p + "ffn.fc_out.weight")), b16(g(p + "ffn.fc_out.bias"))
+            kv_w += [g(p + "attn2.to_k.weight"), g(p + "attn2.to_v.weight")]
+            kv_b += [g(p + "attn2.to_k.bias"), g(p + "attn2.to_v.bias")]
+            tables.append(g(p + "scale_shift_table"))
+            blocks.append(b)
+        self.blocks = blocks
+        # all layers' text K/V projections as ONE GEMM over the 512 text tokens: [L*2d, d]
+        self.ckv_w, self.ckv_b = b16(torch.cat(kv_w, 0)), b16(torch.cat(kv_b, 0))
+        self.tables = b16(torch.stack(tables, 0))  # [L,1,6,d] in parameter dtype (bf16 + fp32 temb -> fp32, :386-390)
+
+    # ------------------------------------------------------------------ attention variants
+    def _vsa_meta(self, grid):
+        m = self._vsa_cache.get(grid)
+        if m is None:
+            h = ops.vsa_build_metadata_host(grid)
+            m = {k: (v.to(self.device) if isinstance(v, torch.Tensor) else v) for k, v in h.items()}
+            m["S_pad"] = math.prod(m["num_tiles"]) * 64
+            m["topk"] = max(1, min(math.ceil((1 - self.vsa_sparsity) * m["variable_block_sizes"].numel()),
+                                   m["variable_block_sizes"].numel()))
+            self._vsa_cache[grid] = m
+        return m
+
+    def _attn_local(self, q, k, v, kv_len, grid, gate=None):
+        """q [Sq,h,D], k/v [Skv,h,D] (strided views ok) -> o [Sq,h,D] contiguous."""
+        q4, k4, v4 = q.unsqueeze(0), k[:kv_len].unsqueeze(0), v[:kv_len].unsqueeze(0)
+        if self.attention == "dense":
+            return ops.attn_dense(q4, k4, v4, scale=self.D**-0.5, layout="bshd")[0]
+        if self.attention == "vsa":
+            # ref: VideoSparseAttentionImpl.preprocess_qkv / forward / postprocess_output (video_sparse_attn.py:254-342)
+            m = self._vsa_meta(grid)
+            S = kv_len
+            tile = lambda t: ops.gather_rows(t[:, :S].contiguous(), m["S_pad"], m["tile_partition_indices"], m["non_pad_index"],
+                                             zero_init=True).transpose(1, 2)  # [1,h,S_pad,D] view (bhsd semantics)
+            tq, tk, tv = tile(q4), tile(k4), tile(v4)
+            tg = tile(gate.unsqueeze(0)) if gate is not None else None
+            vbs = m["variable_block_sizes"]
+            o = kernel_api.video_sparse_attn(tq.contiguous(), tk.contiguous(), tv.contiguous(), vbs, vbs, m["topk"], (4, 4, 4),
+                                             None if tg is None else tg.contiguous())
+            o = ops.gather_rows(o.transpose(1, 2).contiguous(), S, m["untile_combined_index"], None)
+            if q.shape[0] != S:
+                o = torch.cat([o, o.new_zeros((1, q.shape[0] - S, *o.shape[2:]))], 1)
+            return o[0]
+        # sliding tile attention: tokens must be in tile-major order on a canvas padded to whole tiles
+        raise NotImplementedError("sta mode in the full model is wired in a later round (kernel: ops.attn_sta)")
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, hidden_states, encoder_hidden_states, timestep, trace=None):
+        dev, d, H, D = self.device, self.d, self.H, self.D
+        if hidden_states.device.type != "cuda":
+            raise RuntimeError("WanTransformer3DModelHip runs on a ROCm device only (no CPU fallback)")
+        B, C, T, Hh, W = hidden_states.shape
+        pt, ph, pw = self.patch
+        grid = (T // pt, Hh // ph, W // pw)
+        S = math.prod(grid)
+        w = self.w
+        sp = self.sp
+        P, rank = sp.lay.P, sp.lay.rank
+        cos, sin = rope.get_rotary_pos_embed(grid, D, device=dev)
+
+        # patch embedding (Conv3d k=s=patch == GEMM over patch rows), then shard the token axis
+        x = ops.gemm(ops.patchify(hidden_states.to(BF16), self.patch).view(B * S, -1), w["pe_w"], w["pe_b"]).view(B, S, d)
+        x = sp.shard(x, dim=1)
+        Sl = x.shape[1]
+        pos0 = rank * Sl
+
+        # condition embedder (wanvideo.py:102-136)
+        t_freq = ops.timestep_embedding(timestep.to(dev), self.freq_dim)
+        h = ops.gemm(t_freq, w["time_embedder.mlp.fc_in.w"], w["time_embedder.mlp.fc_in.b"], epilogue=ops.EPI_SILU)
+        temb = ops.gemm(h, w["time_embedder.mlp.fc_out.w"], w["time_embedder.mlp.fc_out.b"])
+        tproj = ops.gemm(ops.silu(temb), w["time_modulation.linear.w"], w["time_modulation.linear.b"]).view(B, 6, d)
+        ctx = encoder_hidden_states.to(device=dev, dtype=BF16)
+        Lc = ctx.shape[1]
+        c = ops.gemm(ctx.reshape(B * Lc, -1), w["text_embedder.fc_in.w"], w["text_embedder.fc_in.b"], epilogue=ops.EPI_GELU_TANH)
+        c = ops.gemm(c, w["text_embedder.fc_out.w"], w["text_embedder.fc_out.b"])
+        ckv = ops.gemm(c, self.ckv_w, self.ckv_b)  # [B*Lc, L*2d]: every layer's text K and V
+
+        # AdaLN vectors for all layers at once: e = table + temb.float()  -> [L,B,6,d] fp32 (wanvideo.py:386-390)
+        e = self.tables + tproj.float().unsqueeze(0)
+        shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = (e[:, :, j].contiguous() for j in range(6))
+        mul_msa, mul_c = 1 + scale_msa, 1.0 + c_scale
+
+        x = x.reshape(B * Sl, d)
+        for i, b in enumerate(self.blocks):
+            nh = ops.ln_modulate(x, mul=mul_msa[i], add=shift_msa[i], eps=self.eps, rows_per_batch=Sl)
+            qkv = ops.gemm(nh, b["qkv_w"], b["qkv_b"])  # [B*Sl, 3d (+d gate)]
+            nq = b["n_qkv"]
+            attn = torch.empty((B * Sl, d), dtype=BF16, device=dev) if B > 1 else None
+            for bi in range(B):
+                rows = qkv[bi * Sl:(bi + 1) * Sl]
+                q, k = ops.rmsnorm_rope([rows[:, :d], rows[:, d:2 * d]], [b["nq_w"], b["nk_w"]], cos, sin, head_dim=D, seq_len=S,
+                                        eps=self.eps, pos_offset=pos0)
+                v = rows[:, 2 * d:3 * d]
+                gate = rows[:, 3 * d:4 * d].view(Sl, H, D) if nq == 4 else None
+                fn = lambda q_, k_, v_, kv_len: self._attn_local(q_, k_, v_, kv_len, grid, gate)
+                o = sp.attention(q.view(Sl, H, D), k.view(Sl, H, D), v.view(Sl, H, D), S, fn).reshape(Sl, d)
+                if B == 1:
+                    attn = o
+                else:
+                    attn[bi * Sl:(bi + 1) * Sl] = o
+            a_out = ops.gemm(attn, b["o_w"], b["o_b"])
+            nh, x = ops.ln_modulate(a_out, residual=x, gate=gate_msa[i], ln_w=b["ln2_w"], ln_b=b["ln2_b"], eps=self.eps,
+                                    want_residual=True, rows_per_batch=Sl)
+            if trace is not None:
+                trace[f"blocks.{i}.after_self_attn"] = x.view(B, Sl, d).clone()
+            # cross attention over the text tokens (WanT2VCrossAttention, wanvideo.py:188-222)
+            cq = ops.gemm(nh, b["cq_w"], b["cq_b"])
+            cq = ops.rmsnorm_rope([cq], [b["cnq_w"]], head_dim=D, seq_len=Sl, eps=self.eps)[0]
+            kv = ckv[:, i * 2 * d:(i + 1) * 2 * d]
+            ck = ops.rmsnorm_rope([kv[:, :d]], [b["cnk_w"]], head_dim=D, seq_len=Lc, eps=self.eps)[0]
+            co = ops.attn_dense(cq.view(B, Sl, H, D), ck.view(B, Lc, H, D), kv[:, d:].view(B, Lc, H, D), scale=D**-0.5,
+                                layout="bshd")
+            c_out = ops.gemm(co.view(B * Sl, d), b["co_w"], b["co_b"])
+            nh, x = ops.ln_modulate(c_out, residual=x, mul=mul_c[i], add=c_shift[i], eps=self.eps, round_residual=True,
+                                    round_norm=True, want_residual=True, rows_per_batch=Sl)
+            f = ops.gemm(nh, b["f1_w"], b["f1_b"], epilogue=ops.EPI_GELU_TANH)
+            x = ops.gemm(f, b["f2_w"], b["f2_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=c_gate[i], rows_per_batch=Sl)
+            if trace is not None:
+                trace[f"blocks.{i}.out"] = x.view(B, Sl, d).clone()
+
+        # output norm (bf16 modulation vectors, wanvideo.py:746-756), gather, projection, unpatchify
+        ss = self.out_table + temb.unsqueeze(1)           # [B,2,d] bf16
+        shift, scale = ss[:, 0], ss[:, 1]
+        x = ops.ln_modulate(x, mul=(1.0 + scale).float(), add=shift.float(), eps=self.eps, round_norm=True, rows_per_batch=Sl)
+        x = sp.all_gather_unpad(x.view(B, Sl, d), S, dim=1)
+        if trace is not None:
+            trace["norm_out"] = x.clone()
+        y = ops.gemm(x.reshape(B * S, d), w["proj_out.w"], w["proj_out.b"])
+        c_out = y.shape[-1] // (pt * ph * pw)
+        return ops.unpatchify(y.view(B, S, -1), (B, c_out, T, Hh, W), self.patch)
+
+    __call__ = forward

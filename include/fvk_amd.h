@@ -59,10 +59,11 @@ int fvk_scale_residual_bf16(const void* residual, const void* x, const float* ga
  * Processes `n_tensors` (1..3) tensors per launch: in[i]/out[i] rows start `in_stride`/`out_stride`
  * elements apart (so q,k slices of a fused [M,3d] QKV buffer work in place of separate tensors).
  * weight[i]: bf16 [width] or NULL (skip norm).  cos/sin: fp32 [seq_len, head_dim] or NULL (skip RoPE);
- * row m uses position m % seq_len.  head_dim % 8 == 0. */
+ * row m uses position (m + pos_offset) % seq_len (pos_offset = first global token of a sequence-parallel shard).
+ * head_dim % 8 == 0. */
 int fvk_rmsnorm_rope_bf16(const void* const* in, void* const* out, const void* const* weight, int n_tensors,
                           const float* cos, const float* sin, int M, int width, int head_dim, int seq_len,
-                          long in_stride, long out_stride, float eps, void* stream);
+                          int pos_offset, long in_stride, long out_stride, float eps, void* stream);
 
 /* V[b, s, h, :] at v + b*in_batch_stride + s*in_stride + h*in_head_stride (elements) -> Vt [B, H, D, S_pad] bf16,
  * S_pad = round_up(S, 64), pad columns zero.  Within every aligned group of 16 keys the key order is

@@ -1,0 +1,75 @@
+"""End-to-end parity of the HIP Wan DiT forward against the REFERENCE's own outputs (tests/golden/wan_tiny.pt, produced by
+oracle/make_golden.py from /root/reference) and against the oracle's per-block traces.  Tolerance: the reference's own
+DiT-vs-diffusers bound atol=1e-1, rtol=1e-2 (fastvideo/tests/transformers/test_wanvideo.py:109); we also assert a much
+tighter mean error."""
+import os
+
+import pytest
+import torch
+
+from oracle import wan_oracle as W
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tiny(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.load(os.path.join(golden_dir, "wan_tiny.pt"), weights_only=False)
+
+
+def _cmp(y, ref, what, atol=1e-1, rtol=1e-2, mean_tol=1.5e-2):
+    y, ref = y.float().cpu(), ref.float()
+    assert torch.isfinite(y).all(), what
+    err = (y - ref).abs()
+    bad = err > atol + rtol * ref.abs()
+    print(f"{what}: max|err|={err.max().item():.4g} mean|err|={err.mean().item():.4g} ref_absmean={ref.abs().mean().item():.4g}")
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} outside tolerance, max {err.max().item():.4g}"
+    assert err.mean().item() < mean_tol, f"{what}: mean error {err.mean().item():.4g}"
+
+
+def test_wan_tiny_forward_matches_reference(tiny):
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    model = WanTransformer3DModelHip(tiny["state_dict"], num_heads=tiny["config"]["num_heads"])
+    for ci, case in enumerate(tiny["cases"]):
+        trace = {}
+        y = model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda(), trace=trace)
+        for i, blk in enumerate(case["blocks"]):
+            _cmp(trace[f"blocks.{i}.out"], blk, f"case {ci} block {i}")
+        _cmp(y, case["out"], f"case {ci} output")
+        assert y.shape == case["out"].shape and y.dtype == torch.bfloat16
+
+
+def test_wan_tiny_vsa_matches_oracle(tiny):
+    """VSA attention inside the full model (no gate weights in the fixture -> out_c + out_s), oracle = same model with the
+    oracle's video_sparse_attn substituted for SDPA (reference wiring: video_sparse_attn.py:254-342)."""
+    import math
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    from oracle import vsa_oracle as V
+    case = tiny["cases"][1]
+    H = tiny["config"]["num_heads"]
+    lat = tuple(case["latent"].shape[2:])
+    md = V.build_metadata(lat)
+    topk = V.compute_topk(0.5, len(md["variable_block_sizes"]))
+
+    def vsa_attention(q, k, v, scale):
+        tq, tk, tv = (V.tile(t, md).transpose(1, 2).contiguous() for t in (q, k, v))
+        o, _ = V.video_sparse_attn(tq, tk, tv, md["variable_block_sizes"], md["variable_block_sizes"], topk, 64, None)
+        return V.untile(o.transpose(1, 2), md)
+
+    orc = W.WanOracle(tiny["state_dict"], num_heads=H)
+    orc.attention = vsa_attention
+    with torch.no_grad():
+        ref = orc.forward(case["latent"], case["ctx"], case["timestep"])
+    model = WanTransformer3DModelHip(tiny["state_dict"], num_heads=H, attention="vsa", vsa_sparsity=0.5)
+    y = model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda())
+    # top-k selection is discontinuous: a different block choice on a near-tie changes a few rows; bound the bulk
+    err = (y.float().cpu() - ref.float()).abs()
+    print(f"vsa model: max|err|={err.max().item():.4g} mean|err|={err.mean().item():.4g}")
+    assert err.mean().item() < 3e-2
+
+
+def test_smoke_entry():
+    import __graft_entry__ as G
+    G.smoke()
