@@ -1,0 +1,178 @@
+#!/usr/bin/env python
+"""bench.py — the contract benchmark: one "step" = one Wan2.1-T2V-1.3B DiT forward (the per-step denoising hot path,
+SURVEY.md §8a2) over a synthetic 81f x 832 x 480 latent ([1,16,21,60,104] -> 32 760 tokens), bf16, random-init weights
+of the 1.3B architecture, dense attention (BASELINE.json configs[1]).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1 shards the token axis over the N GPUs with 2-D Ulysses sequence parallelism (fastvideo_amd/distributed.py; RCCL
+all-to-all over xGMI), i.e. the SAME forward split N ways -> "strong" scaling.  Rank 0 prints ONE JSON line.
+`value` = latent tokens per second of the whole job; inputs are resident in HBM before the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md); never the 2:1-sparse figure
+
+
+def cpu_baseline(cfg, S, L_text, max_seconds=40.0):
+    """Reference-algorithm CPU baseline ("port" = oracle/wan_oracle.py, the bit-exact restatement of the reference eager path)
+    on a BOUNDED sample: ONE of the 30 transformer blocks at the full sequence length, extrapolated x num_layers."""
+    from oracle import wan_oracle as W
+    from fastvideo_amd.wan_config import WanConfig, random_state_dict
+    one = WanConfig(cfg.name, cfg.num_heads, cfg.head_dim, cfg.ffn_dim, 1, cfg.text_dim)
+    sd = random_state_dict(one, seed=0, device="cpu")
+    orc = W.WanOracle(sd, num_heads=cfg.num_heads)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    g = torch.Generator().manual_seed(1)
+    grid = (21, 30, 52)
+    # shrink the sample if one full-length block would blow the time budget: time a 1/8-length block first
+    S_probe = S // 8
+    def run(Sx):
+        x = torch.randn((1, Sx, cfg.dim), generator=g).bfloat16()
+        ctx = torch.randn((1, L_text, cfg.dim), generator=g).bfloat16()
+        tproj = (torch.randn((1, 6, cfg.dim), generator=g) * 0.1).bfloat16()
+        cos, sin = W.rope_tables(grid, cfg.head_dim)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            orc.block(0, x, ctx, tproj, cos[:Sx], sin[:Sx])
+        return time.perf_counter() - t0
+    t_probe = run(S_probe)
+    # attention is quadratic, the rest linear: conservative estimate of the full-length block time
+    est_full = t_probe * 64
+    if est_full <= max_seconds:
+        t_block, S_used, note = run(S), S, "1 of 30 transformer blocks at full S=32760"
+        per_forward = t_block * cfg.num_layers
+    else:
+        # measure at S/2 and scale the attention part x4 / linear part x2 using algorithmic FLOP shares
+        from fastvideo_amd.wan_config import algorithmic_flops
+        S_half = S // 2
+        t_half = run(S_half) if t_probe * 16 <= max_seconds else t_probe
+        S_used = S_half if t_probe * 16 <= max_seconds else S_probe
+        fl_used, fl_full = algorithmic_flops(one, S_used, L_text)["total"], algorithmic_flops(one, S, L_text)["total"]
+        per_forward = t_half * (fl_full / fl_used) * cfg.num_layers
+        note = f"1 of 30 transformer blocks at S={S_used}, scaled by algorithmic FLOPs to S={S}"
+    return dict(value=S / per_forward, unit="latent-tokens/s", cores=cores, kind="port",
+                sample=note + " (oracle/wan_oracle.py, torch CPU bf16), extrapolated x30 layers",
+                ms_per_step=per_forward * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--attention", default="dense", choices=["dense", "vsa"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import __graft_entry__ as G
+    G.build()
+    from fastvideo_amd import wan_config as WC
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+
+    cfg = WC.WAN21_T2V_1_3B
+    if args.layers:
+        cfg = WC.WanConfig(cfg.name, cfg.num_heads, cfg.head_dim, cfg.ffn_dim, args.layers)
+    latent_shape = WC.LATENT_81F_480P
+    L_text = 512
+    S = (latent_shape[2] // 1) * (latent_shape[3] // 2) * (latent_shape[4] // 2)
+
+    sd = WC.random_state_dict(cfg, seed=0, device=dev, with_vsa_gate=(args.attention == "vsa"))
+    model = WanTransformer3DModelHip(sd, cfg.num_heads, cfg.head_dim, cfg.patch_size, cfg.eps, cfg.freq_dim,
+                                     attention=args.attention, device=dev)
+    del sd
+    g = torch.Generator(device=dev).manual_seed(1)
+    latent = torch.randn(latent_shape, generator=g, device=dev).bfloat16()
+    ctx = torch.randn((1, L_text, cfg.text_dim), generator=g, device=dev).bfloat16()
+    ts = torch.tensor([500.0], device=dev)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        y = model(latent, ctx, ts)
+    sync()
+    model.attn_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = model(latent, ctx, ts)
+    sync()
+    elapsed = time.perf_counter() - t0
+    events, model.attn_events = model.attn_events, None
+    if not torch.isfinite(y.float()).all():
+        raise SystemExit("non-finite output")
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    # roofline of the dominant kernel (dense self-attention): algorithmic FLOPs per launch / mean launch duration
+    attn_ms = [e0.elapsed_time(e1) for e0, e1, *_ in events]
+    _, _, Sq, Skv, h = events[0]
+    flops_launch = 4.0 * Sq * Skv * h * cfg.head_dim
+    mean_ms = sum(attn_ms) / len(attn_ms)
+    achieved = flops_launch / (mean_ms * 1e-3) / 1e12
+    roof = dict(bound="mfma", kernel="attn_fwd_kernel<4,dense> (self-attention)", achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS,
+                unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+                flops_per_launch=flops_launch, mean_launch_ms=round(mean_ms, 4), launches=len(attn_ms),
+                share_of_step=round(sum(attn_ms) / args.steps / (elapsed / args.steps * 1e3), 3))
+    fl = WC.algorithmic_flops(cfg, S, L_text)
+    ms_per_step = elapsed / args.steps * 1e3
+    lay = model.sp.lay
+    par = "sp1" if world == 1 else f"sp{world} 2-D Ulysses (head groups {lay.G} x query blocks {lay.U})"
+    out = {
+        "metric": "DiT-step latent-tokens/s, Wan2.1-T2V-1.3B 81fx480p (one DiT forward per step)",
+        "value": round(S / (elapsed / args.steps), 1), "unit": "latent-tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (randn latent, random-init weights)",
+        "config": {"workload": f"{cfg.name} {cfg.num_layers} layers, latent {list(latent_shape)} = {S} tokens, text 512 tokens, "
+                               f"{args.attention} attention, 1 forward/step (no CFG)", "parallelism": par},
+        "step_tflops": round(fl["total"] / (ms_per_step * 1e-3) / 1e12, 1),
+        "step_frac_of_bf16_peak": round(fl["total"] / (ms_per_step * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
+        "roofline": roof,
+    }
+    if args.layers:
+        out["INVALID"] = "debug run with fewer layers"
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(cfg, S, L_text)
+            except Exception as ex:  # the baseline must never hide the GPU number
+                out["cpu_baseline"] = {"error": repr(ex)[:300]}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

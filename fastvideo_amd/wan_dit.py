@@ -53,6 +53,7 @@ class WanTransformer3DModelHip:
         self.num_layers = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
         self._load(state_dict)
         self._vsa_cache = {}
+        self.attn_events = None  # set to a list to collect (start, end, Sq, Skv, heads) HIP-event pairs
 
     # ------------------------------------------------------------------ weights
     def _load(self, sd):
@@ -114,7 +115,16 @@ class WanTransformer3DModelHip:
         """q [Sq,h,D], k/v [Skv,h,D] (strided views ok) -> o [Sq,h,D] contiguous."""
         q4, k4, v4 = q.unsqueeze(0), k[:kv_len].unsqueeze(0), v[:kv_len].unsqueeze(0)
         if self.attention == "dense":
-            return ops.attn_dense(q4, k4, v4, scale=self.D**-0.5, layout="bshd")[0]
+            vt = ops.v_transpose(v4)
+            if self.attn_events is None:
+                return ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd")[0]
+            # bench.py roofline leg: HIP events on the launch stream around the dominant kernel only
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o = ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd")[0]
+            e1.record()
+            self.attn_events.append((e0, e1, q4.shape[1], k4.shape[1], q4.shape[2]))
+            return o
         if self.attention == "vsa":
             # ref: VideoSparseAttentionImpl.preprocess_qkv / forward / postprocess_output (video_sparse_attn.py:254-342)
             m = self._vsa_meta(grid)
