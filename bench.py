@@ -27,47 +27,47 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md); never the 2:1-sparse figure
 
 
-def cpu_baseline(cfg, S, L_text, max_seconds=40.0):
-    """Reference-algorithm CPU baseline ("port" = oracle/wan_oracle.py, the bit-exact restatement of the reference eager path)
-    on a BOUNDED sample: ONE of the 30 transformer blocks at the full sequence length, extrapolated x num_layers."""
+def cpu_baseline(cfg, S, L_text, budget_s=25.0):
+    """Reference-algorithm CPU baseline ("port" = oracle/wan_oracle.py, the restatement of the reference eager path that is
+    pinned bit-exact against the real reference) on a BOUNDED sample: ONE of the 30 transformer blocks, fp32 weights and
+    activations (the reference's CPU harness dtype), at the largest sequence length whose block fits the time
+    budget, scaled to the full S by algorithmic FLOPs and x30 layers."""
     from oracle import wan_oracle as W
-    from fastvideo_amd.wan_config import WanConfig, random_state_dict
+    from fastvideo_amd.wan_config import WanConfig, algorithmic_flops, random_state_dict
     one = WanConfig(cfg.name, cfg.num_heads, cfg.head_dim, cfg.ffn_dim, 1, cfg.text_dim)
-    sd = random_state_dict(one, seed=0, device="cpu")
+    sd = {k: v.float() for k, v in random_state_dict(one, seed=0, device="cpu").items()}
     orc = W.WanOracle(sd, num_heads=cfg.num_heads)
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(cores, 64)  # torch CPU GEMM/SDPA stop scaling (and oversubscribe) far below 256 threads
+    torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(1)
-    grid = (21, 30, 52)
-    # shrink the sample if one full-length block would blow the time budget: time a 1/8-length block first
-    S_probe = S // 8
+    cos_full, sin_full = W.rope_tables((21, 30, 52), cfg.head_dim)
+
     def run(Sx):
-        x = torch.randn((1, Sx, cfg.dim), generator=g).bfloat16()
-        ctx = torch.randn((1, L_text, cfg.dim), generator=g).bfloat16()
-        tproj = (torch.randn((1, 6, cfg.dim), generator=g) * 0.1).bfloat16()
-        cos, sin = W.rope_tables(grid, cfg.head_dim)
+        x = torch.randn((1, Sx, cfg.dim), generator=g)
+        ctx = torch.randn((1, L_text, cfg.dim), generator=g)
+        tproj = torch.randn((1, 6, cfg.dim), generator=g) * 0.1
         t0 = time.perf_counter()
         with torch.no_grad():
-            orc.block(0, x, ctx, tproj, cos[:Sx], sin[:Sx])
+            orc.block(0, x, ctx, tproj, cos_full[:Sx], sin_full[:Sx])
         return time.perf_counter() - t0
-    t_probe = run(S_probe)
-    # attention is quadratic, the rest linear: conservative estimate of the full-length block time
-    est_full = t_probe * 64
-    if est_full <= max_seconds:
-        t_block, S_used, note = run(S), S, "1 of 30 transformer blocks at full S=32760"
-        per_forward = t_block * cfg.num_layers
-    else:
-        # measure at S/2 and scale the attention part x4 / linear part x2 using algorithmic FLOP shares
-        from fastvideo_amd.wan_config import algorithmic_flops
-        S_half = S // 2
-        t_half = run(S_half) if t_probe * 16 <= max_seconds else t_probe
-        S_used = S_half if t_probe * 16 <= max_seconds else S_probe
-        fl_used, fl_full = algorithmic_flops(one, S_used, L_text)["total"], algorithmic_flops(one, S, L_text)["total"]
-        per_forward = t_half * (fl_full / fl_used) * cfg.num_layers
-        note = f"1 of 30 transformer blocks at S={S_used}, scaled by algorithmic FLOPs to S={S}"
-    return dict(value=S / per_forward, unit="latent-tokens/s", cores=cores, kind="port",
-                sample=note + " (oracle/wan_oracle.py, torch CPU bf16), extrapolated x30 layers",
-                ms_per_step=per_forward * 1e3)
+
+    run(256)  # warm-up: thread pool, oneDNN primitives
+    Sx, t = 1024, run(1024)
+    while Sx * 2 <= S:
+        fl_ratio = algorithmic_flops(one, Sx * 2, L_text)["total"] / algorithmic_flops(one, Sx, L_text)["total"]
+        if t * fl_ratio > budget_s:
+            break
+        Sx *= 2
+        t = run(Sx)
+    if Sx * 2 > S and t * (algorithmic_flops(one, S, L_text)["total"] / algorithmic_flops(one, Sx, L_text)["total"]) <= budget_s:
+        Sx, t = S, run(S)
+    scale = algorithmic_flops(one, S, L_text)["total"] / algorithmic_flops(one, Sx, L_text)["total"]
+    per_forward = t * scale * cfg.num_layers
+    return dict(value=round(S / per_forward, 2), unit="latent-tokens/s", cores=threads, kind="port",
+                sample=f"1 of {cfg.num_layers} transformer blocks at S={Sx} in {t:.2f} s (oracle/wan_oracle.py, torch CPU fp32, "
+                       f"{threads} threads of {cores} cores), scaled by algorithmic FLOPs to S={S} and x{cfg.num_layers} layers",
+                ms_per_step=round(per_forward * 1e3, 1))
 
 
 def main():

@@ -61,6 +61,9 @@ class SequenceParallel:
             P, rank = 1, 0
         G = math.gcd(num_heads, P)
         self.lay = SPLayout(P=P, rank=rank, H=num_heads, G=G, U=P // G)
+        # gloo cannot move device memory: stage through the host (used by the 2-process single-GPU parity test;
+        # production runs use backend "nccl" = RCCL, which takes device pointers directly)
+        self._stage_host = P > 1 and dist.get_backend(group) == "gloo"
 
     # -- sharding with zero padding (ref: distributed/utils.py:63-123, communication_op.py:61-91) ---------------
     def padded_len(self, S: int) -> int:
@@ -86,15 +89,22 @@ class SequenceParallel:
         if P == 1:
             return x
         xm = x.movedim(dim, 0).contiguous()
+        dev = xm.device
+        if self._stage_host:
+            xm = xm.cpu()
         out = xm.new_empty((P * xm.shape[0], *xm.shape[1:]))
         dist.all_gather_into_tensor(out, xm, group=self.group)
-        return out[:S].movedim(0, dim).contiguous()
+        return out[:S].movedim(0, dim).contiguous().to(dev)
 
     # -- the exchanges ------------------------------------------------------------------------------------------
     def _a2a(self, send: torch.Tensor, in_splits, out_splits, out_rows: int) -> torch.Tensor:
+        dev = send.device
+        if self._stage_host:
+            send = send.cpu()
         recv = send.new_empty((out_rows, *send.shape[1:]))
-        dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
-        return recv
+        dist.all_to_all_single(recv, send.contiguous(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                               group=self.group)
+        return recv.to(dev)
 
     def scatter_heads_gather_seq(self, q, k, v):
         """q,k,v: this rank's shard [Sl, H, D] (batch 1).  Returns (q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all)."""
