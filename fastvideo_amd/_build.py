@@ -52,6 +52,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    import ctypes
+    try:  # catches e.g. a kernel whose host stub was not emitted (undefined symbol at dlopen time)
+        ctypes.CDLL(LIB)
+    except OSError as e:
+        os.remove(LIB)
+        raise RuntimeError(f"built library does not load: {e}") from e
     return LIB
 
 

@@ -1,0 +1,250 @@
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Any
+
+import torch
+
+from .. import kernel_api, ops
+
+try:  # subclass the reference's ABCs when it is installed (drop-in registration), else use local twins
+    from fastvideo.attention.backends.abstract import (AttentionBackend, AttentionImpl, AttentionMetadata,  # type: ignore
+                                                       AttentionMetadataBuilder)
+except Exception:  # noqa: BLE001 - the GPU box / CI has no reference package
+
+    class AttentionBackend:  # ref: abstract.py:31-66
+        accept_output_buffer: bool = False
+
+    @dataclass
+    class AttentionMetadata:  # ref: abstract.py:69-86
+        current_timestep: int
+        VSA_sparsity: float = field(default=0.0, kw_only=True)
+
+    class AttentionMetadataBuilder:  # ref: abstract.py:92-113
+        pass
+
+    class AttentionImpl:  # ref: abstract.py:133-194
+
+        def preprocess_qkv(self, qkv, attn_metadata):
+            return qkv
+
+        def postprocess_output(self, output, attn_metadata):
+            return output
+
+
+VSA_TILE_SIZE = (4, 4, 4)
+
+
+def _require_bf16_cuda(*ts):
+    for t in ts:
+        if not t.is_cuda or t.dtype != torch.bfloat16:
+            raise RuntimeError("fastvideo_amd attention backends take bf16 ROCm tensors [B,S,H,128] "
+                               f"(got {t.dtype} on {t.device}); there is no eager fallback")
+
+
+# ------------------------------------------------------------------ dense (replaces SDPA / flash-attn on ROCm)
+class HipDenseAttentionImpl(AttentionImpl):
+    """ref: SDPAImpl (fastvideo/attention/backends/sdpa.py:108-147) / FlashAttentionImpl (flash_attn.py:247-345)."""
+
+    def __init__(self, num_heads: int, head_size: int, causal: bool = False, softmax_scale: float | None = None,
+                 num_kv_heads: int | None = None, prefix: str = "", **extra_impl_args) -> None:
+        if causal:
+            raise ValueError("HipDenseAttentionImpl: causal attention is not on the Wan T2V path")
+        if head_size != 128:
+            raise ValueError(f"HipDenseAttentionImpl: head_size {head_size} unsupported (128 only)")
+        if num_kv_heads not in (None, num_heads):
+            raise ValueError("HipDenseAttentionImpl: grouped-query attention is not supported")
+        self.softmax_scale = head_size**-0.5 if softmax_scale is None else softmax_scale
+
+    def forward(self, query, key, value, attn_metadata=None):
+        _require_bf16_cuda(query, key, value)
+        if attn_metadata is not None and getattr(attn_metadata, "attn_mask", None) is not None:
+            raise NotImplementedError("HipDenseAttentionImpl: attention masks are not supported")
+        return ops.attn_dense(query, key, value, scale=self.softmax_scale, layout="bshd")
+
+
+class HipDenseAttentionBackend(AttentionBackend):
+    accept_output_buffer: bool = True
+
+    @staticmethod
+    def get_supported_head_sizes() -> list[int]:
+        return [128]
+
+    @staticmethod
+    def get_name() -> str:
+        return "FLASH_ATTN"  # an existing AttentionBackendEnum member (platforms/interface.py:13-27): no enum change needed
+
+    @staticmethod
+    def get_impl_cls():
+        return HipDenseAttentionImpl
+
+    @staticmethod
+    def get_metadata_cls():
+        return AttentionMetadata
+
+    @staticmethod
+    def get_builder_cls():
+        return None
+
+
+# ------------------------------------------------------------------ VSA (ref: backends/video_sparse_attn.py)
+def compute_topk(sparsity: float, num_blocks: int) -> int:
+    """ref: video_sparse_attn.py:161-163."""
+    return max(1, min(math.ceil((1 - sparsity) * num_blocks), num_blocks))
+
+
+@dataclass
+class VideoSparseAttentionMetadata(AttentionMetadata):  # ref: video_sparse_attn.py:139-158
+    current_timestep: int
+    dit_seq_shape: tuple
+    num_tiles: tuple
+    total_seq_length: int
+    tile_partition_indices: torch.Tensor
+    reverse_tile_partition_indices: torch.Tensor
+    variable_block_sizes: torch.Tensor
+    non_pad_index: torch.Tensor
+    untile_combined_index: torch.Tensor
+    tile_buf: torch.Tensor | None = None
+    cache_tile_buf: bool = True
+
+
+class VideoSparseAttentionMetadataBuilder(AttentionMetadataBuilder):  # ref: video_sparse_attn.py:192-235
+
+    def __init__(self) -> None:
+        pass
+
+    def prepare(self) -> None:
+        pass
+
+    def build(self, current_timestep: int, raw_latent_shape, patch_size, VSA_sparsity: float, device,
+              cache_tile_buf: bool = True, **kwargs: Any) -> VideoSparseAttentionMetadata:
+        shape = tuple(r // p for r, p in zip(raw_latent_shape, patch_size))
+        m = ops.vsa_build_metadata_host(shape, VSA_TILE_SIZE)  # pure-integer C ABI call, bit-exact vs the reference
+        to = lambda t: t.to(device)
+        return VideoSparseAttentionMetadata(
+            current_timestep=current_timestep, dit_seq_shape=shape, VSA_sparsity=VSA_sparsity, num_tiles=m["num_tiles"],
+            total_seq_length=math.prod(shape), tile_partition_indices=to(m["tile_partition_indices"]),
+            reverse_tile_partition_indices=to(m["reverse_tile_partition_indices"]),
+            variable_block_sizes=to(m["variable_block_sizes"]), non_pad_index=to(m["non_pad_index"]),
+            untile_combined_index=to(m["untile_combined_index"]), cache_tile_buf=cache_tile_buf)
+
+
+class HipVideoSparseAttentionImpl(AttentionImpl):
+    """ref: VideoSparseAttentionImpl (video_sparse_attn.py:238-342): preprocess_qkv = tile, forward = video_sparse_attn,
+    postprocess_output = untile.  Index tensors are int32 on device (the reference uses int64)."""
+
+    def __init__(self, num_heads: int, head_size: int, causal: bool = False, softmax_scale: float | None = None,
+                 num_kv_heads: int | None = None, prefix: str = "", **extra_impl_args) -> None:
+        if head_size != 128:
+            raise ValueError(f"HipVideoSparseAttentionImpl: head_size {head_size} unsupported (128 only)")
+        self.prefix = prefix
+
+    def tile(self, x, md: VideoSparseAttentionMetadata):
+        s_pad = math.prod(md.num_tiles) * math.prod(VSA_TILE_SIZE)
+        return ops.gather_rows(x, s_pad, md.tile_partition_indices, md.non_pad_index, zero_init=True)
+
+    def untile(self, x, md: VideoSparseAttentionMetadata):
+        return ops.gather_rows(x, md.total_seq_length, md.untile_combined_index, None)
+
+    def preprocess_qkv(self, qkv, attn_metadata):
+        return self.tile(qkv, attn_metadata)
+
+    def postprocess_output(self, output, attn_metadata):
+        return self.untile(output, attn_metadata)
+
+    def forward(self, query, key, value, gate_compress, attn_metadata):
+        _require_bf16_cuda(query, key, value)
+        md = attn_metadata
+        topk = compute_topk(md.VSA_sparsity, md.variable_block_sizes.numel())
+        t = lambda z: z.transpose(1, 2).contiguous()
+        out = kernel_api.video_sparse_attn(t(query), t(key), t(value), md.variable_block_sizes, md.variable_block_sizes, topk,
+                                           block_size=VSA_TILE_SIZE,
+                                           compress_attn_weight=None if gate_compress is None else t(gate_compress))
+        return out.transpose(1, 2)
+
+
+class HipVideoSparseAttentionBackend(AttentionBackend):
+    accept_output_buffer: bool = True
+
+    @staticmethod
+    def get_supported_head_sizes() -> list[int]:
+        return [128]
+
+    @staticmethod
+    def get_name() -> str:
+        return "VIDEO_SPARSE_ATTN"
+
+    @staticmethod
+    def get_impl_cls():
+        return HipVideoSparseAttentionImpl
+
+    @staticmethod
+    def get_metadata_cls():
+        return VideoSparseAttentionMetadata
+
+    @staticmethod
+    def get_builder_cls():
+        return VideoSparseAttentionMetadataBuilder
+
+
+# ------------------------------------------------------------------ STA (the archived SLIDING_TILE_ATTN backend)
+class HipSlidingTileAttentionImpl(AttentionImpl):
+    """Tokens are permuted raster -> tile-major (tile (6,8,8) by default) in preprocess_qkv and back in postprocess_output;
+    the canvas must be divisible by the tile (the reference kernels hard-code three such canvases)."""
+
+    def __init__(self, num_heads: int, head_size: int, causal: bool = False, softmax_scale: float | None = None,
+                 num_kv_heads: int | None = None, prefix: str = "", *, canvas_thw=None, tile_thw=(6, 8, 8),
+                 window_size=None, **extra_impl_args) -> None:
+        if head_size != 128:
+            raise ValueError(f"HipSlidingTileAttentionImpl: head_size {head_size} unsupported (128 only)")
+        if canvas_thw is None or any(c % t for c, t in zip(canvas_thw, tile_thw)):
+            raise ValueError(f"HipSlidingTileAttentionImpl: canvas {canvas_thw} must be divisible by tile {tile_thw}")
+        self.canvas, self.tile_thw = tuple(canvas_thw), tuple(tile_thw)
+        self.windows = list(window_size) if window_size is not None else [(3, 3, 3)] * num_heads
+        if len(self.windows) != num_heads:
+            raise ValueError("HipSlidingTileAttentionImpl: window_size must list one (t,h,w) per head")
+        m = ops.vsa_build_metadata_host(self.canvas, self.tile_thw)  # same raster->tile permutation as VSA, other tile
+        self._perm, self._rev = m["tile_partition_indices"], m["reverse_tile_partition_indices"]
+
+    def _idx(self, name, device):
+        t = getattr(self, name)
+        if t.device != device:
+            t = t.to(device)
+            setattr(self, name, t)
+        return t
+
+    def preprocess_qkv(self, qkv, attn_metadata=None):
+        return ops.gather_rows(qkv, qkv.shape[1], self._idx("_perm", qkv.device), None)
+
+    def postprocess_output(self, output, attn_metadata=None):
+        return ops.gather_rows(output, output.shape[1], self._idx("_rev", output.device), None)
+
+    def forward(self, query, key, value, attn_metadata=None):
+        _require_bf16_cuda(query, key, value)
+        tiles = tuple(c // t for c, t in zip(self.canvas, self.tile_thw))
+        return ops.attn_sta(query, key, value, tiles, math.prod(self.tile_thw), self.windows, layout="bshd")
+
+
+class HipSlidingTileAttentionBackend(AttentionBackend):
+    accept_output_buffer: bool = True
+
+    @staticmethod
+    def get_supported_head_sizes() -> list[int]:
+        return [128]
+
+    @staticmethod
+    def get_name() -> str:
+        return "SLIDING_TILE_ATTN"
+
+    @staticmethod
+    def get_impl_cls():
+        return HipSlidingTileAttentionImpl
+
+    @staticmethod
+    def get_metadata_cls():
+        return AttentionMetadata
+
+    @staticmethod
+    def get_builder_cls():
+        return None

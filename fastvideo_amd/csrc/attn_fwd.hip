@@ -11,9 +11,10 @@
 //                         no lane exchange — because V^T is stored (by fvk_v_transpose_bf16) with the keys
 //                         of every 16-group permuted into the accumulator's row order ((r&3)+8(r>>2)+4hi).
 //                         A = V^T tile rows (ds_read_b128).  The O rescale factor is a per-lane scalar.
-//   * K / V^T tiles: global -> registers -> LDS, double-buffered, next tile's loads issued before this tile's
-//     MFMAs and written after them (guide T14), one barrier per tile.  16-B chunk XOR swizzles make every
-//     fragment read conflict-free (K rows are 256 B: chunk ^= row&15; V^T rows are 128 B: chunk ^= (row>>1)&7).
+//   * K / V^T tiles: global -> LDS directly by LDS-DMA (buffer_load ... lds), double-buffered: the next tile's DMA is
+//     issued before this tile's MFMAs and lands under them; one barrier per tile.  LDS rows carry one 16-B pad chunk, which makes
+//     every fragment read conflict-free and base+immediate addressed (see K_ROW_BYTES below); the global side uses
+//     buffer loads (hardware bounds check, scalar tile offset).
 //   * fp32 online softmax in the exp2 domain; the accumulator rescale is skipped (exactly) when no row's
 //     running max moved in this tile; P is rounded to bf16 (RNE) before P·V, like the reference kernels
 //     (block_sparse_attn_triton.py:152, st_attn_triton.py:84).
@@ -34,18 +35,24 @@ struct ModeArgs {
     int win[3 * 64];
 };
 
-constexpr int K_TILE_BYTES = 64 * 128 * 2;   // 16 KiB
-constexpr int STAGE_BYTES = 2 * K_TILE_BYTES;  // K + V^T
+// LDS rows are padded by one 16-B chunk (K: 256+16 B, V^T: 128+16 B): a fragment read (32 rows x one chunk) then
+// touches 16 distinct 16-B slots per 16-lane group (conflict-free, slot = (17*row+c) mod 16 resp. (9*row+c) mod 16)
+// AND every fragment address is lane_base + compile-time immediate — no per-read address arithmetic.
+constexpr int K_ROW_BYTES = 272, V_ROW_BYTES = 144;
+constexpr int K_TILE_BYTES = 64 * K_ROW_BYTES;     // 17 408
+constexpr int V_TILE_BYTES = 128 * V_ROW_BYTES;    // 18 432
+constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;  // 35 840
 
 template <int NW, int MODE>
 __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fvk_attn_args a, ModeArgs ma) {
+#if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the body uses gfx950 LDS-DMA builtins the host pass cannot parse
     constexpr int NT = NW * 64;
     constexpr int BMQ = NW * 32;
-    constexpr int CPT = 1024 / NT;  // 16-B chunks per thread per tile (K and V^T each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (scalar branches, SGPR M0 base)
     const int l31 = lane & 31, hi = lane >> 5;
     const int nqb = (a.Sq + BMQ - 1) / BMQ;
     const int qb = blockIdx.x % nqb;
@@ -120,25 +127,33 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) qf[ks] = ld_bf16x8(qp + (long)qrow * a.q_ss + ks * 16 + hi * 8);
 
-    // ---- staging assignment ------------------------------------------------------------------------------
-    int k_row[CPT], k_goff[CPT], k_soff[CPT], v_soff[CPT];
-    long v_goff[CPT];
+    // ---- staging: LDS-DMA (buffer_load ... lds).  A stage is one linear array of 2240 16-B chunks: K rows of 17 chunks
+    // (16 data + 1 pad) x 64, then V^T rows of 9 chunks (8 + 1 pad) x 128.  One wave-instruction moves 64 consecutive
+    // chunks (1 KiB) to M0-base + lane*16; K is exactly 17 wave-instructions and V^T 18, so each one is uniformly K or V.
+    // The per-lane SOURCE offset is precomputed (pad chunks re-read chunk 0 of their row); the tile offset is the scalar
+    // soffset; rows >= Skv are out of the descriptor's range and read as zeros.  No staging VGPRs, no ds_write.
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)kp, 0, (int)((((long)a.Skv - 1) * a.k_ss + 128) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vtp, 0, (int)(256L * a.Skv_pad), 0x00020000);
+    constexpr int N_DMA = (35 + NW - 1) / NW;  // wave-instructions per wave per tile
+    int dma_voff[N_DMA];
 #pragma unroll
-    for (int i = 0; i < CPT; ++i) {
-        const int c = tid + NT * i;
-        const int kr = c >> 4, kc = c & 15;
-        k_row[i] = kr;
-        k_goff[i] = kc * 8;
-        k_soff[i] = kr * 256 + ((kc ^ (kr & 15)) << 4);
-        const int vr = c >> 3, vc = c & 7;
-        v_goff[i] = (long)vr * a.Skv_pad + vc * 8;
-        v_soff[i] = K_TILE_BYTES + vr * 128 + ((vc ^ ((vr >> 1) & 7)) << 4);
+    for (int i = 0; i < N_DMA; ++i) {
+        const int t = i * NW + wave;  // wave-instruction index within the stage
+        if (t < 17) {
+            const int g = t * 64 + lane;
+            const int kr = g / 17, kc = g % 17;
+            dma_voff[i] = (int)(((long)kr * a.k_ss + (kc < 16 ? kc : 0) * 8) * 2);
+        } else {
+            const int g = (t - 17) * 64 + lane;
+            const int vr = g / 9, vc = g % 9;
+            dma_voff[i] = (vr * a.Skv_pad + (vc < 8 ? vc : 0) * 8) * 2;
+        }
     }
-    // fragment read bases
-    const int kx = l31 & 15;
-    const int k_rbase = l31 * 256;
-    const int vx = (l31 >> 1) & 7;
-    const int v_rbase = K_TILE_BYTES + l31 * 128;
+    const int k_tile_stride = (int)(a.k_ss * 2);  // bytes per key row
+    // fragment read bases (per lane); everything else is an immediate
+    const int k_rbase = l31 * K_ROW_BYTES + hi * 16;
+    const int v_rbase = K_TILE_BYTES + l31 * V_ROW_BYTES + hi * 16;
 
     f32x16 o[4];
 #pragma unroll
@@ -148,26 +163,25 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
     float m_run = -1e30f, l_run = 0.f;
     const float c2 = a.scale * 1.4426950408889634f;
 
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 rk[CPT], rv[CPT];
-#define ISSUE_LOADS(KV0)                                                                         \
-    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                            \
-        int kr_ = (KV0) + k_row[i];                                                              \
-        kr_ = kr_ < a.Skv ? kr_ : a.Skv - 1;                                                     \
-        rk[i] = *reinterpret_cast<const u32x4*>(kp + (long)kr_ * a.k_ss + k_goff[i]);           \
-        rv[i] = *reinterpret_cast<const u32x4*>(vtp + v_goff[i] + (KV0));                        \
-    }
-#define WRITE_STAGE(ST)                                                                          \
-    _Pragma("unroll") for (int i = 0; i < CPT; ++i) {                                            \
-        *reinterpret_cast<u32x4*>((ST) + k_soff[i]) = rk[i];                                     \
-        *reinterpret_cast<u32x4*>((ST) + v_soff[i]) = rv[i];                                     \
+    typedef __attribute__((address_space(3))) void lds_void;
+#define ISSUE_DMA(KV0, ST)                                                                                   \
+    {                                                                                                        \
+        const int ks_ = __builtin_amdgcn_readfirstlane((KV0) * k_tile_stride);                               \
+        const int vs_ = __builtin_amdgcn_readfirstlane((KV0) * 2);                                           \
+        _Pragma("unroll") for (int i = 0; i < N_DMA; ++i) {                                                  \
+            const int t_ = i * NW + wave;                                                                    \
+            if (t_ < 17) {                                                                                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)((ST) + t_ * 1024), 16, dma_voff[i], ks_, 0, 0); \
+            } else if (t_ < 35) {                                                                            \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)((ST) + t_ * 1024), 16, dma_voff[i], vs_, 0, 0); \
+            }                                                                                                \
+        }                                                                                                    \
     }
 
     int kv0 = 0, valid = 64, kv0_n = 0, valid_n = 64;
     if (n_tiles > 0) {
         get_tile(0, kv0, valid);
-        ISSUE_LOADS(kv0)
-        WRITE_STAGE(smem)
+        ISSUE_DMA(kv0, smem)
     }
     __syncthreads();
 
@@ -176,7 +190,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
         const bool more = (j + 1) < n_tiles;
         if (more) {
             get_tile(j + 1, kv0_n, valid_n);
-            ISSUE_LOADS(kv0_n)
+            unsigned char* nxt = smem + ((j + 1) & 1) * STAGE_BYTES;
+            ISSUE_DMA(kv0_n, nxt)
         }
         // ---- S^T = K · Q^T  (2 key blocks of 32 x 8 k-steps of 16) --------------------------------------
         f32x16 s[2];
@@ -184,14 +199,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cur + k_rbase + kb * 32 * 256 + (((2 * ks + hi) ^ kx) << 4));
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cur + k_rbase + (kb * 32 * K_ROW_BYTES + ks * 32));
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         // ---- online softmax (row q = lane&31; this lane holds 32 of its 64 scores) ------------------------
         if (valid < 64) {
 #pragma unroll
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
             }
         l_run += psum;
         // ---- O^T += V^T · P^T  (4 d-blocks of 32 x 4 k-steps of 16 keys) ---------------------------------
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             bf16x8 pf;
@@ -237,13 +255,12 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
             for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)s[kk >> 1][(kk & 1) * 8 + jj];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cur + v_rbase + d * 32 * 128 + (((2 * kk + hi) ^ vx) << 4));
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cur + v_rbase + (d * 32 * V_ROW_BYTES + kk * 32));
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         if (more) {
-            unsigned char* nxt = smem + ((j + 1) & 1) * STAGE_BYTES;
-            WRITE_STAGE(nxt)
             kv0 = kv0_n;
             valid = valid_n;
         }
@@ -266,6 +283,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
             }
         if (a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow] = m_run * c2 + log2f(l_tot);
     }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 int check_common(const fvk_attn_args* a, const char* fn) {

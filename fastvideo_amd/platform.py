@@ -1,0 +1,35 @@
+"""Platform hook: the reference resolves an attention backend through
+``current_platform.get_attn_backend_cls(selected_backend, head_size, dtype) -> "dotted.path.Class"``
+(fastvideo/platforms/interface.py:121-125, selector.py:289-292).  Its ROCm platform only knows TORCH_SDPA / FLASH_ATTN and
+raises for everything else (fastvideo/platforms/rocm.py:63-112).  ``Mi355xPlatformMixin`` is the override a
+maintainer adds: every name below is a class in fastvideo_amd.attention."""
+from __future__ import annotations
+
+_BACKENDS = {
+    "FLASH_ATTN": "fastvideo_amd.attention.HipDenseAttentionBackend",
+    "TORCH_SDPA": "fastvideo_amd.attention.HipDenseAttentionBackend",
+    "VIDEO_SPARSE_ATTN": "fastvideo_amd.attention.HipVideoSparseAttentionBackend",
+    "SLIDING_TILE_ATTN": "fastvideo_amd.attention.HipSlidingTileAttentionBackend",
+}
+
+
+def get_attn_backend_cls(selected_backend, head_size: int, dtype) -> str:
+    """Same contract as ``Platform.get_attn_backend_cls``: returns a qualname, raises ValueError to refuse
+    (silent fallback is a bug in the reference's convention, fastvideo/platforms/cuda.py:149-154,182-186)."""
+    import torch
+    name = getattr(selected_backend, "name", selected_backend) or "FLASH_ATTN"
+    if name not in _BACKENDS:
+        raise ValueError(f"Invalid attention backend for MI355X: {name}")
+    if head_size != 128:
+        raise ValueError(f"MI355X HIP attention kernels support head_size 128 only (got {head_size})")
+    if dtype not in (torch.bfloat16, None):
+        raise ValueError(f"MI355X HIP attention kernels are bf16 only (got {dtype})")
+    return _BACKENDS[name]
+
+
+class Mi355xPlatformMixin:
+    """``class Mi355xPlatform(Mi355xPlatformMixin, RocmPlatform)`` — see INTEGRATION.md."""
+
+    @classmethod
+    def get_attn_backend_cls(cls, selected_backend, head_size: int, dtype) -> str:
+        return get_attn_backend_cls(selected_backend, head_size, dtype)
