@@ -28,6 +28,7 @@ SIGNATURES = {
     "fvk_last_error": [],
     "fvk_abi_version": [],
     "fvk_device_arch": [C.c_char_p, i32],
+    "fvk_set_tunable": [C.c_char_p, i32],
     "fvk_ln_modulate_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "fvk_scale_residual_bf16": [vp, vp, vp, vp, i32, i32, i32, vp],
     "fvk_rmsnorm_rope_bf16": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, i32, i32, i32, i32, i32, i64, i64, f32, vp],

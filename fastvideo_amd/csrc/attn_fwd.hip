@@ -18,7 +18,9 @@
 //   * fp32 online softmax in the exp2 domain; the accumulator rescale is skipped (exactly) when no row's
 //     running max moved in this tile; P is rounded to bf16 (RNE) before P·V, like the reference kernels
 //     (block_sparse_attn_triton.py:152, st_attn_triton.py:84).
-#include "fvk_common.h"
+#include "gemm_common.h"
+
+int fvk_attn_pp_launch(const fvk_attn_args* a, int variant, hipStream_t s);  // attn_pp.hip
 
 namespace {
 
@@ -321,6 +323,10 @@ int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
 extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
     int rc = check_common(a, "fvk_attn_dense_bf16");
     if (rc) return rc;
+    // full-length query blocks go to the 8-wave ping-pong kernel (attn_pp.hip); "attn_impl" = 1 forces this 4-wave kernel,
+    // 2 / 3 select the alternative DMA placements of the ping-pong kernel (measurement only)
+    const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
+    if (impl != 1 && a->Sq >= 256) return fvk_attn_pp_launch(a, impl >= 2 ? impl - 1 : 0, (hipStream_t)stream);
     ModeArgs ma{};
     return launch<4, MODE_DENSE>(a, ma, (hipStream_t)stream);
 }

@@ -3,7 +3,7 @@
 #include <stdio.h>
 #include <string.h>
 
-#include "fvk_common.h"
+#include "gemm_common.h"
 
 static thread_local char g_err[512] = "";
 
@@ -28,4 +28,20 @@ extern "C" int fvk_device_arch(char* buf, int len) {
     strncpy(buf, prop.gcnArchName, len - 1);
     buf[len - 1] = 0;
     return FVK_OK;
+}
+
+// ---- tunables (A/B switches for measurements; defaults = shipped configuration) ---------------------------------------
+static int g_tunables[fvk::TUNE_COUNT] = {0};
+static const char* const g_tunable_names[fvk::TUNE_COUNT] = {"gemm_impl", "attn_impl", nullptr};
+
+int fvk::tunable(int id) { return (id >= 0 && id < fvk::TUNE_COUNT) ? g_tunables[id] : 0; }
+
+extern "C" int fvk_set_tunable(const char* name, int value) {
+    for (int i = 0; i < fvk::TUNE_COUNT; ++i)
+        if (name && g_tunable_names[i] && strcmp(name, g_tunable_names[i]) == 0) {
+            g_tunables[i] = value;
+            return FVK_OK;
+        }
+    fvk_set_error("fvk_set_tunable: unknown tunable '%s'", name ? name : "(null)");
+    return FVK_ERR_ARG;
 }

@@ -14,27 +14,15 @@
 //
 // Epilogue variants follow the reference's rounding points: y = bf16(acc + bias) first, then the activation /
 // gated residual on float(y), then one more rounding.
-#include "fvk_common.h"
+#include "gemm_common.h"
 
 namespace {
+
+using fvk::GemmArgs;
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int STAGE_BYTES = (BM + BN) * BK * 2;  // 32 KiB
 
-struct GemmArgs {
-    const bf16_t* x;
-    const bf16_t* w;
-    const bf16_t* bias;
-    bf16_t* out;
-    const bf16_t* residual;
-    const float* gate;
-    int M, N, K;
-    long lda, ldc;
-    int rows_per_batch;
-    int ntm, ntn;
-    float epi_scalar;
-    long x_bstride, w_bstride, out_bstride;
-};
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -194,7 +182,7 @@ static int gemm_impl(const void* x, const void* w, const void* bias, void* out, 
                      int epilogue, const void* residual, const float* gate, int rows_per_batch, float epi_scalar, int batch,
                      long x_bstride, long w_bstride, long out_bstride, void* stream) {
     FVK_CHECK(x && w && out, FVK_ERR_ARG, "fvk_gemm_bf16: null pointer");
-    FVK_CHECK(K > 0 && K % BK == 0, FVK_ERR_ARG, "fvk_gemm_bf16: K=%d must be a positive multiple of %d", K, BK);
+    FVK_CHECK(K > 0 && K % 32 == 0, FVK_ERR_ARG, "fvk_gemm_bf16: K=%d must be a positive multiple of 32", K);
     FVK_CHECK(N > 0 && lda >= K && ldc >= N && lda % 8 == 0, FVK_ERR_ARG, "fvk_gemm_bf16: bad N=%d lda=%ld ldc=%ld", N, lda, ldc);
     FVK_CHECK(epilogue >= 0 && epilogue <= 4, FVK_ERR_ARG, "fvk_gemm_bf16: unknown epilogue %d", epilogue);
     FVK_CHECK(epilogue != FVK_EPI_RESIDUAL_GATE || (residual && rows_per_batch > 0), FVK_ERR_ARG,
@@ -206,6 +194,9 @@ static int gemm_impl(const void* x, const void* w, const void* bias, void* out, 
                M, N, K, lda, ldc, rows_per_batch > 0 ? rows_per_batch : M, (M + BM - 1) / BM, (N + BN - 1) / BN,
                epi_scalar, x_bstride, w_bstride, out_bstride};
     hipStream_t s = (hipStream_t)stream;
+    // token-axis GEMMs go to the 256x256 LDS-DMA ping-pong kernel (gemm_pp.hip); this 128x128 kernel keeps the small / odd shapes
+    if (fvk::tunable(fvk::TUNE_GEMM_IMPL) != 1 && fvk::gemm_pp_eligible(a)) return fvk::gemm_pp_launch(a, epilogue, batch, s);
+    FVK_CHECK(K % BK == 0, FVK_ERR_ARG, "fvk_gemm_bf16: K=%d must be a multiple of %d for this shape (M=%d N=%d)", K, BK, M, N);
     switch (epilogue) {
         case FVK_EPI_NONE: return launch<FVK_EPI_NONE>(a, batch, s);
         case FVK_EPI_GELU_TANH: return launch<FVK_EPI_GELU_TANH>(a, batch, s);

@@ -1,0 +1,31 @@
+// Argument block shared by the two bf16 GEMM kernels (gemm_bf16.hip: 128x128 register-staged tile for small / odd
+// shapes; gemm_pp.hip: 256x256 LDS-DMA ping-pong tile for the token-axis GEMMs) and the tunables registry.
+#pragma once
+#include "fvk_common.h"
+
+namespace fvk {
+
+struct GemmArgs {
+    const bf16_t* x;
+    const bf16_t* w;
+    const bf16_t* bias;
+    bf16_t* out;
+    const bf16_t* residual;
+    const float* gate;
+    int M, N, K;
+    long lda, ldc;
+    int rows_per_batch;
+    int ntm, ntn;
+    float epi_scalar;
+    long x_bstride, w_bstride, out_bstride;
+};
+
+// gemm_pp.hip
+bool gemm_pp_eligible(const GemmArgs& a);
+int gemm_pp_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
+
+// capi.hip: integer knobs for within-process A/B measurements (fvk_set_tunable); defaults are the shipped configuration.
+enum Tunable { TUNE_GEMM_IMPL = 0, TUNE_ATTN_IMPL = 1, TUNE_COUNT = 8 };
+int tunable(int id);
+
+}  // namespace fvk

@@ -38,6 +38,11 @@ def _f32(t, name):
     return _chk(t, torch.float32, name).contiguous()
 
 
+def set_tunable(name: str, value: int) -> None:
+    """Measurement switches of the library (include/fvk_amd.h fvk_set_tunable); 0 = shipped configuration."""
+    _lib.call("fvk_set_tunable", name.encode(), int(value))
+
+
 # ------------------------------------------------------------------ norm / modulate
 def ln_modulate(x, *, residual=None, gate=None, ln_w=None, ln_b=None, mul=None, add=None, eps=1e-6,
                 round_residual=False, round_norm=False, want_residual=False, rows_per_batch=None):

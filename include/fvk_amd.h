@@ -29,6 +29,10 @@ extern "C" {
 const char* fvk_last_error(void);
 int fvk_abi_version(void);                 /* bumps when a signature changes */
 int fvk_device_arch(char* buf, int len);   /* gcnArchName of the current device ("gfx950...") */
+/* Integer knobs for within-process A/B measurements (scripts/microbench.py); 0 = shipped configuration.
+ *   "gemm_impl": 0 auto (256x256 LDS-DMA ping-pong kernel when eligible), 1 force the 128x128 register-staged kernel
+ *   "attn_impl": 0 auto (8-wave ping-pong dense kernel), 1 force the 4-wave kernel */
+int fvk_set_tunable(const char* name, int value);
 
 /* ------------------------------------------------------------------ norm / modulate family (HBM-bound)
  * ref: fastvideo/layers/layernorm.py:115-125 (FP32LayerNorm), :128-213 (ScaleResidualLayerNormScaleShift),
@@ -80,7 +84,7 @@ int fvk_v_transpose_bf16(const void* v, void* vt, int B, int S, int H, int D, lo
  *   FVK_EPI_SILU      : out = bf16(silu(float(y)))
  *   FVK_EPI_RESIDUAL_GATE : out = bf16(float(residual[m,n]) + float(y) * gate[m / rows_per_batch, n])
  *                           (gate NULL = 1; = ScaleResidual fused into the out-projection)
- * K % 64 == 0.  Any M, N (tails masked).  out row stride ldc. */
+ * K % 64 == 0 (K % 32 == 0 on the large-M path).  Any M, N (tails masked).  out row stride ldc. */
 #define FVK_EPI_NONE 0
 #define FVK_EPI_GELU_TANH 1
 #define FVK_EPI_SILU 2

@@ -334,3 +334,77 @@ def test_errors_are_loud(ops):
         ops.ln_modulate(rnd((4, 100), 1))  # CPU tensor: no fallback
     with pytest.raises(RuntimeError):
         ops.attn_dense(rnd((1, 8, 1, 64), 1).to(DEV), rnd((1, 8, 1, 64), 2).to(DEV), rnd((1, 8, 1, 64), 3).to(DEV))
+
+
+# ------------------------------------------------------------------ large-tile kernels (gemm_pp.hip / attn_pp.hip) and their A/B switches
+@pytest.fixture
+def tunables(ops):
+    yield ops.set_tunable
+    ops.set_tunable("gemm_impl", 0)
+    ops.set_tunable("attn_impl", 0)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 1536, 1536), (777, 520, 96), (513, 264, 32), (2048, 256, 64), (129, 8, 1536)])
+def test_gemm_pp_shapes(ops, M, N, K):
+    """Shapes that take the 256x256 LDS-DMA ping-pong kernel: ragged M/N tiles, 1..48 K-steps (ring prologue / tail re-reads)."""
+    x, w, b = rnd((M, K), 11), rnd((N, K), 12, K**-0.5), rnd((N, ), 13)
+    close(ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV)), _lin_ref(x, w, b), what=f"gemm_pp {M}x{N}x{K}")
+
+
+def test_gemm_pp_identity_asymmetric(ops):
+    K = 512
+    x = torch.eye(K).bfloat16()
+    w = (torch.arange(K * K).view(K, K) % 251).float().bfloat16()
+    assert torch.equal(ops.gemm(x.to(DEV), w.to(DEV), None).cpu(), w.t().contiguous())
+    # every K-step of a longer K lands in the right ring slot: x = [0 | I | 0] picks one K-step of w
+    K2 = 1536
+    x2 = torch.zeros((512, K2)).bfloat16()
+    x2[:, 512:1024] = torch.eye(512).bfloat16()
+    w2 = (torch.arange(300 * K2).view(300, K2) % 241).float().bfloat16()[:296]
+    assert torch.equal(ops.gemm(x2.to(DEV), w2.to(DEV), None).cpu(), w2[:, 512:1024].t().contiguous())
+
+
+def test_gemm_kernels_agree(ops, tunables):
+    """The two GEMM kernels accumulate 16-k MFMA steps in the same order: identical outputs except for the GELU formulation."""
+    M, N, K, B = 600, 768, 256, 2
+    x, w, b = rnd((M, K), 1), rnd((N, K), 2, K**-0.5), rnd((N, ), 3)
+    res, gate = rnd((M, N), 4, 2.0), rnd((B, N), 5, 0.5, torch.float32)
+    outs = {}
+    for impl in (0, 1):
+        tunables("gemm_impl", impl)
+        outs[impl] = [ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
+                               gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None).cpu()
+                      for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_RESIDUAL_GATE, ops.EPI_GELU_TANH)]
+    for i in range(3):
+        assert torch.equal(outs[0][i], outs[1][i]), f"epilogue #{i}: kernels disagree"
+    close(outs[0][3], outs[1][3], atol=1e-2, rtol=1e-2, what="gelu formulations")
+    y = _lin_ref(x, w, b)
+    close(outs[0][3], W.gelu_tanh(y), what="gelu (pp)")
+    ref = W.scale_residual(res.view(B, M // B, N), y.view(B, M // B, N), gate.view(B, 1, N)).bfloat16().view(M, N)
+    close(outs[0][2], ref, what="residual+gate (pp)")
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2, 3])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 700), (2, 3, 512, 130), (1, 1, 256, 64), (1, 2, 1030, 1999)])
+def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
+    """attn_impl 0/2/3 = 8-wave ping-pong kernel (three DMA placements), 1 = 4-wave kernel; ragged Sq / Skv tails, 1..32 KV tiles."""
+    tunables("attn_impl", impl)
+    q, k, v = rnd((B, Sq, H, 128), 1), rnd((B, Skv, H, 128), 2), rnd((B, Skv, H, 128), 3)
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    out = ops.attn_dense(q.to(DEV), k.to(DEV), v.to(DEV), layout="bshd")
+    _attn_check(out, ref, f"dense impl {impl} {B},{H},{Sq},{Skv}")
+
+
+@pytest.mark.parametrize("impl", [0, 2, 3])
+def test_attn_pp_rescale_branch_and_repeatability(ops, tunables, impl):
+    """Spiked keys force the running-max rescale in late tiles of the ping-pong kernel; 3 launches must agree bit-for-bit
+    (a race between the staggered wave groups or an early LDS read would show up as run-to-run differences)."""
+    tunables("attn_impl", impl)
+    B, H, S = 1, 2, 640
+    q, k, v = rnd((B, S, H, 128), 1, 0.5), rnd((B, S, H, 128), 2, 0.5), rnd((B, S, H, 128), 3)
+    k[0, 250, 0] = q[0, 7, 0] * 6
+    k[0, 600, 1] = q[0, 300, 1] * 6
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    outs = [ops.attn_dense(q.to(DEV), k.to(DEV), v.to(DEV), layout="bshd").cpu() for _ in range(3)]
+    _attn_check(outs[0], ref, f"rescale branch impl {impl}")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
