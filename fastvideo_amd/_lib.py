@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfvk_amd.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -20,7 +20,7 @@ class AttnArgs(C.Structure):
     _fields_ = [("q", vp), ("k", vp), ("vt", vp), ("o", vp), ("lse", vp),
                 ("B", i32), ("H", i32), ("Sq", i32), ("Skv", i32), ("Skv_pad", i32),
                 ("q_bs", i64), ("q_ss", i64), ("q_hs", i64), ("k_bs", i64), ("k_ss", i64), ("k_hs", i64),
-                ("o_bs", i64), ("o_ss", i64), ("o_hs", i64), ("scale", f32)]
+                ("o_bs", i64), ("o_ss", i64), ("o_hs", i64), ("scale", f32), ("qk_dim", i32)]
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPES)
@@ -49,6 +49,8 @@ SIGNATURES = {
     "fvk_unpatchify_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "fvk_timestep_embedding_bf16": [vp, vp, i32, i32, f32, vp],
     "fvk_silu_bf16": [vp, vp, i64, vp],
+    "fvk_vae_conv_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i32, i32, vp],
+    "fvk_vae_rmsnorm_silu_bf16": [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
 }
 _RESTYPES = {"fvk_last_error": C.c_char_p}
 

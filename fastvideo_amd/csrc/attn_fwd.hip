@@ -40,14 +40,22 @@ struct ModeArgs {
 // LDS rows are padded by one 16-B chunk (K: 256+16 B, V^T: 128+16 B): a fragment read (32 rows x one chunk) then
 // touches 16 distinct 16-B slots per 16-lane group (conflict-free, slot = (17*row+c) mod 16 resp. (9*row+c) mod 16)
 // AND every fragment address is lane_base + compile-time immediate — no per-read address arithmetic.
-constexpr int K_ROW_BYTES = 272, V_ROW_BYTES = 144;
-constexpr int K_TILE_BYTES = 64 * K_ROW_BYTES;     // 17 408
+// DK = depth of the Q·K^T contraction (128 for the DiT; 384 for the VAE mid-block's single 384-wide head, whose V / O are
+// processed as three 128-column slices = three "heads" that share q and k: q_hs = k_hs = 0, o_hs = 128).
+constexpr int V_ROW_BYTES = 144;
 constexpr int V_TILE_BYTES = 128 * V_ROW_BYTES;    // 18 432
-constexpr int STAGE_BYTES = K_TILE_BYTES + V_TILE_BYTES;  // 35 840
+template <int DK> struct KGeom {
+    static constexpr int ROW_BYTES = DK * 2 + 16;          // 272 | 784
+    static constexpr int CHUNKS = DK / 8 + 1;              // 16-B chunks per padded row = DMA wave-instructions per tile (17 | 49)
+    static constexpr int TILE_BYTES = 64 * ROW_BYTES;      // 17 408 | 50 176
+    static constexpr int STAGE_BYTES = TILE_BYTES + V_TILE_BYTES;
+};
 
-template <int NW, int MODE>
+template <int NW, int MODE, int DK>
 __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fvk_attn_args a, ModeArgs ma) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the body uses gfx950 LDS-DMA builtins the host pass cannot parse
+    constexpr int K_ROW_BYTES = KGeom<DK>::ROW_BYTES, KC = KGeom<DK>::CHUNKS, K_TILE_BYTES = KGeom<DK>::TILE_BYTES;
+    constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES, KS = DK / 16;
     constexpr int NT = NW * 64;
     constexpr int BMQ = NW * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -125,9 +133,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
     int qrow = q0 + l31;
     const bool q_ok = qrow < a.Sq;
     qrow = q_ok ? qrow : a.Sq - 1;
-    bf16x8 qf[8];
+    bf16x8 qf[KS];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) qf[ks] = ld_bf16x8(qp + (long)qrow * a.q_ss + ks * 16 + hi * 8);
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = ld_bf16x8(qp + (long)qrow * a.q_ss + ks * 16 + hi * 8);
 
     // ---- staging: LDS-DMA (buffer_load ... lds).  A stage is one linear array of 2240 16-B chunks: K rows of 17 chunks
     // (16 data + 1 pad) x 64, then V^T rows of 9 chunks (8 + 1 pad) x 128.  One wave-instruction moves 64 consecutive
@@ -135,19 +143,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
     // The per-lane SOURCE offset is precomputed (pad chunks re-read chunk 0 of their row); the tile offset is the scalar
     // soffset; rows >= Skv are out of the descriptor's range and read as zeros.  No staging VGPRs, no ds_write.
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)kp, 0, (int)((((long)a.Skv - 1) * a.k_ss + 128) * 2), 0x00020000);
+        (void*)kp, 0, (int)((((long)a.Skv - 1) * a.k_ss + DK) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vtp, 0, (int)(256L * a.Skv_pad), 0x00020000);
-    constexpr int N_DMA = (35 + NW - 1) / NW;  // wave-instructions per wave per tile
+    constexpr int N_DMA = (KC + 18 + NW - 1) / NW;  // wave-instructions per wave per tile
     int dma_voff[N_DMA];
 #pragma unroll
     for (int i = 0; i < N_DMA; ++i) {
         const int t = i * NW + wave;  // wave-instruction index within the stage
-        if (t < 17) {
+        if (t < KC) {
             const int g = t * 64 + lane;
-            const int kr = g / 17, kc = g % 17;
-            dma_voff[i] = (int)(((long)kr * a.k_ss + (kc < 16 ? kc : 0) * 8) * 2);
+            const int kr = g / KC, kc = g % KC;
+            dma_voff[i] = (int)(((long)kr * a.k_ss + (kc < KC - 1 ? kc : 0) * 8) * 2);
         } else {
-            const int g = (t - 17) * 64 + lane;
+            const int g = (t - KC) * 64 + lane;
             const int vr = g / 9, vc = g % 9;
             dma_voff[i] = (vr * a.Skv_pad + (vc < 8 ? vc : 0) * 8) * 2;
         }
@@ -172,9 +180,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
         const int vs_ = __builtin_amdgcn_readfirstlane((KV0) * 2);                                           \
         _Pragma("unroll") for (int i = 0; i < N_DMA; ++i) {                                                  \
             const int t_ = i * NW + wave;                                                                    \
-            if (t_ < 17) {                                                                                   \
+            if (t_ < KC) {                                                                                   \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)((ST) + t_ * 1024), 16, dma_voff[i], ks_, 0, 0); \
-            } else if (t_ < 35) {                                                                            \
+            } else if (t_ < KC + 18) {                                                                          \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)((ST) + t_ * 1024), 16, dma_voff[i], vs_, 0, 0); \
             }                                                                                                \
         }                                                                                                    \
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cur + k_rbase + (kb * 32 * K_ROW_BYTES + ks * 32));
@@ -300,11 +308,12 @@ int check_common(const fvk_attn_args* a, const char* fn) {
     return FVK_OK;
 }
 
-template <int NW, int MODE>
+template <int NW, int MODE, int DK = 128>
 int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
+    constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE, DK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * STAGE_BYTES) != hipSuccess) {
             fvk_set_error("fvk_attn: cannot set dynamic LDS size");
             return FVK_ERR_LAUNCH;
@@ -313,7 +322,7 @@ int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
     }
     const int bmq = NW * 32;
     const long nblk = (long)((a->Sq + bmq - 1) / bmq) * a->H * a->B;
-    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE>), dim3((unsigned)nblk), dim3(NW * 64), 2 * STAGE_BYTES, s, *a, ma);
+    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE, DK>), dim3((unsigned)nblk), dim3(NW * 64), 2 * STAGE_BYTES, s, *a, ma);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -325,6 +334,12 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
     if (rc) return rc;
     // full-length query blocks go to the 8-wave ping-pong kernel (attn_pp.hip); "attn_impl" = 1 forces this 4-wave kernel,
     // 2 / 3 select the alternative DMA placements of the ping-pong kernel (measurement only)
+    FVK_CHECK(a->qk_dim == 0 || a->qk_dim == 128 || a->qk_dim == 384, FVK_ERR_ARG, "fvk_attn_dense_bf16: qk_dim=%d unsupported (128 or 384)",
+              a->qk_dim);
+    if (a->qk_dim == 384) {
+        ModeArgs ma{};
+        return launch<4, MODE_DENSE, 384>(a, ma, (hipStream_t)stream);
+    }
     const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
     if (impl != 1 && a->Sq >= 256) return fvk_attn_pp_launch(a, impl >= 2 ? impl - 1 : 0, (hipStream_t)stream);
     ModeArgs ma{};

@@ -163,7 +163,7 @@ def gemm_batched(x, w, epilogue=EPI_NONE, scalar=1.0):
 
 
 # ------------------------------------------------------------------ attention
-def _attn_args(q, k, vt, o, scale, layout, lse=None):
+def _attn_args(q, k, vt, o, scale, layout, lse=None, qk_dim=0):
     """layout 'bshd': q [B,S,H,D]; 'bhsd': q [B,H,S,D]."""
     for t, n in ((q, "q"), (k, "k"), (vt, "vt"), (o, "o")):
         _chk(t, BF16, n)
@@ -177,7 +177,7 @@ def _attn_args(q, k, vt, o, scale, layout, lse=None):
         B, H, Sq, D = q.shape
         Skv = k.shape[2]
         st = lambda t: (t.stride(0), t.stride(2), t.stride(1))
-    if D != 128:
+    if D != 128 and not (qk_dim == 384 and D == 384):
         raise RuntimeError(f"attention: head_dim {D} != 128")
     a = AttnArgs()
     a.q, a.k, a.vt, a.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
@@ -187,6 +187,9 @@ def _attn_args(q, k, vt, o, scale, layout, lse=None):
     a.k_bs, a.k_ss, a.k_hs = st(k)
     a.o_bs, a.o_ss, a.o_hs = st(o)
     a.scale = float(scale)
+    a.qk_dim = int(qk_dim)
+    if qk_dim == 384:  # one 384-wide head = three 128-column output slices sharing q and k (include/fvk_amd.h)
+        a.H, a.q_hs, a.k_hs, a.o_hs = 3 * H, 0, 0, 128
     return a
 
 
@@ -231,6 +234,74 @@ def attn_sta(q, k, v, canvas_tiles, tile_tokens, windows, scale=None, layout="bh
     _lib.call("fvk_attn_sta_bf16", C.byref(a), int(canvas_tiles[0]), int(canvas_tiles[1]), int(canvas_tiles[2]), int(tile_tokens),
               arr, _stream())
     return o
+
+
+def attn_dense_wide(q, k, v, scale=None):
+    """Single-head attention with head_dim 384 (the Wan VAE mid block, ref: wanvae.py:479-507).
+    q, k, v: bf16 [S, 384] views with unit column stride (e.g. the three column blocks of a fused [S, 1152] projection)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _chk(t, BF16, n)
+    S, D = q.shape
+    if D != 384:
+        raise RuntimeError(f"attn_dense_wide: head_dim {D} != 384")
+    scale = D**-0.5 if scale is None else scale
+    v4 = v.as_strided((1, S, 3, 128), (0, v.stride(0), 128, 1))
+    vt = v_transpose(v4)
+    o = torch.empty((S, D), dtype=BF16, device=q.device)
+    a = _attn_args(q.as_strided((1, S, 1, D), (0, q.stride(0), 0, 1)), k.as_strided((1, S, 1, D), (0, k.stride(0), 0, 1)), vt,
+                   o.view(1, S, 1, D), scale, "bshd", qk_dim=384)
+    _lib.call("fvk_attn_dense_bf16", C.byref(a), _stream())
+    return o
+
+
+# ------------------------------------------------------------------ Wan VAE decode
+VAE_EPI_BIAS, VAE_EPI_RESIDUAL, VAE_EPI_FINAL = 0, 1, 2
+
+
+def vae_conv(inp, w, bias, *, T, H, W, kt, ks, ring_start=0, out=None, out_frame_stride=None, residual=None,
+             res_frame_stride=None, upsample2x=False, out_f32=None, plane_stride=0):
+    """Implicit-GEMM conv on channels-last frames (fvk_vae_conv_bf16).  inp: bf16 [ring, Hin, Win, Cin] contiguous;
+    w: bf16 [Cout, kt*ks*ks*Cin]; out: bf16 tensor whose data_ptr is the first output pixel (frame stride in elements) or
+    out_f32 for the final planar fp32 epilogue."""
+    _chk(inp, BF16, "inp"), _chk(w, BF16, "w")
+    ring, Hin, Win, Cin = inp.shape
+    Cout = w.shape[0]
+    if w.shape[1] != kt * ks * ks * Cin or not inp.is_contiguous() or not w.is_contiguous():
+        raise RuntimeError(f"vae_conv: weight {tuple(w.shape)} does not match taps {kt}x{ks}x{ks} x Cin {Cin} (or non-contiguous input)")
+    if (Hin, Win) != ((H // 2, W // 2) if upsample2x else (H, W)):
+        raise RuntimeError(f"vae_conv: input spatial size {(Hin, Win)} inconsistent with output {(H, W)}")
+    if out_f32 is not None:
+        epi = VAE_EPI_FINAL
+        _chk(out_f32, torch.float32, "out_f32")
+    else:
+        epi = VAE_EPI_RESIDUAL if residual is not None else VAE_EPI_BIAS
+        if out is None:
+            out = torch.empty((T, H, W, Cout), dtype=BF16, device=inp.device)
+        if out_frame_stride is None:
+            out_frame_stride = H * W * Cout
+        if residual is not None:
+            _chk(residual, BF16, "residual")
+            if res_frame_stride is None:
+                res_frame_stride = H * W * Cout
+    if bias is not None:
+        _chk(bias, BF16, "bias")
+    _lib.call("fvk_vae_conv_bf16", _p(inp), _p(w), _p(bias), _p(out), _p(residual), _p(out_f32), T, H, W, Cin, Cout, kt, ks, ks,
+              ring, int(ring_start), int(out_frame_stride or 0), int(res_frame_stride or 0), int(plane_stride), int(upsample2x), epi,
+              _stream())
+    return out if out_f32 is None else out_f32
+
+
+def vae_rmsnorm_silu(x, gamma, out_ring, *, HW, slot0=0, silu=True):
+    """x bf16 [n_pix, C] (contiguous) -> out_ring [ring, HW, C] at frame slots (slot0 + t) % ring (fvk_vae_rmsnorm_silu_bf16)."""
+    _chk(x, BF16, "x"), _chk(out_ring, BF16, "out_ring")
+    gamma = _f32(gamma, "gamma")
+    C_ = x.shape[-1]
+    n_pix = x.numel() // C_
+    ring = out_ring.numel() // (HW * C_)
+    if not x.is_contiguous() or not out_ring.is_contiguous():
+        raise RuntimeError("vae_rmsnorm_silu: tensors must be contiguous")
+    _lib.call("fvk_vae_rmsnorm_silu_bf16", _p(x), _p(gamma), _p(out_ring), n_pix, C_, HW, ring, int(slot0), int(silu), _stream())
+    return out_ring
 
 
 # ------------------------------------------------------------------ VSA pieces

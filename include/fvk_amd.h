@@ -111,6 +111,9 @@ typedef struct {
     int B, H, Sq, Skv, Skv_pad;
     long q_bs, q_ss, q_hs, k_bs, k_ss, k_hs, o_bs, o_ss, o_hs;
     float scale;
+    int qk_dim; /* depth of the q·k contraction: 0 or 128 (the DiT), 384 = dense only: the VAE mid-block's single 384-wide head,
+                   run as H = 3 output slices of 128 columns that share q and k (q_hs = k_hs = 0, o_hs = 128;
+                   ref: WanAttentionBlock.forward, fastvideo/models/vaes/wanvae.py:479-507) */
 } fvk_attn_args;
 
 /* dense: ref fastvideo/attention/backends/sdpa.py:122-147 / flash_attn.py:247-345 (the path replaced). */
@@ -155,6 +158,30 @@ int fvk_softmax_rows_bf16(const void* in, void* out, int rows, int n, void* stre
  * ref: fastvideo_kernel/ops.py:120-133.  out_s/gate/out share strides (bs, ss, hs); out_c is [B,H,Nblk,D] contiguous. */
 int fvk_vsa_combine_bf16(const void* out_c, const void* out_s, const void* gate, void* out, int B, int S, int H, int D,
                          int block, long bs, long ss, long hs, void* stream);
+
+/* ------------------------------------------------------------------ Wan VAE decode (causal 3-D conv; MFMA-bound convs, HBM-bound norm)
+ * Activations are channels-last bf16 [frames, H, W, C].  ref: fastvideo/models/vaes/wanvae.py:160-207 (WanCausalConv3d),
+ * :251-380 (WanResample), :383-462 (WanResidualBlock), :857-993 (WanDecoder3d), :1189-1215 (decode).
+ * Implicit-GEMM convolution:  out[t,h,w,co] = bias[co] + sum_{dt,dh,dw,ci} w[co][((dt*KH+dh)*KW+dw)*Cin+ci] *
+ *                                              in[slot(t+dt)][h+dh-KH/2][w+dw-KW/2][ci]      (zero outside the image)
+ *   in      : ring of `ring` frames [ring, Hin, Win, Cin]; logical frame l lives in slot (ring_start + l) % ring.  For KT = 3
+ *             logical frames 0,1 are the causal history (the reference's feat_cache / zero padding) and frame 2+t is the
+ *             chunk's t-th frame; for KT = 1 logical frame t is the t-th frame.
+ *   upsample2x: the input is at half resolution (Hin = H/2, Win = W/2) and nearest-exact 2x upsampling is folded into the
+ *             gather (KT must be 1)  — WanUpsample + Conv2d of WanResample.
+ *   output pixel (t,h,w) -> out + t*out_frame_stride + (h*W+w)*Cout (strides in elements; lets the two halves of an
+ *             upsample3d time_conv interleave their frames, wanvae.py:354-356), same for residual with res_frame_stride.
+ *   epilogue: 0 bias, 1 bias + residual (WanResidualBlock `x + h`), 2 final: out_f32[co*plane_stride + t*H*W + h*W + w] =
+ *             clamp(acc + bias, -1, 1) in fp32 (the decoder's `.float().clamp(-1,1)` and NCTHW layout).
+ * Cin % 32 == 0 (pad z_dim 16 -> 32 with zero weights); KT in {1,3}; KH = KW in {1,3}; Cout % 8 == 0 unless epilogue 2. */
+int fvk_vae_conv_bf16(const void* in, const void* w, const void* bias, void* out, const void* residual, float* out_f32, int T,
+                      int H, int W, int Cin, int Cout, int KT, int KH, int KW, int ring, int ring_start, long out_frame_stride,
+                      long res_frame_stride, long plane_stride, int upsample2x, int epilogue, void* stream);
+/* WanRMS_norm (+ SiLU): out = [silu]( x / max(||x||_2, 1e-12) * sqrt(C) * gamma ) per pixel (ref: wanvae.py:231-232, :418-419).
+ * x [n_pix, C] bf16, gamma fp32 [C]; pixel p = (t = p / HW, hw) is written to frame slot (slot0 + t) % ring of `out`
+ * ([ring, HW, C]) — i.e. straight into the consumer conv's input ring.  C % 8 == 0, C <= 512. */
+int fvk_vae_rmsnorm_silu_bf16(const void* x, const float* gamma, void* out, long n_pix, int C, int HW, int ring, int slot0,
+                              int silu, void* stream);
 
 /* ------------------------------------------------------------------ patch / time embedding glue
  * ref: fastvideo/layers/visual_embedding.py:46-55 (PatchEmbed k=s=(1,2,2)), :136-157 (timestep_embedding),
