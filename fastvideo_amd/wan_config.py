@@ -85,3 +85,78 @@ def random_state_dict(cfg: WanConfig, seed: int = 0, device="cpu", dtype=torch.b
         sd[p + "ffn.fc_in.weight"], sd[p + "ffn.fc_in.bias"] = mat(f, d), vec(f)
         sd[p + "ffn.fc_out.weight"], sd[p + "ffn.fc_out.bias"] = mat(d, f), vec(d)
     return sd
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Wan VAE decoder (fastvideo/models/vaes/wanvae.py:857-953, fastvideo/configs/models/vaes/wanvae.py:10-17)
+def wan_vae_param_spec(base_dim: int = 96, z_dim: int = 16, dim_mult=(1, 2, 4, 4), num_res_blocks: int = 2,
+                       temperal_upsample=(True, True, False), out_channels: int = 3):
+    """Ordered [(reference parameter name, shape)] of the decoder + post_quant_conv (for synthetic weights)."""
+    dims = [base_dim * u for u in [dim_mult[-1]] + list(dim_mult[::-1])]
+    spec = [("post_quant_conv.weight", (z_dim, z_dim, 1, 1, 1)), ("post_quant_conv.bias", (z_dim,)),
+            ("decoder.conv_in.weight", (dims[0], z_dim, 3, 3, 3)), ("decoder.conv_in.bias", (dims[0],))]
+
+    def res(p, cin, cout):
+        s = [(p + "norm1.gamma", (cin, 1, 1, 1)), (p + "conv1.weight", (cout, cin, 3, 3, 3)), (p + "conv1.bias", (cout,)),
+             (p + "norm2.gamma", (cout, 1, 1, 1)), (p + "conv2.weight", (cout, cout, 3, 3, 3)), (p + "conv2.bias", (cout,))]
+        if cin != cout:
+            s += [(p + "conv_shortcut.weight", (cout, cin, 1, 1, 1)), (p + "conv_shortcut.bias", (cout,))]
+        return s
+
+    d0 = dims[0]
+    spec += res("decoder.mid_block.resnets.0.", d0, d0)
+    a = "decoder.mid_block.attentions.0."
+    spec += [(a + "norm.gamma", (d0, 1, 1)), (a + "to_qkv.weight", (3 * d0, d0, 1, 1)), (a + "to_qkv.bias", (3 * d0,)),
+             (a + "proj.weight", (d0, d0, 1, 1)), (a + "proj.bias", (d0,))]
+    spec += res("decoder.mid_block.resnets.1.", d0, d0)
+    for i, (cin, cout) in enumerate(zip(dims[:-1], dims[1:])):
+        if i > 0:
+            cin //= 2
+        for j in range(num_res_blocks + 1):
+            spec += res(f"decoder.up_blocks.{i}.resnets.{j}.", cin if j == 0 else cout, cout)
+        if i != len(dim_mult) - 1:
+            u = f"decoder.up_blocks.{i}.upsamplers.0."
+            spec += [(u + "resample.1.weight", (cout // 2, cout, 3, 3)), (u + "resample.1.bias", (cout // 2,))]
+            if temperal_upsample[i]:
+                spec += [(u + "time_conv.weight", (2 * cout, cout, 3, 1, 1)), (u + "time_conv.bias", (2 * cout,))]
+    spec += [("decoder.norm_out.gamma", (dims[-1], 1, 1, 1)), ("decoder.conv_out.weight", (out_channels, dims[-1], 3, 3, 3)),
+             ("decoder.conv_out.bias", (out_channels,))]
+    return spec
+
+
+def vae_decode_flops(T: int, H: int, W: int, base_dim: int = 96, z_dim: int = 16, dim_mult=(1, 2, 4, 4), num_res_blocks: int = 2,
+                     temperal_upsample=(True, True, False)) -> float:
+    """2*MAC FLOPs of the chunked decode of a [T,H,W] latent (convs + mid attention), chunk 0 has no temporal upsampling."""
+    spec = dict(wan_vae_param_spec(base_dim, z_dim, dim_mult, num_res_blocks, temperal_upsample))
+    total = 0.0
+    for c in range(T):
+        t, h, w = 1, H, W
+
+        def conv(name, frames, hh, ww):
+            s = spec[name + ".weight"]
+            k = 1
+            for d in s[1:]:
+                k *= d
+            return 2.0 * frames * hh * ww * s[0] * k
+
+        total += conv("decoder.conv_in", 1, h, w)
+        d0 = spec["decoder.conv_in.weight"][0]
+        for p in ("decoder.mid_block.resnets.0.", "decoder.mid_block.resnets.1."):
+            total += conv(p + "conv1", 1, h, w) + conv(p + "conv2", 1, h, w)
+        total += conv("decoder.mid_block.attentions.0.to_qkv", 1, h, w) + conv("decoder.mid_block.attentions.0.proj", 1, h, w)
+        total += 4.0 * (h * w)**2 * d0
+        for i in range(len(dim_mult)):
+            for j in range(num_res_blocks + 1):
+                p = f"decoder.up_blocks.{i}.resnets.{j}."
+                total += conv(p + "conv1", t, h, w) + conv(p + "conv2", t, h, w)
+                if (p + "conv_shortcut.weight") in spec:
+                    total += conv(p + "conv_shortcut", t, h, w)
+            if i != len(dim_mult) - 1:
+                u = f"decoder.up_blocks.{i}.upsamplers.0."
+                if temperal_upsample[i] and c > 0:
+                    total += conv(u + "time_conv", t, h, w)
+                    t *= 2
+                h, w = 2 * h, 2 * w
+                total += conv(u + "resample.1", t, h, w)
+        total += conv("decoder.conv_out", t, h, w)
+    return total
