@@ -21,6 +21,7 @@
 #include "gemm_common.h"
 
 int fvk_attn_pp_launch(const fvk_attn_args* a, int variant, hipStream_t s);  // attn_pp.hip
+int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s);   // attn_pp2.hip
 
 namespace {
 
@@ -341,7 +342,10 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
         return launch<4, MODE_DENSE, 384>(a, ma, (hipStream_t)stream);
     }
     const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
-    if (impl != 1 && a->Sq >= 256) return fvk_attn_pp_launch(a, impl >= 2 ? impl - 1 : 0, (hipStream_t)stream);
+    // full-length query blocks: 0 = the 128-key-tile ping-pong kernel (attn_pp2.hip, shipped); 1 = this file's 4-wave kernel;
+    // >= 2 = the 64-key-tile ping-pong kernel (attn_pp.hip) variant impl-1 (measurement only)
+    if ((impl == 0 || impl >= 100) && a->Sq >= 256) return fvk_attn_pp2_launch(a, impl >= 100 ? impl - 99 : 0, (hipStream_t)stream);
+    if (impl >= 2 && impl < 100 && a->Sq >= 256) return fvk_attn_pp_launch(a, impl - 1, (hipStream_t)stream);
     ModeArgs ma{};
     return launch<4, MODE_DENSE>(a, ma, (hipStream_t)stream);
 }

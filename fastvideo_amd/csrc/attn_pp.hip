@@ -35,7 +35,7 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 
 // SPLIT: where a wave issues its 4 DMA pieces of the next tile set: 0 = K pieces at the top of M, V pieces at the top of V;
 //        1 = all at the top of V; 2 = all at the top of M.
-template <int SPLIT>
+template <int SPLIT, bool PIPE, int PRIO, int ABL>
 __global__ __launch_bounds__(512, 2) void attn_pp_kernel(fvk_attn_args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -93,6 +93,18 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(fvk_attn_args a) {
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(d_ + i * 8192), 16, kvoff[i] + o_, 0, 0, 0); \
     }
+#define ISSUE_K1(T, I)                                                                                               \
+    {                                                                                                                \
+        const int t_ = (T) < n ? (T) : 0;                                                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + ((T) % RING) * K_TILE + kdst + (I) * 8192), 16, \
+                                                 kvoff[I] + (unsigned)t_ * k_tile_bytes, 0, 0, 0);                   \
+    }
+#define ISSUE_V1(T, I)                                                                                               \
+    {                                                                                                                \
+        const int t_ = (T) < n ? (T) : 0;                                                                            \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + ((T) % RING) * V_TILE + vdst + (I) * 8192), 16, \
+                                                 vvoff[I], __builtin_amdgcn_readfirstlane(t_ * 128), 0, 0);          \
+    }
 #define ISSUE_V(T)                                                                                                   \
     {                                                                                                                \
         const int t_ = (T) < n ? (T) : 0;                                                                            \
@@ -138,6 +150,37 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(fvk_attn_args a) {
             o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kk], o[d], 0, 0, 0);                               \
         }                                                                                                            \
     }
+    // The whole matrix segment of the steady state as ONE software-pipelined fragment stream: 16 V^T fragments (P·V of tile J-1) then
+    // 16 K fragments (Q·K^T of tile J), each ds_read_b128 issued FD MFMAs ahead of its use.  Left to itself hipcc emits
+    // read-pair / wait / MFMA-pair, i.e. every second MFMA eats a full LDS round trip (matrix pipe 52 % busy); sched_group_barrier
+    // pins the 1 MFMA : 1 read interleave so that its lgkmcnt waits become counted (FD-1 reads stay in flight).
+#define MSEG(J)                                                                                                      \
+    {                                                                                                                \
+        const unsigned char* vb_ = smem + (((J) - 1) % RING) * V_TILE;                                               \
+        const unsigned char* kb_ = smem + ((J) % RING) * K_TILE;                                                     \
+        constexpr int FD = 6;                                                                                        \
+        bf16x8 fr_[FD];                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < FD; ++i)                                                               \
+            fr_[i] = *reinterpret_cast<const bf16x8*>(vb_ + voff[i >> 2] + (i & 3) * 4096);                          \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) s[kb][r] = 0.f; \
+        __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);                                                          \
+        _Pragma("unroll") for (int i = 0; i < 32; ++i) {                                                             \
+            if (ABL == 3) { if ((i & 7) == 0) { if (i < 16) o[i & 3][0] += (float)fr_[i % FD][0]; else s[i & 1][0] += (float)fr_[i % FD][0]; } } \
+            else if (i < 16) o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[i % FD], pf[i >> 2], o[i & 3], 0, 0, 0); \
+            else s[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[i % FD], qf[(i - 16) >> 1], s[i & 1], 0, 0, 0); \
+            const int n_ = (ABL >= 4) ? 64 : i + FD; /* ABL 4 (timing only): no fragment reads inside the stream */ \
+            if (n_ < 16) fr_[n_ % FD] = *reinterpret_cast<const bf16x8*>(vb_ + voff[n_ >> 2] + (n_ & 3) * 4096);     \
+            else if (n_ < 32) fr_[n_ % FD] = *reinterpret_cast<const bf16x8*>(kb_ + koff[(n_ - 16) >> 1] + ((n_ - 16) & 1) * 8192); \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+            if (n_ < 32) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                          \
+            if (SPLIT == 3 && ABL != 6) { /* the next tiles' DMA pieces ride in the MFMA gaps (issue slack of the matrix segment) */ \
+                if (i == 9) { ISSUE_K1((J) + 2, 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }              \
+                if (i == 13) { ISSUE_K1((J) + 2, 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }             \
+                if (i == 17) { ISSUE_V1((J) + 1, 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }             \
+                if (i == 21) { ISSUE_V1((J) + 1, 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }             \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
     // online softmax of tile J (row q = lane&31; this lane holds 32 of its 64 scores, lane^32 the other 32)
 #define SOFTMAX(J)                                                                                                   \
     {                                                                                                                \
@@ -148,9 +191,15 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(fvk_attn_args a) {
                 if (key >= valid_) s[kb][r] = -INFINITY;                                                             \
             }                                                                                                        \
         }                                                                                                            \
-        float mx = s[0][0];                                                                                          \
-        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]); \
-        mx = xhalf_max(mx);                                                                      \
+        /* 4 independent max / sum chains: only ONE wave per SIMD is in its softmax segment, so VALU latency is hidden by ILP alone */ \
+        float mx4[4];                                                                                                \
+        _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                              \
+            mx4[c] = fmaxf(s[c >> 1][(c & 1) * 8], s[c >> 1][(c & 1) * 8 + 1]);                                      \
+            _Pragma("unroll") for (int r = 2; r < 8; r += 2)                                                         \
+                mx4[c] = fmaxf(fmaxf(mx4[c], s[c >> 1][(c & 1) * 8 + r]), s[c >> 1][(c & 1) * 8 + r + 1]);           \
+        }                                                                                                            \
+        float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));                                              \
+        mx = xhalf_max(mx);                                                                                          \
         const float m_new = fmaxf(m_run, mx);                                                                        \
         if (!__all(m_new == m_run)) {                                                                                \
             const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);                                        \
@@ -159,13 +208,16 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(fvk_attn_args a) {
             m_run = m_new;                                                                                           \
         }                                                                                                            \
         const float mc = m_run * c2;                                                                                 \
-        float psum = 0.f;                                                                                            \
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};                                                                         \
         _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) {           \
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -mc));                              \
+            float p;                                                                                                 \
+            if (ABL == 1) p = __builtin_fmaf(s[kb][r], c2, -mc); /* timing ablation: no exp */                       \
+            else if (ABL == 2 || ABL >= 5) p = s[kb][r];                     /* timing ablation: no fma, no exp */               \
+            else p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -mc));                                      \
             s[kb][r] = p;                                                                                            \
-            psum += p;                                                                                               \
+            if (ABL != 2 && ABL < 5) ps4[r & 3] += p;                                                                           \
         }                                                                                                            \
-        l_run += psum;                                                                                               \
+        l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);                                                              \
         _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) _Pragma("unroll") for (int jj = 0; jj < 8; ++jj)           \
             pf[kk][jj] = (bf16_t)s[kk >> 1][(kk & 1) * 8 + jj];                                                      \
         /* keep the packing inside this (VALU) segment: without a use here it is sunk below the barrier into M */   \
@@ -194,31 +246,54 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(fvk_attn_args a) {
 
     // ---- j = 0 ---------------------------------------------------------------------------------------------------------------
     if (SPLIT != 1) ISSUE_K(2)
-    if (SPLIT == 2) ISSUE_V(1)
+    if (SPLIT >= 2) ISSUE_V(1)
     __builtin_amdgcn_s_setprio(1);
     QK(0)
     __builtin_amdgcn_s_setprio(0);
     WAIT_SET()
     BAR()
     if (SPLIT == 1) ISSUE_K(2)
-    if (SPLIT != 2) ISSUE_V(1)
+    if (SPLIT < 2) ISSUE_V(1)
     SOFTMAX(0)
     BAR()
     // ---- steady state ----------------------------------------------------------------------------------------------------------
-    for (int j = 1; j < n; ++j) {
-        if (SPLIT != 1) ISSUE_K(j + 2)
-        if (SPLIT == 2) ISSUE_V(j + 1)
-        __builtin_amdgcn_s_setprio(1);
-        PV(j - 1)
-        QK(j)
-        __builtin_amdgcn_s_setprio(0);
-        WAIT_SET()
-        BAR()
-        if (SPLIT == 1) ISSUE_K(j + 2)
-        if (SPLIT != 2) ISSUE_V(j + 1)
-        SOFTMAX(j)
-        BAR()
+    // ABL 7 (timing probe): every wave of workgroup 0 accumulates the s_memtime deltas between its segment boundaries over tiles
+    // 100..355 in registers (no stores inside the loop) and writes the 7 sums to a.lse (as uint64) after the loop.
+    unsigned long long acc_[7] = {0, 0, 0, 0, 0, 0, 0}, last_ = 0;
+#define STAMP(K)                                                                                                     \
+    if (ABL == 7 && blockIdx.x == 0 && j >= 100 && j < 356) {                                                        \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                                \
+        if ((K) != 0 || j > 100) acc_[K] += now_ - last_;                                                            \
+        last_ = now_;                                                                                                \
     }
+    for (int j = 1; j < n; ++j) {
+        STAMP(0)
+        if ((SPLIT == 0 || SPLIT == 2) && ABL != 6) ISSUE_K(j + 2)
+        if (SPLIT == 2 && ABL != 6) ISSUE_V(j + 1)
+        if (PRIO == 0) __builtin_amdgcn_s_setprio(1);
+        if (PIPE) MSEG(j)
+        else {
+            PV(j - 1)
+            QK(j)
+        }
+        if (PRIO == 0) __builtin_amdgcn_s_setprio(0);
+        STAMP(1)
+        WAIT_SET()
+        STAMP(2)
+        BAR()
+        STAMP(3)
+        if (SPLIT == 1 && ABL != 6) ISSUE_K(j + 2)
+        if (SPLIT < 2 && ABL != 6) ISSUE_V(j + 1)
+        STAMP(4)
+        if (PRIO == 2) __builtin_amdgcn_s_setprio(1);
+        SOFTMAX(j)
+        if (PRIO == 2) __builtin_amdgcn_s_setprio(0);
+        STAMP(5)
+        BAR()
+        STAMP(6)
+    }
+    if (ABL == 7 && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 7; ++i) reinterpret_cast<unsigned long long*>(a.lse)[wave * 8 + i] = acc_[i];
     // ---- j = n: last P·V --------------------------------------------------------------------------------------------------------
     __builtin_amdgcn_s_setprio(1);
     PV(n - 1)
@@ -227,7 +302,11 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(fvk_attn_args a) {
     if (grp == 0) BAR()                               // matches the extra leading barrier of waves 4-7
 #undef ISSUE_K
 #undef ISSUE_V
+#undef ISSUE_K1
+#undef ISSUE_V1
 #undef QK
+#undef MSEG
+#undef STAMP
 #undef PV
 #undef SOFTMAX
 #undef WAIT_SET
@@ -247,16 +326,16 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(fvk_attn_args a) {
                 for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(o[d][g * 4 + e] * inv);
                 *reinterpret_cast<bf16x4*>(orow + d * 32 + g * 8 + hi * 4) = v4;
             }
-        if (a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow] = m_run * c2 + log2f(l_tot);
+        if (ABL != 7 && a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow] = m_run * c2 + log2f(l_tot);
     }
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int SPLIT>
+template <int SPLIT, bool PIPE, int PRIO = 0, int ABL = 0>
 int launch(const fvk_attn_args* a, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)attn_pp_kernel<SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        if (hipFuncSetAttribute((const void*)attn_pp_kernel<SPLIT, PIPE, PRIO, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) {
             fvk_set_error("fvk_attn_dense_bf16 (pp): cannot set dynamic LDS size");
             return FVK_ERR_LAUNCH;
@@ -264,18 +343,30 @@ int launch(const fvk_attn_args* a, hipStream_t s) {
         configured = true;
     }
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
-    hipLaunchKernelGGL((attn_pp_kernel<SPLIT>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a);
+    hipLaunchKernelGGL((attn_pp_kernel<SPLIT, PIPE, PRIO, ABL>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
 
 }  // namespace
 
-// variant: 0/1/2 = DMA issue placement (see SPLIT)
+// variant: 0/1/2 = DMA issue placement (see SPLIT) with the software-pipelined matrix segment; 3 = SPLIT 0 with the
+// compiler-scheduled matrix segment (the previous shipped form, kept for A/B)
 int fvk_attn_pp_launch(const fvk_attn_args* a, int variant, hipStream_t s) {
     switch (variant) {
-        case 1: return launch<1>(a, s);
-        case 2: return launch<2>(a, s);
-        default: return launch<0>(a, s);
+        case 1: return launch<1, true>(a, s);
+        case 2: return launch<2, true>(a, s);
+        case 3: return launch<0, false>(a, s);
+        case 4: return launch<1, true, 1>(a, s);  // no priority hints
+        case 5: return launch<1, true, 2>(a, s);  // priority on the softmax segment
+        case 6: return launch<1, true, 0, 1>(a, s);  // timing ablations (wrong results): no exp
+        case 7: return launch<1, true, 0, 2>(a, s);  //   no fma / exp / sum
+        case 8: return launch<1, true, 0, 3>(a, s);  //   no MFMA
+        case 9: return launch<1, true, 0, 4>(a, s);  //   MFMAs without their LDS fragment reads
+        case 10: return launch<1, true, 0, 5>(a, s);  //   MFMAs only: no fragment reads, no softmax arithmetic
+        case 11: return launch<1, true, 0, 6>(a, s);  //   ... and no DMA
+        case 12: return launch<3, true>(a, s);        // DMA pieces inside the MFMA stream
+        case 13: return launch<1, true, 0, 7>(a, s);  // timing probe (a.lse = stamp buffer)
+        default: return launch<0, true>(a, s);
     }
 }

@@ -1,0 +1,300 @@
+// Dense flash-style attention forward, head_dim 128, gfx950 — 8-wave ping-pong kernel with 128-key tiles (the shipped kernel for the
+// DiT's full-length self-attention).  Same mathematics, operand orientation and V^T input layout as attn_fwd.hip / attn_pp.hip
+// (S^T = K·Q^T so a softmax row is lane-local; O^T = V^T·P^T with P^T taken straight from the packed S^T accumulators; fp32 online
+// softmax in the exp2 domain, rescale skipped exactly when no row maximum moved; P rounded to bf16 before P·V).
+//
+// Why 128 keys per step: s_memtime probes of attn_pp.hip (64-key tiles) showed the softmax segment is NOT the bottleneck (it idles
+// ~900 of every 3650 cycles at a barrier); each matrix segment pays ~480 cycles of hand-off (barrier skew + release latency + LDS
+// latency of its first fragments) on top of 32 MFMAs.  Doubling the tile doubles the work per hand-off: 64 MFMAs per matrix segment
+// (P·V of tile j-1: 32, Q·K^T of tile j: 32, four independent accumulator chains each), 2 barriers per 128 keys.
+//   * One 512-thread workgroup per CU owns 256 query rows (8 waves x 32 rows); waves w and w+4 share a SIMD and run one barrier
+//     apart, so each SIMD always has one wave in its matrix segment and one in its softmax segment.
+//   * K and V^T tiles (32 KiB each) go global -> LDS by LDS-DMA into a 2-deep ring (128 KiB), XOR-swizzled on the source side so that
+//     every ds_read_b128 fragment read is conflict-free.  A wave issues its 8 pieces of the next set {K(j+1), V(j)} as soon as the
+//     ring slots are free — the leading group inside the first half of its MFMA stream (one piece per 4 MFMAs; pieces issued late would still be in flight at the segment's barrier, which measurably waits for them), the trailing group at the top of its
+//     softmax segment — and retires them with one s_waitcnt vmcnt(0) two segments later; raw s_barrier only.
+//   * The matrix segment is one software-pipelined fragment stream: each ds_read_b128 is issued 6 MFMAs ahead of its use
+//     (sched_group_barrier pins the interleave; left alone hipcc emits read-pair / wait / MFMA-pair).
+#include "fvk_common.h"
+
+namespace {
+
+constexpr int KT = 128;             // keys per tile
+constexpr int K_TILE = KT * 256;    // 128 keys x 128 d bf16
+constexpr int V_TILE = 128 * KT * 2;  // 128 d x 128 keys bf16
+constexpr int RING = 2;
+constexpr int V_BASE = RING * K_TILE;
+constexpr int LDS_BYTES = RING * (K_TILE + V_TILE);  // 131 072
+
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <bool PROBE, bool PRIO>
+__global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    constexpr int BMQ = 256;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nqb = (a.Sq + BMQ - 1) / BMQ;
+    const int qb = blockIdx.x % nqb;
+    const int h = (blockIdx.x / nqb) % a.H;
+    const int b = blockIdx.x / (nqb * a.H);
+
+    const bf16_t* qp = (const bf16_t*)a.q + (long)b * a.q_bs + (long)h * a.q_hs;
+    const bf16_t* kp = (const bf16_t*)a.k + (long)b * a.k_bs + (long)h * a.k_hs;
+    const bf16_t* vtp = (const bf16_t*)a.vt + ((long)b * a.H + h) * 128L * a.Skv_pad;
+    bf16_t* op = (bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs;
+    const int n = (a.Skv + KT - 1) / KT;  // KV tiles
+
+    // ---- Q fragments (B operand of S^T = K·Q^T): row q0 + l31, d = 16*ks + 8*hi .. +8 ------------------------------------
+    const int q0 = qb * BMQ + wave * 32;
+    int qrow = q0 + l31;
+    const bool q_ok = qrow < a.Sq;
+    qrow = q_ok ? qrow : a.Sq - 1;
+    bf16x8 qf[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks] = ld_bf16x8(qp + (long)qrow * a.q_ss + ks * 16 + hi * 8);
+
+    // ---- LDS-DMA: wave w moves K pieces {w, w+8, w+16, w+24} (4 key rows x 256 B each) and the same pieces of V^T (4 d rows x 256 B).
+    // LDS image of both tiles: row r, 16-B chunk c at r*256 + ((c ^ (r&15)) << 4).  The hardware writes lane-linearly, so each lane
+    // fetches the SOURCE chunk that belongs at its linear position.  Key rows >= Skv are out of the descriptor's range -> zeros.
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)kp, 0, (unsigned)((((long)a.Skv - 1) * a.k_ss + 128) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vtp, 0, (unsigned)(256L * a.Skv_pad), 0x00020000);
+    unsigned kvoff[4], vvoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 4 * (wave + 8 * i) + (lane >> 4);
+        const unsigned sw = (unsigned)(((lane & 15) ^ (r & 15)) << 4);
+        kvoff[i] = (unsigned)(((long)r * a.k_ss) * 2) + sw;
+        vvoff[i] = (unsigned)(r * a.Skv_pad * 2) + sw;
+    }
+    const unsigned k_tile_bytes = (unsigned)(a.k_ss * 2 * KT);  // bytes between consecutive key tiles
+    const int pdst = wave * 1024;                               // + ring slot, + i*8192
+
+    // piece I (0..3 = K(T+1), 4..7 = V^T(T)) of the set that tile step T makes room for; tiles past the end re-read tile 0 (harmless)
+#define ISSUE_PIECE(T, I)                                                                                            \
+    {                                                                                                                \
+        if ((I) < 4) {                                                                                               \
+            const int t_ = (T) + 1 < n ? (T) + 1 : 0;                                                                \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + (((T) + 1) & 1) * K_TILE + pdst + (I) * 8192), 16, \
+                                                     kvoff[I] + (unsigned)t_ * k_tile_bytes, 0, 0, 0);               \
+        } else {                                                                                                     \
+            const int t_ = (T) < n ? (T) : 0;                                                                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + ((T) & 1) * V_TILE + pdst + ((I) - 4) * 8192), 16, \
+                                                     vvoff[(I) - 4], __builtin_amdgcn_readfirstlane(t_ * (KT * 2)), 0, 0); \
+        }                                                                                                            \
+    }
+#define ISSUE_SET(T) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) ISSUE_PIECE(T, i_) }
+
+    // ---- fragment read offsets (same swizzle for both tiles): row l31 (+32*block), k-chunk 2*step + hi ------------------------
+    int foff[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) foff[ks] = l31 * 256 + (((2 * ks + hi) ^ (l31 & 15)) << 4);
+
+    f32x16 o[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    f32x16 s[4];
+    bf16x8 pf[8];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float m_run = -1e30f, l_run = 0.f;
+    const float c2 = a.scale * 1.4426950408889634f;
+
+    // fragment i of the matrix segment of tile step J: i < 32: V^T(J-1) block (k-step i>>2, d-block i&3); else K(J) (k-step, key block)
+#define FRAG(J, I) \
+    (*reinterpret_cast<const bf16x8*>((I) < 32 ? smem + V_BASE + (((J) - 1) & 1) * V_TILE + foff[(I) >> 2] + ((I) & 3) * 8192 \
+                                                : smem + ((J) & 1) * K_TILE + foff[((I) - 32) >> 2] + ((I) & 3) * 8192))
+    // the matrix segment: FIRST..63; DMA != 0: this wave's 8 pieces of set J ride in the MFMA gaps
+#define MSEG(J, FIRST, LAST, DMA)                                                                                    \
+    {                                                                                                                \
+        constexpr int FD = 6;                                                                                        \
+        bf16x8 fr_[FD];                                                                                              \
+        _Pragma("unroll") for (int i = 0; i < FD; ++i) fr_[i] = FRAG(J, (FIRST) + i);                                \
+        __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);                                                          \
+        _Pragma("unroll") for (int i = (FIRST); i < (LAST); ++i) {                                                   \
+            if (i < 32) o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[(i - (FIRST)) % FD], pf[i >> 2], o[i & 3], 0, 0, 0); \
+            else if (i < 36) s[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[(i - (FIRST)) % FD], qf[0], zero16, 0, 0, 0); /* S is not live during P·V */ \
+            else s[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[(i - (FIRST)) % FD], qf[(i - 32) >> 2], s[i & 3], 0, 0, 0); \
+            const int n_ = i + FD;                                                                                   \
+            if (n_ < (LAST)) fr_[(n_ - (FIRST)) % FD] = FRAG(J, n_);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
+            if (n_ < (LAST)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
+            if ((DMA) && (i & 3) == 1 && i < 32 && grp == 0) ISSUE_PIECE(J, i >> 2) /* wave-uniform branch: one code path for both groups \
+                                                                             (two copies of the stream spill ~100 VGPRs) */ \
+        }                                                                                                            \
+    }
+    // online softmax of tile J (row q = lane&31; this lane holds 64 of its 128 scores, lane^32 the other 64)
+#define SOFTMAX(J)                                                                                                   \
+    {                                                                                                                \
+        const int valid_ = a.Skv - (J) * KT;                                                                         \
+        if (valid_ < KT) {                                                                                           \
+            _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) {       \
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;                                           \
+                if (key >= valid_) s[kb][r] = -INFINITY;                                                             \
+            }                                                                                                        \
+        }                                                                                                            \
+        float mx4[4];                                                                                                \
+        _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) {                                                           \
+            mx4[kb] = fmaxf(s[kb][0], s[kb][1]);                                                                     \
+            _Pragma("unroll") for (int r = 2; r < 16; r += 2) mx4[kb] = fmaxf(fmaxf(mx4[kb], s[kb][r]), s[kb][r + 1]); \
+        }                                                                                                            \
+        const float mx = xhalf_max(fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3])));                             \
+        const float m_new = fmaxf(m_run, mx);                                                                        \
+        if (!__all(m_new == m_run)) {                                                                                \
+            float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);                                              \
+            asm volatile("s_nop 1" : "+v"(alpha)); /* trans-op result -> VALU read wait state: hipcc pads nothing for inline asm */ \
+            l_run *= alpha;                                                                                          \
+            /* single-issue v_mul_f32: hipcc SLP-packs these into v_pk_mul_f32, which crawls beside the partner wave's MFMAs  \
+               (s_memtime probe: a wave taking this branch finished its segment ~1900 cycles late) */                  \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) _Pragma("unroll") for (int r = 0; r < 16; ++r)             \
+                asm volatile("v_mul_f32 %0, %1, %0" : "+v"(o[d][r]) : "v"(alpha));                                   \
+            m_run = m_new;                                                                                           \
+        }                                                                                                            \
+        const float mc = m_run * c2;                                                                                 \
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};                                                                         \
+        _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) {           \
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -mc));                              \
+            s[kb][r] = p;                                                                                            \
+            ps4[r & 3] += p;                                                                                         \
+        }                                                                                                            \
+        l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);                                                              \
+        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) _Pragma("unroll") for (int jj = 0; jj < 8; ++jj)           \
+            pf[kk][jj] = (bf16_t)s[kk >> 1][(kk & 1) * 8 + jj];                                                      \
+        /* keep the packing inside this (VALU) segment: without a use here it is sunk below the barrier into the matrix segment */ \
+        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(pf[kk]));                           \
+    }
+#define WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define BAR()                                   \
+    {                                           \
+        __builtin_amdgcn_sched_barrier(0);      \
+        __builtin_amdgcn_s_barrier();           \
+        __builtin_amdgcn_sched_barrier(0);      \
+    }
+
+    // ---- prologue: K(0) landed; set 0 = {K(1), V(0)} in flight ----------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + pdst + i * 8192), 16, kvoff[i], 0, 0, 0);
+    ISSUE_SET(0)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    BAR()
+    if (grp == 1) BAR()  // stagger: waves 4-7 run one barrier behind
+
+    // ---- j = 0: Q·K^T only ---------------------------------------------------------------------------------------------------
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+    MSEG(0, 32, 64, 0)
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    if (grp == 1) WAIT_ALL()  // trailing group: set 0 landed before the barrier that precedes the leading group's M(1)
+    BAR()
+    if (grp == 1) ISSUE_SET(1)  // ring slots of set 1 are free: every wave has finished M(0)
+    SOFTMAX(0)
+    if (grp == 0) WAIT_ALL()
+    BAR()
+    // ---- steady state ----------------------------------------------------------------------------------------------------------
+    // PROBE (timing only): every wave of workgroup 0 sums the s_memtime deltas between its segment boundaries over tiles 50..177 in
+    // registers and writes the sums to a.lse (as uint64) after the loop.
+    unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0}, abs_[6] = {0, 0, 0, 0, 0, 0}, last_ = 0;
+#define STAMP(K)                                                                                                     \
+    if (PROBE && blockIdx.x == 0 && j >= 50 && j < 178) {                                                            \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                                \
+        if ((K) != 0 || j > 50) acc_[K] += now_ - last_;                                                             \
+        last_ = now_;                                                                                                \
+        if (j == 100) abs_[K] = now_;                                                                                \
+    }
+    for (int j = 1; j < n; ++j) {
+        STAMP(0)
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
+        MSEG(j, 0, 64, 1)  // leading group: set j rides in the MFMA gaps (its ring slots are free: the barrier just passed ended M(j-1))
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        STAMP(1)
+        if (grp == 1) WAIT_ALL()         // set j (issued at the top of V(j-1)) landed
+        BAR()
+        STAMP(2)
+        if (grp == 1) ISSUE_SET(j + 1)
+        STAMP(3)
+        SOFTMAX(j)
+        STAMP(4)
+        if (grp == 0) WAIT_ALL()         // set j (issued inside M(j)) landed
+        BAR()
+        STAMP(5)
+    }
+    if (PROBE && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 6; ++i) {
+            reinterpret_cast<unsigned long long*>(a.lse)[wave * 8 + i] = acc_[i];
+            reinterpret_cast<unsigned long long*>(a.lse)[64 + wave * 8 + i] = abs_[i];
+        }
+    // ---- j = n: last P·V ---------------------------------------------------------------------------------------------------------
+    if (PRIO) __builtin_amdgcn_s_setprio(1);
+    MSEG(n, 0, 32, 0)
+    if (PRIO) __builtin_amdgcn_s_setprio(0);
+    WAIT_ALL()           // drain the tail re-reads before this workgroup's LDS can be re-assigned
+    if (grp == 0) BAR()  // matches the extra leading barrier of waves 4-7
+#undef ISSUE_PIECE
+#undef ISSUE_SET
+#undef FRAG
+#undef MSEG
+#undef STAMP
+#undef SOFTMAX
+#undef WAIT_ALL
+#undef BAR
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------------
+    const float l_tot = xhalf_sum(l_run);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (q_ok) {
+        bf16_t* orow = op + (long)qrow * a.o_ss;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 v4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(o[d][g * 4 + e] * inv);
+                *reinterpret_cast<bf16x4*>(orow + d * 32 + g * 8 + hi * 4) = v4;
+            }
+        if (!PROBE && a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow] = m_run * c2 + log2f(l_tot);
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+}  // namespace
+
+template <bool PROBE, bool PRIO>
+static int launch_pp2(const fvk_attn_args* a, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute((const void*)attn_pp2_kernel<PROBE, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+            fvk_set_error("fvk_attn_dense_bf16 (pp2): cannot set dynamic LDS size");
+            return FVK_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
+    hipLaunchKernelGGL((attn_pp2_kernel<PROBE, PRIO>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+// probe != 0: timing probe build (a->lse receives s_memtime sums, see PROBE)
+int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s) {
+    switch (probe) {  // 0 shipped; 1 probe; 2 = no s_setprio (A/B); 3 = probe without s_setprio
+        case 1: return launch_pp2<true, true>(a, s);
+        case 2: return launch_pp2<false, false>(a, s);
+        case 3: return launch_pp2<true, false>(a, s);
+        default: return launch_pp2<false, true>(a, s);
+    }
+}

@@ -1,8 +1,9 @@
 #!/bin/bash
-# PMC passes (separate runs, kernel-trace only) for the dominant kernels; prints per-kernel counter sums.
-# usage: scripts/pmc.sh <tag>
+# PMC passes (separate runs, kernel-trace only — never combined with other trace domains) for one kernel family; prints
+# per-kernel counter sums.   usage: scripts/pmc.sh <tag> <kernel-substring> <python script + args...>
 set -u
-TAG=${1:-r1}
+TAG=${1:-r1}; KSUB=${2:-attn_pp}; shift 2
+CMD=${*:-scripts/attn_only.py}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/pmc/$TAG
@@ -12,19 +13,18 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/p$i" -o pmc -- python scripts/attn_only.py > "$OUT/p$i.log" 2>&1 < /dev/null
+  timeout 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/p$i" -o pmc -- python $CMD > "$OUT/p$i.log" 2>&1 < /dev/null
   echo "pass $i ($SET) rc=$?"
 done
-python - "$OUT" <<'PY'
+python - "$OUT" "$KSUB" <<'PY'
 import csv, glob, sys, collections
-out = sys.argv[1]
+out, ksub = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(int)
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "attn_fwd" in k: k = "attn_fwd"
-        elif "gemm_bf16" in k: k = "gemm_bf16"
-        else: continue
+        if ksub not in k: continue
+        k = k.replace("(anonymous namespace)::", "").replace("void ", "")[:48].replace(",", ";")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
 with open(out + "/summary.csv", "w") as fo:
@@ -35,3 +35,4 @@ with open(out + "/summary.csv", "w") as fo:
             line = f"{k},{c},{v:.6g},{n},{v/n:.6g}"
             print(line); fo.write(line + "\n")
 PY
+find "$OUT" -name "*.csv" -size +5M -delete
