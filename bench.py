@@ -142,7 +142,7 @@ def main():
     flops_launch = 4.0 * Sq * Skv * h * cfg.head_dim
     mean_ms = sum(attn_ms) / len(attn_ms)
     achieved = flops_launch / (mean_ms * 1e-3) / 1e12
-    roof = dict(bound="mfma", kernel="attn_pp_kernel (dense self-attention, 8-wave ping-pong)", achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS,
+    roof = dict(bound="mfma", kernel="attn_pp2_kernel (dense self-attention, 8-wave ping-pong, 128-key tiles)", achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS,
                 unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
                 flops_per_launch=flops_launch, mean_launch_ms=round(mean_ms, 4), launches=len(attn_ms),
                 share_of_step=round(sum(attn_ms) / args.steps / (elapsed / args.steps * 1e3), 3))

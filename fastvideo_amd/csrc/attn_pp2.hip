@@ -72,31 +72,31 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)kp, 0, (unsigned)((((long)a.Skv - 1) * a.k_ss + 128) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vtp, 0, (unsigned)(256L * a.Skv_pad), 0x00020000);
-    unsigned kvoff[4], vvoff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 4 * (wave + 8 * i) + (lane >> 4);
-        const unsigned sw = (unsigned)(((lane & 15) ^ (r & 15)) << 4);
-        kvoff[i] = (unsigned)(((long)r * a.k_ss) * 2) + sw;
-        vvoff[i] = (unsigned)(r * a.Skv_pad * 2) + sw;
-    }
+    // The TRAILING group (waves 4-7) issues every piece: its softmax segment has ~900 cycles of slack per tile, the leading group's
+    // matrix segment has none.  Wave w' = wave-4 moves pieces {w', w'+4, ..., w'+28} of K and of V^T; rows r = 4*piece + (lane>>4),
+    // and r & 15 does not depend on the piece index, so one swizzled base per tensor + a scalar stride addresses all eight.
+    const int wq = wave & 3;
+    const int r0 = 4 * wq + (lane >> 4);
+    const unsigned sw0 = (unsigned)(((lane & 15) ^ (r0 & 15)) << 4);
+    const unsigned kv0 = (unsigned)(((long)r0 * a.k_ss) * 2) + sw0, vv0 = (unsigned)(r0 * a.Skv_pad * 2) + sw0;
+    const unsigned k_pstride = (unsigned)(16 * a.k_ss * 2), v_pstride = (unsigned)(16 * a.Skv_pad * 2);  // 16 rows between a wave's pieces
     const unsigned k_tile_bytes = (unsigned)(a.k_ss * 2 * KT);  // bytes between consecutive key tiles
-    const int pdst = wave * 1024;                               // + ring slot, + i*8192
+    const int pdst = wq * 1024;                                 // + ring slot, + i*4096
 
-    // piece I (0..3 = K(T+1), 4..7 = V^T(T)) of the set that tile step T makes room for; tiles past the end re-read tile 0 (harmless)
+    // piece I (0..7 = K(T+1), 8..15 = V^T(T)) of the set that tile step T makes room for; tiles past the end re-read tile 0 (harmless)
 #define ISSUE_PIECE(T, I)                                                                                            \
     {                                                                                                                \
-        if ((I) < 4) {                                                                                               \
+        if ((I) < 8) {                                                                                               \
             const int t_ = (T) + 1 < n ? (T) + 1 : 0;                                                                \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + (((T) + 1) & 1) * K_TILE + pdst + (I) * 8192), 16, \
-                                                     kvoff[I] + (unsigned)t_ * k_tile_bytes, 0, 0, 0);               \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + (((T) + 1) & 1) * K_TILE + pdst + (I) * 4096), 16, \
+                                                     kv0 + (I) * k_pstride + (unsigned)t_ * k_tile_bytes, 0, 0, 0);  \
         } else {                                                                                                     \
             const int t_ = (T) < n ? (T) : 0;                                                                        \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + ((T) & 1) * V_TILE + pdst + ((I) - 4) * 8192), 16, \
-                                                     vvoff[(I) - 4], __builtin_amdgcn_readfirstlane(t_ * (KT * 2)), 0, 0); \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + ((T) & 1) * V_TILE + pdst + ((I) - 8) * 4096), 16, \
+                                                     vv0 + ((I) - 8) * v_pstride, __builtin_amdgcn_readfirstlane(t_ * (KT * 2)), 0, 0); \
         }                                                                                                            \
     }
-#define ISSUE_SET(T) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) ISSUE_PIECE(T, i_) }
+#define ISSUE_SET(T) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) ISSUE_PIECE(T, i_) }
 
     // ---- fragment read offsets (same swizzle for both tiles): row l31 (+32*block), k-chunk 2*step + hi ------------------------
     int foff[8];
@@ -133,8 +133,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
             if (n_ < (LAST)) fr_[(n_ - (FIRST)) % FD] = FRAG(J, n_);                                                 \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
             if (n_ < (LAST)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
-            if ((DMA) && (i & 3) == 1 && i < 32 && grp == 0) ISSUE_PIECE(J, i >> 2) /* wave-uniform branch: one code path for both groups \
-                                                                             (two copies of the stream spill ~100 VGPRs) */ \
+            /* (an in-stream DMA variant for the leading group measured ~160 cycles slower per segment: see DMA == 0 everywhere) */           \
         }                                                                                                            \
     }
     // online softmax of tile J (row q = lane&31; this lane holds 64 of its 128 scores, lane^32 the other 64)
@@ -185,12 +184,14 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
         __builtin_amdgcn_sched_barrier(0);      \
     }
 
-    // ---- prologue: K(0) landed; set 0 = {K(1), V(0)} in flight ----------------------------------------------------------------
+    // ---- prologue: K(0) landed; set 0 = {K(1), V(0)} in flight (issued by the trailing group) -------------------------------------
+    if (grp == 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + pdst + i * 8192), 16, kvoff[i], 0, 0, 0);
-    ISSUE_SET(0)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + pdst + i * 4096), 16, kv0 + i * k_pstride, 0, 0, 0);
+        ISSUE_SET(0)
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    }
     BAR()
     if (grp == 1) BAR()  // stagger: waves 4-7 run one barrier behind
 
@@ -202,7 +203,6 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
     BAR()
     if (grp == 1) ISSUE_SET(1)  // ring slots of set 1 are free: every wave has finished M(0)
     SOFTMAX(0)
-    if (grp == 0) WAIT_ALL()
     BAR()
     // ---- steady state ----------------------------------------------------------------------------------------------------------
     // PROBE (timing only): every wave of workgroup 0 sums the s_memtime deltas between its segment boundaries over tiles 50..177 in
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
     for (int j = 1; j < n; ++j) {
         STAMP(0)
         if (PRIO) __builtin_amdgcn_s_setprio(1);
-        MSEG(j, 0, 64, 1)  // leading group: set j rides in the MFMA gaps (its ring slots are free: the barrier just passed ended M(j-1))
+        MSEG(j, 0, 64, 0)
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         STAMP(1)
         if (grp == 1) WAIT_ALL()         // set j (issued at the top of V(j-1)) landed
@@ -228,7 +228,6 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
         STAMP(3)
         SOFTMAX(j)
         STAMP(4)
-        if (grp == 0) WAIT_ALL()         // set j (issued inside M(j)) landed
         BAR()
         STAMP(5)
     }

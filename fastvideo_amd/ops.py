@@ -116,7 +116,7 @@ def v_transpose(v):
     B, S, H, D = v.shape
     if v.stride(3) != 1:
         v = v.contiguous()
-    S_pad = (S + 63) // 64 * 64
+    S_pad = (S + 127) // 128 * 128  # whole 128-key tiles: the 128-key-tile attention kernel reads V^T rows in 256-B pieces
     vt = torch.empty((B, H, D, S_pad), dtype=BF16, device=v.device)
     _lib.call("fvk_v_transpose_bf16", _p(v), _p(vt), B, S, H, D, v.stride(1), v.stride(0), v.stride(2), S_pad, _stream())
     return vt

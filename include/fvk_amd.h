@@ -70,7 +70,7 @@ int fvk_rmsnorm_rope_bf16(const void* const* in, void* const* out, const void* c
                           int pos_offset, long in_stride, long out_stride, float eps, void* stream);
 
 /* V[b, s, h, :] at v + b*in_batch_stride + s*in_stride + h*in_head_stride (elements) -> Vt [B, H, D, S_pad] bf16,
- * S_pad = round_up(S, 64), pad columns zero.  Within every aligned group of 16 keys the key order is
+ * S_pad = a multiple of 64 >= S (the host wrapper uses round_up(S, 128): whole tiles of the 128-key-tile kernel), pad columns zero.  Within every aligned group of 16 keys the key order is
  * permuted by swapping bits 2 and 3 of the in-group index (the MFMA-B-operand order of fvk_attn_*; see
  * DESIGN.md "Vt layout").  D == 128. */
 int fvk_v_transpose_bf16(const void* v, void* vt, int B, int S, int H, int D, long in_stride, long in_batch_stride,

@@ -115,7 +115,7 @@ def test_v_transpose_layout(ops):
     B, S, H, D = 2, 150, 3, 128
     v = rnd((B, S, H, D), 1)
     vt = ops.v_transpose(v.to(DEV)).cpu()
-    S_pad = 192
+    S_pad = 256  # whole 128-key tiles (zero padded)
     assert vt.shape == (B, H, D, S_pad)
     p = torch.arange(S_pad)
     key = (p & ~12) | ((p & 4) << 1) | ((p & 8) >> 1)
