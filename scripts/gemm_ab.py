@@ -1,0 +1,22 @@
+"""Interleaved timing of the GEMM kernels at the cfg2 shapes: python scripts/gemm_ab.py [impl ...] (0 stream, 2 ping-pong, 1 128x128)"""
+import os, sys, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fastvideo_amd import ops
+impls = [int(x) for x in sys.argv[1:]] or [0, 2]
+S, d, F = 32760, 1536, 8960
+for name, M, N, K in (("qkv", S, 3 * d, d), ("ffn_in", S, F, d), ("ffn_out", S, d, F), ("8k", 8192, 8192, 8192)):
+    a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * K**-0.5).bfloat16()
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    res = {i: [] for i in impls}
+    for r in range(3):
+        for i in impls:
+            ops.set_tunable("gemm_impl", i)
+            ops.gemm(a, w, None, out=out); torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(5): ops.gemm(a, w, None, out=out)
+            e.record(); torch.cuda.synchronize()
+            res[i].append(s.elapsed_time(e) / 5)
+    ops.set_tunable("gemm_impl", 0)
+    print(name, json.dumps({f"impl{i}_tflops": round(2.0 * M * N * K / sorted(v)[1] / 1e9, 1) for i, v in res.items()}))

@@ -52,7 +52,7 @@ def gemm_case(name, M, N, K, epi=0, residual=False):
     r_ = ab(lambda: ops.gemm(a, w, b, epilogue=epi, residual=r, gate=g, out=out), "gemm_impl", [0, 1])
     ms = t_ms(lambda: torch.nn.functional.linear(a, w, b), it=5)
     res[name] = {"pp_ms": r_[0][0], "pp_tflops": fl / r_[0][0] / 1e9, "pp_best_tflops": fl / r_[0][1] / 1e9,
-                 "v1_ms": r_[1][0], "v1_tflops": fl / r_[1][0] / 1e9, "hipblaslt_ms": ms, "hipblaslt_tflops": fl / ms / 1e9}
+                 "v1_tflops": fl / r_[1][0] / 1e9, "hipblaslt_ms": ms, "hipblaslt_tflops": fl / ms / 1e9}
     print(name, json.dumps(res[name]), flush=True)
 
 
@@ -69,7 +69,7 @@ q, k, v = (torch.randn(1, S, H, D, device=dev).bfloat16() for _ in range(3))
 vt = ops.v_transpose(v)
 o = torch.empty_like(q)
 fl = 4.0 * S * S * H * D
-r_ = ab(lambda: ops.attn_dense(q, k, vt=vt, out=o), "attn_impl", [0, 1, 2, 3, 4], rounds=3, it=3)
+r_ = ab(lambda: ops.attn_dense(q, k, vt=vt, out=o), "attn_impl", [0, 1, 2], rounds=3, it=3)
 res["attn_dense[S=32760,H=12]"] = {f"impl{v_}_tflops": fl / m[0] / 1e9 for v_, m in r_.items()} | {f"impl{v_}_ms": m[0] for v_, m in r_.items()}
 print("attn_dense", json.dumps(res["attn_dense[S=32760,H=12]"]), flush=True)
 # cross-attention shape: 512 text keys
