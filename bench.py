@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--attention", default="dense", choices=["dense", "vsa"])
+    ap.add_argument("--quant", default=None, choices=["fp8", "fp8_channel"],
+                    help="fp8 linear path (BASELINE config 5's GEMM dtype); the contract line is the default bf16 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
     args = ap.parse_args()
@@ -107,7 +109,7 @@ def main():
 
     sd = WC.random_state_dict(cfg, seed=0, device=dev, with_vsa_gate=(args.attention == "vsa"))
     model = WanTransformer3DModelHip(sd, cfg.num_heads, cfg.head_dim, cfg.patch_size, cfg.eps, cfg.freq_dim,
-                                     attention=args.attention, device=dev)
+                                     attention=args.attention, device=dev, quantization=args.quant)
     del sd
     g = torch.Generator(device=dev).manual_seed(1)
     latent = torch.randn(latent_shape, generator=g, device=dev).bfloat16()
@@ -154,7 +156,7 @@ def main():
         "metric": "DiT-step latent-tokens/s, Wan2.1-T2V-1.3B 81fx480p (one DiT forward per step)",
         "value": round(S / (elapsed / args.steps), 1), "unit": "latent-tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (randn latent, random-init weights)",
+        "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if not args.quant else f"{args.quant} linears (e4m3fn MFMA) + bf16 attention", "data": "synthetic (randn latent, random-init weights)",
         "config": {"workload": f"{cfg.name} {cfg.num_layers} layers, latent {list(latent_shape)} = {S} tokens, text 512 tokens, "
                                f"{args.attention} attention, 1 forward/step (no CFG)", "parallelism": par},
         "step_tflops": round(fl["total"] / (ms_per_step * 1e-3) / 1e12, 1),

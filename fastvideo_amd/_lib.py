@@ -49,6 +49,8 @@ SIGNATURES = {
     "fvk_unpatchify_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "fvk_timestep_embedding_bf16": [vp, vp, i32, i32, f32, vp],
     "fvk_silu_bf16": [vp, vp, i64, vp],
+    "fvk_fp8_quantize_bf16": [vp, vp, vp, vp, i32, i32, i64, i32, vp],
+    "fvk_gemm_fp8": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i64, i32, i32, i32, vp, vp, i32, vp],
     "fvk_vae_conv_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i32, i32, vp],
     "fvk_vae_rmsnorm_silu_bf16": [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
 }

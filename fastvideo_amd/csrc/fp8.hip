@@ -1,0 +1,118 @@
+// OCP fp8 (e4m3fn) linear path of the DiT (BASELINE config 5), gfx950.
+// ref: fastvideo/layers/quantization/fp8_config.py:55-68 (_quantize_tensorwise / _quantize_rowwise), :119-158 (FP8QuantizeMethod.apply:
+//      dynamic activation quantisation -> torch._scaled_mm(x_fp8, w_fp8.t(), scale_a, scale_b, out_dtype=bf16) -> + bias),
+//      :211-245 (convert_model_to_fp8: the same arithmetic on the weights, once).
+//   absmax  = max |x|  over the tensor (tensorwise) or per row (rowwise = per token / per output channel)
+//   scale   = max(absmax / 448, 1 / (448 * 512))                                            fp32
+//   q       = e4m3fn_rne( clamp( bf16( float(x) / float(bf16(scale)) ), -448, 448 ) )       (the reference divides in bf16)
+// The GEMM itself is gemm_pp.hip's kernel instantiated with FP8 = true (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales).
+#include "gemm_common.h"
+
+namespace {
+
+constexpr float FP8_MAX = 448.0f;
+constexpr float FP8_MIN_SCALE = 1.0f / (448.0f * 512.0f);
+
+// rowwise: one wave per row.  tensorwise: grid-stride over rows, one atomicMax per wave on the (non-negative) float bits.
+template <bool ROWWISE>
+__global__ __launch_bounds__(256) void fp8_absmax_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, int M, int K, long lda) {
+    const int lane = threadIdx.x & 63;
+    const int wave_g = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int n_waves = (gridDim.x * 256) >> 6;
+    float mx = 0.f;
+    for (int m = wave_g; m < M; m += n_waves) {
+        float r = 0.f;
+        const bf16_t* row = x + (long)m * lda;
+        for (int k = lane * 8; k < K; k += 512) {
+            const bf16x8 v = ld_bf16x8(row + k);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r = fmaxf(r, fabsf((float)v[e]));
+        }
+        if (ROWWISE) {
+            r = wave_max(r);
+            if (lane == 0) out[m] = r;
+        } else {
+            mx = fmaxf(mx, r);
+        }
+    }
+    if (!ROWWISE) {
+        mx = wave_max(mx);
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(mx));
+    }
+}
+
+template <bool ROWWISE>
+__global__ __launch_bounds__(256) void fp8_quantize_kernel(const bf16_t* __restrict__ x, const float* __restrict__ absmax,
+                                                           unsigned char* __restrict__ q, float* __restrict__ scale_out, int M, int K,
+                                                           long lda) {
+    const long chunk = (long)blockIdx.x * 256 + threadIdx.x;  // one 8-element chunk per thread
+    const int kc = K >> 3;
+    const long m = chunk / kc;
+    if (m >= M) return;
+    const int k = (int)(chunk - m * kc) * 8;
+    const float am = ROWWISE ? absmax[m] : absmax[0];
+    const float scale = fmaxf(__fdiv_rn(am, FP8_MAX), FP8_MIN_SCALE);
+    if (k == 0 && (ROWWISE || m == 0)) scale_out[ROWWISE ? m : 0] = scale;
+    const float sb = (float)(bf16_t)scale;  // the reference divides by x_scale.to(x.dtype)
+    const bf16x8 v = ld_bf16x8(x + m * lda + k);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float d = (float)(bf16_t)__fdiv_rn((float)v[e], sb);
+        f[e] = fminf(fmaxf(d, -FP8_MAX), FP8_MAX);
+    }
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+    *reinterpret_cast<int2*>(q + m * (long)K + k) = make_int2(w0, w1);
+}
+
+}  // namespace
+
+extern "C" int fvk_fp8_quantize_bf16(const void* x, void* q, float* scale, float* absmax_scratch, int M, int K, long lda, int rowwise,
+                                     void* stream) {
+    FVK_CHECK(x && q && scale && absmax_scratch, FVK_ERR_ARG, "fvk_fp8_quantize_bf16: null pointer");
+    FVK_CHECK(M > 0 && K > 0 && K % 8 == 0 && lda % 8 == 0, FVK_ERR_ARG, "fvk_fp8_quantize_bf16: M=%d K=%d lda=%ld (K, lda multiples of 8)", M, K, lda);
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks_a = M < 4096 ? (M + 3) / 4 : 1024;
+    if (rowwise) {
+        hipLaunchKernelGGL((fp8_absmax_kernel<true>), dim3((M + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, absmax_scratch, M, K, lda);
+    } else {
+        if (hipMemsetAsync(absmax_scratch, 0, sizeof(float), s) != hipSuccess) {
+            fvk_set_error("fvk_fp8_quantize_bf16: memset failed");
+            return FVK_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL((fp8_absmax_kernel<false>), dim3(blocks_a), dim3(256), 0, s, (const bf16_t*)x, absmax_scratch, M, K, lda);
+    }
+    FVK_LAUNCH_CHECK();
+    const long chunks = (long)M * (K / 8);
+    const unsigned blocks_q = (unsigned)((chunks + 255) / 256);
+    if (rowwise)
+        hipLaunchKernelGGL((fp8_quantize_kernel<true>), dim3(blocks_q), dim3(256), 0, s, (const bf16_t*)x, absmax_scratch, (unsigned char*)q, scale, M, K, lda);
+    else
+        hipLaunchKernelGGL((fp8_quantize_kernel<false>), dim3(blocks_q), dim3(256), 0, s, (const bf16_t*)x, absmax_scratch, (unsigned char*)q, scale, M, K, lda);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+extern "C" int fvk_gemm_fp8(const void* x_fp8, const void* w_fp8, const float* scale_a, const float* scale_b, const void* bias, void* out,
+                            int M, int N, int K, long ldc, int a_rowwise, int b_rowwise, int epilogue, const void* residual,
+                            const float* gate, int rows_per_batch, void* stream) {
+    FVK_CHECK(x_fp8 && w_fp8 && scale_a && scale_b && out, FVK_ERR_ARG, "fvk_gemm_fp8: null pointer");
+    FVK_CHECK(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 8 == 0 && ldc % 8 == 0, FVK_ERR_ARG,
+              "fvk_gemm_fp8: M=%d N=%d K=%d ldc=%ld (K %% 64 == 0, N and ldc multiples of 8)", M, N, K, ldc);
+    FVK_CHECK(epilogue == FVK_EPI_NONE || epilogue == FVK_EPI_GELU_TANH || epilogue == FVK_EPI_SILU || epilogue == FVK_EPI_RESIDUAL_GATE,
+              FVK_ERR_ARG, "fvk_gemm_fp8: epilogue %d unsupported", epilogue);
+    FVK_CHECK(epilogue != FVK_EPI_RESIDUAL_GATE || residual, FVK_ERR_ARG, "fvk_gemm_fp8: residual epilogue without residual");
+    FVK_CHECK(((uintptr_t)x_fp8 & 15) == 0 && ((uintptr_t)w_fp8 & 15) == 0 && ((uintptr_t)out & 15) == 0, FVK_ERR_ARG,
+              "fvk_gemm_fp8: operands must be 16-byte aligned");
+    FVK_CHECK(255L * K + K < 0x7fffffffL, FVK_ERR_ARG, "fvk_gemm_fp8: K too large");
+    fvk::GemmArgs a{};
+    a.x = (const bf16_t*)x_fp8; a.w = (const bf16_t*)w_fp8; a.bias = (const bf16_t*)bias; a.out = (bf16_t*)out;
+    a.residual = (const bf16_t*)residual; a.gate = gate;
+    a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = ldc; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
+    a.scale_a = scale_a; a.scale_b = scale_b; a.scale_a_rowwise = a_rowwise; a.scale_b_rowwise = b_rowwise;
+    return fvk::gemm_pp_fp8_launch(a, epilogue, (hipStream_t)stream);
+}

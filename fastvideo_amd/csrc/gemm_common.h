@@ -18,11 +18,16 @@ struct GemmArgs {
     int ntm, ntn;
     float epi_scalar;
     long x_bstride, w_bstride, out_bstride;
+    // fp8 path (gemm_pp_fp8_launch): x / w point at e4m3 bytes; dequantisation scales, one value or one per row / output channel
+    const float* scale_a;
+    const float* scale_b;
+    int scale_a_rowwise, scale_b_rowwise;
 };
 
 // gemm_pp.hip
 bool gemm_pp_eligible(const GemmArgs& a);
 int gemm_pp_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
+int gemm_pp_fp8_launch(GemmArgs a, int epilogue, hipStream_t s);
 
 // capi.hip: integer knobs for within-process A/B measurements (fvk_set_tunable); defaults are the shipped configuration.
 enum Tunable { TUNE_GEMM_IMPL = 0, TUNE_ATTN_IMPL = 1, TUNE_COUNT = 8 };

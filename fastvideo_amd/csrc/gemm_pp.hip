@@ -41,7 +41,10 @@ __device__ __forceinline__ float gelu_tanh_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + t);
 }
 
-template <int EPI>
+// FP8: x and w are OCP e4m3 bytes ([M,K] / [N,K], K-contiguous); a K-step is 64 elements = the same 64-B LDS rows, and the 16 bf16 MFMAs
+// of a step become 8 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the bf16 MFMA rate; the k order inside a fragment is
+// irrelevant as long as A and B use the same one — scripts/probes/mfma_fp8_layout.hip).  The epilogue applies the dequantisation scales.
+template <int EPI, bool FP8>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -75,21 +78,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     // ---- LDS-DMA staging: waves 0-3 stage the x panel, waves 4-7 the w panel; 4 pieces (16 rows x 64 B) per wave per step
     const bool stage_w = wave >= 4;
     const int srow0 = (wave & 3) * 64;
-    const bf16_t* sbase = stage_w ? a.w + (long)n0 * a.K : a.x + (long)m0 * a.lda;
+    constexpr int ES = FP8 ? 1 : 2;  // bytes per operand element
+    const unsigned char* sbase = stage_w ? (const unsigned char*)a.w + (long)n0 * a.K * ES : (const unsigned char*)a.x + (long)m0 * a.lda * ES;
     const long sld = stage_w ? (long)a.K : a.lda;
     int srows = stage_w ? a.N - n0 : a.M - m0;
     srows = srows > 256 ? 256 : srows;
-    const int nrec = (int)((((long)srows - 1) * sld + a.K) * 2);  // rows past the panel's valid rows read as zeros
+    const int nrec = (int)((((long)srows - 1) * sld + a.K) * ES);  // rows past the panel's valid rows read as zeros
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, nrec, 0x00020000);
     int voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = srow0 + 16 * i + (lane >> 2);
         const int c = (lane & 3) ^ ((lane >> 4) & 3);  // source chunk that lands at LDS chunk position lane&3 of this row
-        voff[i] = (int)((long)row * sld * 2) + c * 16;
+        voff[i] = (int)((long)row * sld * ES) + c * 16;
     }
     const int dma_dst = (stage_w ? REGION : 0) + srow0 * 64;  // + slot*SLOT + i*1024 (+ lane*16 by the hardware)
-    const int nt = a.K / TK;
+    const int nt = a.K * ES / (TK * 2);  // K-steps of 64 bytes per row
 
 #define PP_ISSUE(TILE)                                                                                              \
     {                                                                                                               \
@@ -102,10 +106,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 
     // ---- fragment read offsets (bytes within a slot): row r, k-chunk c at r*64 + ((c ^ ((r>>2)&3)) << 4) ------------
     const int sw = (l31 >> 2) & 3;
-    const int xb0 = (wm * 128 + l31) * 64 + ((hi ^ sw) << 4);
-    const int xb1 = (wm * 128 + l31) * 64 + (((2 + hi) ^ sw) << 4);
-    const int wb0 = REGION + (wn * 64 + l31) * 64 + ((hi ^ sw) << 4);
-    const int wb1 = REGION + (wn * 64 + l31) * 64 + (((2 + hi) ^ sw) << 4);
+    // bf16: fragment ks = chunk 2*ks + hi (8 k per lane).  fp8: ONE 32-byte fragment = chunks 2*hi and 2*hi + 1 (32 k per lane).
+    const int c0 = FP8 ? 2 * hi : hi, c1 = FP8 ? 2 * hi + 1 : 2 + hi;
+    const int xb0 = (wm * 128 + l31) * 64 + ((c0 ^ sw) << 4);
+    const int xb1 = (wm * 128 + l31) * 64 + ((c1 ^ sw) << 4);
+    const int wb0 = REGION + (wn * 64 + l31) * 64 + ((c0 ^ sw) << 4);
+    const int wb1 = REGION + (wn * 64 + l31) * 64 + ((c1 ^ sw) << 4);
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -145,13 +151,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         // MFMA segment
         __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        if (FP8) {
+            typedef int v8i __attribute__((ext_vector_type(8)));
+            typedef int v4i __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-                for (int mb = 0; mb < 4; ++mb)
-                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb][ks], xf[mb][ks], acc[nb][mb], 0, 0, 0);
+                for (int mb = 0; mb < 4; ++mb) {
+                    const v4i w0 = __builtin_bit_cast(v4i, wf[nb][0]), w1 = __builtin_bit_cast(v4i, wf[nb][1]);
+                    const v4i x0 = __builtin_bit_cast(v4i, xf[mb][0]), x1 = __builtin_bit_cast(v4i, xf[mb][1]);
+                    const v8i wa = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+                    const v8i xa = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3]};
+                    acc[nb][mb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wa, xa, acc[nb][mb], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int mb = 0; mb < 4; ++mb)
+                        acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb][ks], xf[mb][ks], acc[nb][mb], 0, 0, 0);
+        }
         __builtin_amdgcn_s_setprio(0);
         if (grp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // step u+1 landed (this wave's pieces)
         __builtin_amdgcn_sched_barrier(0);
@@ -177,11 +198,28 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) b4[e] = (float)bv[e];
             }
+            float sb4[4] = {1.f, 1.f, 1.f, 1.f};
+            if (FP8) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sb4[e] = a.scale_b_rowwise ? (ncol0 + nl + e < a.N ? a.scale_b[ncol0 + nl + e] : 0.f) : a.scale_b[0];
+            }
 #pragma unroll
             for (int mb = 0; mb < 4; ++mb) {
                 bf16x4 y;
+                if (FP8) {
+                    // ref: torch._scaled_mm(x_fp8, w_fp8.t(), scale_a, scale_b, out_dtype=bf16) then `out + bias` in bf16
+                    // (fastvideo/layers/quantization/fp8_config.py:141-152): two roundings
+                    const int mrow = m0 + wm * 128 + mb * 32 + l31;
+                    const float sa = a.scale_a_rowwise ? (mrow < a.M ? a.scale_a[mrow] : 0.f) : a.scale_a[0];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (bf16_t)(acc[nb][mb][4 * g + e] + b4[e]);
+                    for (int e = 0; e < 4; ++e) {
+                        const float y0 = (float)(bf16_t)(acc[nb][mb][4 * g + e] * (sa * sb4[e]));
+                        y[e] = a.bias ? (bf16_t)(y0 + b4[e]) : (bf16_t)y0;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = (bf16_t)(acc[nb][mb][4 * g + e] + b4[e]);
+                }
                 *reinterpret_cast<bf16x4*>(st + (mb * 32 + l31) * EPI_PITCH + nl * 2) = y;
             }
         }
@@ -222,18 +260,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int EPI>
+template <int EPI, bool FP8 = false>
 int launch(const GemmArgs& a, int batch, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        if (hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) {
             fvk_set_error("fvk_gemm_bf16 (pp): cannot set dynamic LDS size %d", LDS_BYTES);
             return FVK_ERR_LAUNCH;
         }
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI>), dim3(a.ntm * a.ntn, batch), dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, FP8>), dim3(a.ntm * a.ntn, batch), dim3(512), LDS_BYTES, s, a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -254,6 +292,17 @@ bool gemm_pp_eligible(const GemmArgs& a) {
     // 32-bit buffer offsets within one 256-row panel
     if (255L * a.lda * 2 + (long)a.K * 2 > 0x7fffffffL || 255L * a.K * 2 + (long)a.K * 2 > 0x7fffffffL) return false;
     return true;
+}
+
+int gemm_pp_fp8_launch(GemmArgs a, int epilogue, hipStream_t s) {
+    a.ntm = (a.M + TM - 1) / TM;
+    a.ntn = (a.N + TN - 1) / TN;
+    switch (epilogue) {
+        case FVK_EPI_NONE: return launch<FVK_EPI_NONE, true>(a, 1, s);
+        case FVK_EPI_GELU_TANH: return launch<FVK_EPI_GELU_TANH, true>(a, 1, s);
+        case FVK_EPI_SILU: return launch<FVK_EPI_SILU, true>(a, 1, s);
+        default: return launch<FVK_EPI_RESIDUAL_GATE, true>(a, 1, s);
+    }
 }
 
 int gemm_pp_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {

@@ -162,6 +162,51 @@ def gemm_batched(x, w, epilogue=EPI_NONE, scalar=1.0):
     return out
 
 
+# ------------------------------------------------------------------ fp8 (e4m3fn) linear path
+FP8 = torch.float8_e4m3fn
+
+
+def fp8_quantize(x, rowwise=False):
+    """Dynamic quantisation of a bf16 [M, K] tensor (fvk_fp8_quantize_bf16; ref: fp8_config.py:55-68).
+    Returns (q float8_e4m3fn [M, K], scale fp32 [1] or [M, 1])."""
+    _chk(x, BF16, "x")
+    K = x.shape[-1]
+    x2 = x if (x.dim() == 2 and x.stride(1) == 1) else x.contiguous().view(-1, K)
+    M = x2.shape[0]
+    q = torch.empty((M, K), dtype=FP8, device=x.device)
+    n = M if rowwise else 1
+    scale = torch.empty((n,), dtype=torch.float32, device=x.device)
+    scratch = torch.empty((n,), dtype=torch.float32, device=x.device)
+    _lib.call("fvk_fp8_quantize_bf16", _p(x2), _p(q), _p(scale), _p(scratch), M, K, x2.stride(0), int(rowwise), _stream())
+    return q, (scale.view(M, 1) if rowwise else scale)
+
+
+def gemm_fp8(x_q, x_scale, w_q, w_scale, bias=None, epilogue=EPI_NONE, residual=None, gate=None, rows_per_batch=None, out=None):
+    """out = epilogue(bf16(bf16((x_q @ w_q^T) * x_scale * w_scale) + bias)) — torch._scaled_mm + bias of FP8QuantizeMethod.apply
+    (fp8_config.py:119-158).  x_q [M,K], w_q [N,K] float8_e4m3fn; scales fp32 [1] (tensorwise) or [M,1] / [N] (rowwise)."""
+    for t, n in ((x_q, "x_q"), (w_q, "w_q")):
+        _chk(t, FP8, n)
+    M, K = x_q.shape
+    N = w_q.shape[0]
+    x_q, w_q = x_q.contiguous(), w_q.contiguous()
+    x_scale, w_scale = _f32(x_scale, "x_scale").view(-1), _f32(w_scale, "w_scale").view(-1)
+    a_row, b_row = int(x_scale.numel() != 1), int(w_scale.numel() != 1)
+    if (a_row and x_scale.numel() != M) or (b_row and w_scale.numel() != N):
+        raise RuntimeError("gemm_fp8: scale shapes must be [1] or one per row / output channel")
+    if out is None:
+        out = torch.empty((M, N), dtype=BF16, device=x_q.device)
+    res2 = None if residual is None else _chk(residual, BF16, "residual").contiguous().view(-1, N)
+    gate = _f32(gate, "gate")
+    if rows_per_batch is None:
+        B = 1 if gate is None else gate.numel() // N
+        rows_per_batch = max(M // B, 1)
+    if bias is not None:
+        bias = _chk(bias, BF16, "bias").contiguous()
+    _lib.call("fvk_gemm_fp8", _p(x_q), _p(w_q), _p(x_scale), _p(w_scale), _p(bias), _p(out), M, N, K, out.stride(0), a_row, b_row,
+              epilogue, _p(res2), _p(gate), rows_per_batch, _stream())
+    return out
+
+
 # ------------------------------------------------------------------ attention
 def _attn_args(q, k, vt, o, scale, layout, lse=None, qk_dim=0):
     """layout 'bshd': q [B,S,H,D]; 'bhsd': q [B,H,S,D]."""

@@ -37,7 +37,7 @@ class WanTransformer3DModelHip:
 
     def __init__(self, state_dict: dict, num_heads: int, head_dim: int = 128, patch_size=(1, 2, 2), eps: float = 1e-6,
                  freq_dim: int = 256, attention: str = "dense", vsa_sparsity: float = 0.8, sta_window=(3, 3, 3),
-                 sta_tile=(6, 8, 8), sp_group=None, device="cuda"):
+                 sta_tile=(6, 8, 8), sp_group=None, device="cuda", quantization: str | None = None):
         if head_dim != 128:
             raise ValueError("the gfx950 attention kernels are specialised for head_dim 128 (Wan2.1 / Wan2.2)")
         if attention not in ("dense", "vsa", "sta"):
@@ -47,6 +47,11 @@ class WanTransformer3DModelHip:
         self.attention, self.vsa_sparsity = attention, vsa_sparsity
         self.sta_window, self.sta_tile = tuple(sta_window), tuple(sta_tile)
         self.device = torch.device(device)
+        # quantization: None (bf16) | "fp8" (per-tensor scales) | "fp8_channel" (per-output-channel weights, per-token activations):
+        # FP8Config(granularity=...) of fastvideo/layers/quantization/fp8_config.py applied to to_q/k/v/to_out (both attentions) and ffn
+        if quantization not in (None, "fp8", "fp8_channel"):
+            raise ValueError(f"unknown quantization {quantization!r}")
+        self.quant = quantization
         self.sp = SequenceParallel(num_heads, sp_group)
         if attention != "dense" and self.sp.lay.P != 1:
             raise NotImplementedError("sparse attention under sequence parallelism is wired in a later round")
@@ -97,6 +102,28 @@ class WanTransformer3DModelHip:
         self.blocks = blocks
         # all layers' text K/V projections as ONE GEMM over the 512 text tokens: [L*2d, d]
         self.ckv_w, self.ckv_b = b16(torch.cat(kv_w, 0)), b16(torch.cat(kv_b, 0))
+        if self.quant:
+            # convert_model_to_fp8 (fp8_config.py:211-245): every tagged linear is quantised on its own (own scale); a fused weight
+            # [sum N_i, K] therefore carries a per-row scale vector that is constant inside each original matrix (tensor granularity)
+            row = self.quant == "fp8_channel"
+
+            def q8(wcat, n_parts):
+                parts = wcat.chunk(n_parts, 0)
+                qs, ss = zip(*[ops.fp8_quantize(p_.contiguous(), rowwise=row) for p_ in parts])
+                scales = [s_.view(-1) if row else s_.expand(p_.shape[0]) for s_, p_ in zip(ss, parts)]
+                return torch.cat(qs, 0).contiguous(), torch.cat(scales, 0).contiguous()
+
+            for b in blocks:
+                if b["n_qkv"] == 4:  # to_gate_compress is not an fp8-tagged layer (fp8_config.py:31-44): it stays a bf16 GEMM
+                    b["gate_w"], b["gate_b"] = b["qkv_w"][3 * self.d:].contiguous(), b["qkv_b"][3 * self.d:].contiguous()
+                    b["qkv_w"], b["qkv_b"] = b["qkv_w"][:3 * self.d].contiguous(), b["qkv_b"][:3 * self.d].contiguous()
+                b["qkv_q"], b["qkv_s"] = q8(b["qkv_w"], 3)
+                for k_ in ("o", "cq", "co", "f1", "f2"):
+                    b[k_ + "_q"], b[k_ + "_s"] = q8(b[k_ + "_w"], 1)
+                    del b[k_ + "_w"]
+                del b["qkv_w"]
+            self.ckv_q, self.ckv_s = q8(self.ckv_w, 2 * L)
+            del self.ckv_w
         self.tables = b16(torch.stack(tables, 0))  # [L,1,6,d] in parameter dtype (bf16 + fp32 temb -> fp32, :386-390)
 
     # ------------------------------------------------------------------ attention variants
@@ -143,6 +170,13 @@ class WanTransformer3DModelHip:
         # sliding tile attention: tokens must be in tile-major order on a canvas padded to whole tiles
         raise NotImplementedError("sta mode in the full model is wired in a later round (kernel: ops.attn_sta)")
 
+    def _lin(self, x, b, key, bias, **kw):
+        """y = epilogue(x @ W^T + bias) through the bf16 GEMM or the fp8 path (dynamic activation quantisation + fp8 MFMA GEMM)."""
+        if not self.quant:
+            return ops.gemm(x, b[key + "_w"], bias, **kw)
+        xq, xs = ops.fp8_quantize(x, rowwise=(self.quant == "fp8_channel"))
+        return ops.gemm_fp8(xq, xs, b[key + "_q"], b[key + "_s"], bias, **kw)
+
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, hidden_states, encoder_hidden_states, timestep, trace=None):
@@ -173,7 +207,7 @@ class WanTransformer3DModelHip:
         Lc = ctx.shape[1]
         c = ops.gemm(ctx.reshape(B * Lc, -1), w["text_embedder.fc_in.w"], w["text_embedder.fc_in.b"], epilogue=ops.EPI_GELU_TANH)
         c = ops.gemm(c, w["text_embedder.fc_out.w"], w["text_embedder.fc_out.b"])
-        ckv = ops.gemm(c, self.ckv_w, self.ckv_b)  # [B*Lc, L*2d]: every layer's text K and V
+        ckv = self._lin(c, {"ckv_w": getattr(self, "ckv_w", None), "ckv_q": getattr(self, "ckv_q", None), "ckv_s": getattr(self, "ckv_s", None)}, "ckv", self.ckv_b)  # [B*Lc, L*2d]: every layer's text K and V
 
         # AdaLN vectors for all layers at once: e = table + temb.float()  -> [L,B,6,d] fp32 (wanvideo.py:386-390)
         e = self.tables + tproj.float().unsqueeze(0)
@@ -183,7 +217,12 @@ class WanTransformer3DModelHip:
         x = x.reshape(B * Sl, d)
         for i, b in enumerate(self.blocks):
             nh = ops.ln_modulate(x, mul=mul_msa[i], add=shift_msa[i], eps=self.eps, rows_per_batch=Sl)
-            qkv = ops.gemm(nh, b["qkv_w"], b["qkv_b"])  # [B*Sl, 3d (+d gate)]
+            if self.quant and b["n_qkv"] == 4:
+                qkv = torch.empty((B * Sl, 4 * d), dtype=BF16, device=dev)
+                self._lin(nh, b, "qkv", b["qkv_b"], out=qkv[:, :3 * d])
+                ops.gemm(nh, b["gate_w"], b["gate_b"], out=qkv[:, 3 * d:])
+            else:
+                qkv = self._lin(nh, b, "qkv", b["qkv_b"])  # [B*Sl, 3d (+d gate)]; fp8: nh quantised once for q, k and v (wants_prequantized_input)
             nq = b["n_qkv"]
             attn = torch.empty((B * Sl, d), dtype=BF16, device=dev) if B > 1 else None
             for bi in range(B):
@@ -198,23 +237,23 @@ class WanTransformer3DModelHip:
                     attn = o
                 else:
                     attn[bi * Sl:(bi + 1) * Sl] = o
-            a_out = ops.gemm(attn, b["o_w"], b["o_b"])
+            a_out = self._lin(attn, b, "o", b["o_b"])
             nh, x = ops.ln_modulate(a_out, residual=x, gate=gate_msa[i], ln_w=b["ln2_w"], ln_b=b["ln2_b"], eps=self.eps,
                                     want_residual=True, rows_per_batch=Sl)
             if trace is not None:
                 trace[f"blocks.{i}.after_self_attn"] = x.view(B, Sl, d).clone()
             # cross attention over the text tokens (WanT2VCrossAttention, wanvideo.py:188-222)
-            cq = ops.gemm(nh, b["cq_w"], b["cq_b"])
+            cq = self._lin(nh, b, "cq", b["cq_b"])
             cq = ops.rmsnorm_rope([cq], [b["cnq_w"]], head_dim=D, seq_len=Sl, eps=self.eps)[0]
             kv = ckv[:, i * 2 * d:(i + 1) * 2 * d]
             ck = ops.rmsnorm_rope([kv[:, :d]], [b["cnk_w"]], head_dim=D, seq_len=Lc, eps=self.eps)[0]
             co = ops.attn_dense(cq.view(B, Sl, H, D), ck.view(B, Lc, H, D), kv[:, d:].view(B, Lc, H, D), scale=D**-0.5,
                                 layout="bshd")
-            c_out = ops.gemm(co.view(B * Sl, d), b["co_w"], b["co_b"])
+            c_out = self._lin(co.view(B * Sl, d), b, "co", b["co_b"])
             nh, x = ops.ln_modulate(c_out, residual=x, mul=mul_c[i], add=c_shift[i], eps=self.eps, round_residual=True,
                                     round_norm=True, want_residual=True, rows_per_batch=Sl)
-            f = ops.gemm(nh, b["f1_w"], b["f1_b"], epilogue=ops.EPI_GELU_TANH)
-            x = ops.gemm(f, b["f2_w"], b["f2_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=c_gate[i], rows_per_batch=Sl)
+            f = self._lin(nh, b, "f1", b["f1_b"], epilogue=ops.EPI_GELU_TANH)
+            x = self._lin(f, b, "f2", b["f2_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=c_gate[i], rows_per_batch=Sl)
             if trace is not None:
                 trace[f"blocks.{i}.out"] = x.view(B, Sl, d).clone()
 

@@ -98,6 +98,21 @@ int fvk_gemm_bf16(const void* x, const void* w, const void* bias, void* out, int
 int fvk_gemm_bf16_batched(const void* x, const void* w, void* out, int batch, int M, int N, int K, long lda, long ldc,
                           long x_bstride, long w_bstride, long out_bstride, int epilogue, float epi_scalar, void* stream);
 
+/* ------------------------------------------------------------------ fp8 (OCP e4m3fn) linear path (MFMA-bound GEMM, HBM-bound quantisation)
+ * ref: fastvideo/layers/quantization/fp8_config.py:55-68 (_quantize_tensorwise/_rowwise), :119-158 (FP8QuantizeMethod.apply),
+ *      :211-245 (convert_model_to_fp8 — the same arithmetic applied once to the weights).
+ * fvk_fp8_quantize_bf16:  absmax over the tensor (rowwise = 0) or per row (rowwise = 1: per token / per output channel);
+ *      scale = max(absmax / 448, 1/(448*512)) -> scale[1] or scale[M] (fp32);
+ *      q = e4m3fn( clamp( bf16( float(x) / float(bf16(scale)) ), -448, 448 ) ) -> q [M, K] bytes (row stride K).
+ *      absmax_scratch: device fp32 [1] or [M] (overwritten).  K, lda multiples of 8.
+ * fvk_gemm_fp8:  out = epilogue( bf16( bf16( (x_fp8 · w_fp8^T)_fp32 * scale_a * scale_b ) + bias ) )  — the two roundings of
+ *      torch._scaled_mm(out_dtype=bf16) followed by `out + bias`; epilogues as fvk_gemm_bf16 (NONE, GELU_TANH, SILU, RESIDUAL_GATE).
+ *      x_fp8 [M,K], w_fp8 [N,K] e4m3 bytes, K % 64 == 0; scale_a [1] or [M] (a_rowwise), scale_b [1] or [N] (b_rowwise). */
+int fvk_fp8_quantize_bf16(const void* x, void* q, float* scale, float* absmax_scratch, int M, int K, long lda, int rowwise, void* stream);
+int fvk_gemm_fp8(const void* x_fp8, const void* w_fp8, const float* scale_a, const float* scale_b, const void* bias, void* out, int M, int N,
+                 int K, long ldc, int a_rowwise, int b_rowwise, int epilogue, const void* residual, const float* gate, int rows_per_batch,
+                 void* stream);
+
 /* ------------------------------------------------------------------ attention (MFMA-bound)
  * Flash-style forward, head_dim 128, non-causal, fp32 online softmax in the exp2 domain, P rounded to bf16
  * before P·V (ref numerics: block_sparse_attn_triton.py:124-158; st_attn_triton.py:60-89).

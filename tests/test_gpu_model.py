@@ -73,3 +73,23 @@ def test_wan_tiny_vsa_matches_oracle(tiny):
 def test_smoke_entry():
     import __graft_entry__ as G
     G.smoke()
+
+
+@pytest.mark.parametrize("quant", ["fp8", "fp8_channel"])
+def test_wan_tiny_fp8_matches_oracle(tiny, quant):
+    """fp8 linear path inside the full model (FP8Config granularity tensor / channel, fastvideo/layers/quantization/fp8_config.py)
+    vs the oracle with the same quantisation.  Same tolerance as the bf16 forward; the quantised bytes themselves are bit-exact
+    (tests/test_gpu_fp8.py), so differences come from accumulation order only."""
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    case = tiny["cases"][1]
+    H = tiny["config"]["num_heads"]
+    orc = W.WanOracle(tiny["state_dict"], num_heads=H, quantization=quant)
+    with torch.no_grad():
+        ref = orc.forward(case["latent"], case["ctx"], case["timestep"])
+    base = W.WanOracle(tiny["state_dict"], num_heads=H).forward(case["latent"], case["ctx"], case["timestep"])
+    model = WanTransformer3DModelHip(tiny["state_dict"], num_heads=H, quantization=quant)
+    y = model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda())
+    _cmp(y, ref, f"{quant} output", mean_tol=2e-2)
+    # the quantised forward must differ from the bf16 one (i.e. the fp8 path really ran) but stay close to it
+    d_q = (ref.float() - base.float()).abs().mean().item()
+    assert 0 < d_q < 0.1 * base.float().abs().mean().item() + 5e-2
