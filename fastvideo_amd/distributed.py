@@ -143,3 +143,83 @@ class SequenceParallel:
         q_blk, k_all, v_all = self.scatter_heads_gather_seq(q, k, v)
         o_blk = attn_fn(q_blk, k_all, v_all, S)
         return self.scatter_seq_gather_heads(o_blk, Sl)
+
+
+class Mi355xCommunicator:
+    """Inference-side drop-in for the reference's ``DeviceCommunicatorBase`` (fastvideo/distributed/device_communicators/
+    base_device_communicator.py:196-277; returned by ``Platform.get_device_communicator_cls()``, platforms/rocm.py:114-116): same
+    constructor and the same ``all_reduce / all_gather(dim) / slice(dim) / all_to_all_4D(scatter_dim, gather_dim) / gather / send /
+    recv / destroy`` methods with the same results, on RCCL (backend "nccl" on ROCm) or gloo.
+
+    ``all_to_all_4D`` keeps the reference's two modes (``:147-183``) but packs with ONE permuted copy per side instead of
+    ``transpose().contiguous()`` + ``cat`` + ``transpose().contiguous()``: per-peer messages are contiguous [bs, s, hn/P, hd] blocks,
+    which on xGMI's point-to-point mesh travel on P-1 links in parallel.  No autograd (the denoising path runs under no_grad)."""
+
+    def __init__(self, cpu_group, device=None, device_group=None, unique_name: str = ""):
+        self.device = device or torch.device("cpu")
+        self.cpu_group, self.device_group, self.unique_name = cpu_group, device_group or cpu_group, unique_name
+        self.rank = dist.get_rank(cpu_group)
+        self.world_size = dist.get_world_size(cpu_group)
+        self.ranks = dist.get_process_group_ranks(cpu_group)
+        self.global_rank, self.global_world_size = dist.get_rank(), dist.get_world_size()
+        self.rank_in_group = dist.get_group_rank(cpu_group, self.global_rank)
+
+    def all_reduce(self, input_, op=dist.ReduceOp.SUM):
+        out = input_.clone()
+        if self.world_size > 1:
+            dist.all_reduce(out, op=op, group=self.device_group)
+        return out
+
+    def all_gather(self, input_, dim: int = -1):
+        if self.world_size == 1:
+            return input_
+        dim = dim % input_.dim()
+        x = input_.movedim(dim, 0).contiguous()
+        out = x.new_empty((self.world_size * x.shape[0], *x.shape[1:]))
+        dist.all_gather_into_tensor(out, x, group=self.device_group)
+        return out.movedim(0, dim).contiguous()
+
+    def slice(self, input_, dim: int = -1, *, scale_grad: bool = False):
+        if self.world_size == 1:
+            return input_.contiguous()
+        dim = dim % input_.dim()
+        n = input_.shape[dim] // self.world_size
+        return input_.narrow(dim, self.rank_in_group * n, n).contiguous()
+
+    def all_to_all_4D(self, input_, scatter_dim: int = 2, gather_dim: int = 1):
+        P = self.world_size
+        if P == 1:
+            return input_
+        if input_.dim() != 4:
+            raise AssertionError(f"input must be 4D tensor, got {input_.dim()} and shape {input_.shape}")
+        if scatter_dim == 2 and gather_dim == 1:      # [bs, s/P, hn, hd] -> [bs, s, hn/P, hd]
+            bs, s, hn, hd = input_.shape
+            send = input_.reshape(bs, s, P, hn // P, hd).permute(2, 0, 1, 3, 4).contiguous()   # [P(dst), bs, s, hn/P, hd]
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=self.device_group)                        # [P(src = seq shard), ...]
+            return recv.permute(1, 0, 2, 3, 4).reshape(bs, P * s, hn // P, hd)
+        if scatter_dim == 1 and gather_dim == 2:      # [bs, s, hn/P, hd] -> [bs, s/P, hn, hd]
+            bs, s, shn, hd = input_.shape
+            send = input_.reshape(bs, P, s // P, shn, hd).permute(1, 0, 2, 3, 4).contiguous()  # [P(dst = seq shard), bs, s/P, shn, hd]
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=self.device_group)                        # [P(src = head group), ...]
+            return recv.permute(1, 2, 0, 3, 4).reshape(bs, s // P, P * shn, hd)
+        raise RuntimeError(f"Invalid scatter_dim={scatter_dim}, gather_dim={gather_dim}. "
+                           f"Only (scatter_dim=2, gather_dim=1) and (scatter_dim=1, gather_dim=2) are supported.")
+
+    def gather(self, input_, dst: int = 0, dim: int = -1):
+        dim = dim % input_.dim()
+        lst = [torch.empty_like(input_) for _ in range(self.world_size)] if self.rank_in_group == dst else None
+        dist.gather(input_, lst, dst=self.ranks[dst], group=self.device_group)
+        return torch.cat(lst, dim=dim) if self.rank_in_group == dst else None
+
+    def send(self, tensor, dst: int | None = None) -> None:
+        dist.send(tensor, self.ranks[(self.rank_in_group + 1) % self.world_size if dst is None else dst], self.device_group)
+
+    def recv(self, size, dtype, src: int | None = None):
+        t = torch.empty(size, dtype=dtype, device=self.device)
+        dist.recv(t, self.ranks[(self.rank_in_group - 1) % self.world_size if src is None else src], self.device_group)
+        return t
+
+    def destroy(self) -> None:
+        pass

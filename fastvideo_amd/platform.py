@@ -33,3 +33,8 @@ class Mi355xPlatformMixin:
     @classmethod
     def get_attn_backend_cls(cls, selected_backend, head_size: int, dtype) -> str:
         return get_attn_backend_cls(selected_backend, head_size, dtype)
+
+    @classmethod
+    def get_device_communicator_cls(cls) -> str:
+        """ref: Platform.get_device_communicator_cls (fastvideo/platforms/interface.py:240-245, rocm.py:114-116)."""
+        return "fastvideo_amd.distributed.Mi355xCommunicator"
