@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--attention", default="dense", choices=["dense", "vsa"])
+    ap.add_argument("--attention", default="dense", choices=["dense", "vsa", "sta"])
     ap.add_argument("--quant", default=None, choices=["fp8", "fp8_channel"],
                     help="fp8 linear path (BASELINE config 5's GEMM dtype); the contract line is the default bf16 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -132,16 +132,25 @@ class SequenceParallel:
         recv = self._a2a(o_blk.contiguous(), o_in, o_out, L.G * Sl)      # [G(g), Sl, hg, D]
         return recv.reshape(L.G, Sl, hg, D).permute(1, 0, 2, 3).reshape(Sl, L.H, D).contiguous()
 
-    def attention(self, q, k, v, S: int, attn_fn):
+    def attention(self, q, k, v, S: int, attn_fn, extra=None):
         """Distributed self-attention for one batch element.
         q,k,v: [Sl, H, D] shards (already normed + rotated).  S = true (unpadded) global sequence length.
         attn_fn(q [Sq, h, D], k [Skv, h, D], v [Skv, h, D], kv_len) -> o [Sq, h, D]; keys >= kv_len are padding."""
         L = self.lay
         if L.P == 1:
-            return attn_fn(q, k, v, S)
+            return attn_fn(q, k, v, S) if extra is None else attn_fn(q, k, v, S, extra)
         Sl = q.shape[0]
         q_blk, k_all, v_all = self.scatter_heads_gather_seq(q, k, v)
-        o_blk = attn_fn(q_blk, k_all, v_all, S)
+        if extra is None:
+            o_blk = attn_fn(q_blk, k_all, v_all, S)
+        else:
+            # a fourth per-token, per-head tensor (the VSA compress gate, layer.py:172-245): it must cover the same rows as q,
+            # which only holds for plain Ulysses (U == 1: every rank sees all tokens of its head group)
+            if L.U != 1:
+                raise NotImplementedError("token-aligned extra tensors need U == 1 (num_heads divisible by the SP world size)")
+            hg, D = L.heads_per_group, extra.shape[-1]
+            e_all = self._a2a(extra.reshape(Sl, L.G, hg, D).permute(1, 0, 2, 3).reshape(L.P * Sl, hg, D), [Sl] * L.P, [Sl] * L.P, L.P * Sl)
+            o_blk = attn_fn(q_blk, k_all, v_all, S, e_all)
         return self.scatter_seq_gather_heads(o_blk, Sl)
 
 

@@ -53,8 +53,11 @@ class WanTransformer3DModelHip:
             raise ValueError(f"unknown quantization {quantization!r}")
         self.quant = quantization
         self.sp = SequenceParallel(num_heads, sp_group)
-        if attention != "dense" and self.sp.lay.P != 1:
-            raise NotImplementedError("sparse attention under sequence parallelism is wired in a later round")
+        if attention != "dense" and self.sp.lay.U != 1:
+            # tiling / block selection needs every token of a head on one rank: plain Ulysses only, like the reference, whose
+            # VSA path tiles after its all-to-all on the full sequence (fastvideo/attention/layer.py:228)
+            raise NotImplementedError(f"{attention} attention needs num_heads divisible by the SP world size "
+                                      f"(heads {num_heads}, world {self.sp.lay.P})")
         self.num_layers = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
         self._load(state_dict)
         self._vsa_cache = {}
@@ -138,6 +141,47 @@ class WanTransformer3DModelHip:
             self._vsa_cache[grid] = m
         return m
 
+    def _sta_meta(self, grid, n_heads):
+        """Tile permutation + per-(head, query block) KV block lists of the sliding-tile window.  Pure integer work on the host
+        (cached); every head of this model uses the same window ``self.sta_window`` (the reference API takes one per head)."""
+        key = (grid, n_heads)
+        m = self._vsa_cache.get(("sta",) + key)
+        if m is None:
+            import numpy as np
+            tt = self.sta_tile
+            tok = tt[0] * tt[1] * tt[2]
+            if tok % 64:
+                raise ValueError(f"sta tile {tt} must hold a multiple of 64 tokens")
+            h = ops.vsa_build_metadata_host(grid, tt)
+            nt = h["num_tiles"]
+            sub = tok // 64
+            vbs = h["variable_block_sizes"].numpy()
+            bsz = np.clip(vbs[:, None] - 64 * np.arange(sub)[None, :], 0, 64).astype(np.int32).reshape(-1)   # per 64-block
+            def win(q, n, k):  # clamped-centre window on one axis (support_flex_sta.py:44-51)
+                c = min(max(q, k // 2), (n - 1) - k // 2)
+                return range(max(c - k // 2, 0), min(c + k // 2 + 1, n))
+            lists = []
+            for a in range(nt[0]):
+                for b in range(nt[1]):
+                    for c in range(nt[2]):
+                        tiles = [(x * nt[1] + y) * nt[2] + z for x in win(a, nt[0], self.sta_window[0])
+                                 for y in win(b, nt[1], self.sta_window[1]) for z in win(c, nt[2], self.sta_window[2])]
+                        blocks = [t * sub + s_ for t in tiles for s_ in range(sub) if bsz[t * sub + s_] > 0]
+                        lists += [blocks] * sub
+            mx = max(len(l) for l in lists)
+            idx = np.zeros((len(lists), mx), dtype=np.int32)
+            num = np.zeros((len(lists),), dtype=np.int32)
+            for i, l in enumerate(lists):
+                idx[i, :len(l)], num[i] = l, len(l)
+            dev = self.device
+            m = dict(S_pad=len(vbs) * tok, perm=h["tile_partition_indices"].to(dev), non_pad=h["non_pad_index"].to(dev),
+                     untile=h["untile_combined_index"].to(dev), block_sizes=torch.from_numpy(bsz).to(dev),
+                     q2k_idx=torch.from_numpy(idx).to(dev)[None, None].expand(1, n_heads, -1, -1).contiguous(),
+                     q2k_num=torch.from_numpy(num).to(dev)[None, None].expand(1, n_heads, -1).contiguous(),
+                     density=float(sum(bsz[b] for l in lists for b in l)) * 64 / (float(grid[0] * grid[1] * grid[2])**2))
+            self._vsa_cache[("sta",) + key] = m
+        return m
+
     def _attn_local(self, q, k, v, kv_len, grid, gate=None):
         """q [Sq,h,D], k/v [Skv,h,D] (strided views ok) -> o [Sq,h,D] contiguous."""
         q4, k4, v4 = q.unsqueeze(0), k[:kv_len].unsqueeze(0), v[:kv_len].unsqueeze(0)
@@ -167,8 +211,19 @@ class WanTransformer3DModelHip:
             if q.shape[0] != S:
                 o = torch.cat([o, o.new_zeros((1, q.shape[0] - S, *o.shape[2:]))], 1)
             return o[0]
-        # sliding tile attention: tokens must be in tile-major order on a canvas padded to whole tiles
-        raise NotImplementedError("sta mode in the full model is wired in a later round (kernel: ops.attn_sta)")
+        # sliding-tile attention (ref kernel API: fastvideo_kernel.sliding_tile_attention, ops.py:21-62; mask semantics
+        # fastvideo-kernel/tests/support_flex_sta.py:29-59).  The token grid is padded to whole tiles; tokens are gathered tile-major
+        # with each tile's real tokens first, and the window rule is expressed as KV 64-blocks with variable sizes for the
+        # block-sparse kernel — which serves any canvas (the reference kernels hard-code three).
+        m = self._sta_meta(grid, q.shape[1])
+        S = kv_len
+        tile = lambda t: ops.gather_rows(t[:, :S].contiguous(), m["S_pad"], m["perm"], m["non_pad"], zero_init=True)  # [1,S_pad,h,D]
+        o = ops.attn_block_sparse(tile(q4), tile(k4), tile(v4), m["q2k_idx"], m["q2k_num"], m["block_sizes"], scale=self.D**-0.5,
+                                  layout="bshd")
+        o = ops.gather_rows(o, S, m["untile"], None)
+        if q.shape[0] != S:
+            o = torch.cat([o, o.new_zeros((1, q.shape[0] - S, *o.shape[2:]))], 1)
+        return o[0]
 
     def _lin(self, x, b, key, bias, **kw):
         """y = epilogue(x @ W^T + bias) through the bf16 GEMM or the fp8 path (dynamic activation quantisation + fp8 MFMA GEMM)."""
@@ -231,8 +286,8 @@ class WanTransformer3DModelHip:
                                         eps=self.eps, pos_offset=pos0)
                 v = rows[:, 2 * d:3 * d]
                 gate = rows[:, 3 * d:4 * d].view(Sl, H, D) if nq == 4 else None
-                fn = lambda q_, k_, v_, kv_len: self._attn_local(q_, k_, v_, kv_len, grid, gate)
-                o = sp.attention(q.view(Sl, H, D), k.view(Sl, H, D), v.view(Sl, H, D), S, fn).reshape(Sl, d)
+                fn = lambda q_, k_, v_, kv_len, g_=None: self._attn_local(q_, k_, v_, kv_len, grid, g_)
+                o = sp.attention(q.view(Sl, H, D), k.view(Sl, H, D), v.view(Sl, H, D), S, fn, extra=gate).reshape(Sl, d)
                 if B == 1:
                     attn = o
                 else:

@@ -239,3 +239,22 @@ def sta_mask(canvas_thw, kernel, tile_thw, text_length: int = 0, total_len: int 
     img2txt = q_img & (idx[None, :] >= img) & (idx[None, :] < img + text_length)
     txt2all = (idx[:, None] >= img) & (idx[None, :] < img + text_length)
     return (q_img & k_img & m) | img2txt | txt2all
+
+
+def sta_mask_ragged(grid_thw, kernel, tile_thw) -> torch.Tensor:
+    """Boolean [S,S] sliding-tile mask for a token grid that is NOT a whole number of tiles, tokens in RASTER order (t,h,w):
+    token i may attend token j iff j's tile lies in the clamped-centre window (sta_window, per axis, on the tile grid of the
+    canvas padded up to whole tiles) of i's tile; padding tokens do not exist.  For grids divisible by the tile this is sta_mask
+    after the tile permutation.  The reference has no kernel for such canvases (SURVEY.md F6: its kernels hard-code three canvases);
+    this is the natural extension that the 81f x 480p grid (21,30,52) with tile (6,8,8) needs (BASELINE config 3)."""
+    T, H, W = grid_thw
+    nt = tuple(-(-g // t) for g, t in zip(grid_thw, tile_thw))
+    t_idx = torch.arange(T).view(T, 1, 1).expand(T, H, W).reshape(-1) // tile_thw[0]
+    h_idx = torch.arange(H).view(1, H, 1).expand(T, H, W).reshape(-1) // tile_thw[1]
+    w_idx = torch.arange(W).view(1, 1, W).expand(T, H, W).reshape(-1) // tile_thw[2]
+    m = torch.ones((T * H * W, T * H * W), dtype=torch.bool)
+    for idx, n, k in ((t_idx, nt[0], kernel[0]), (h_idx, nt[1], kernel[1]), (w_idx, nt[2], kernel[2])):
+        win = torch.tensor([sta_window(q, n, k) for q in range(n)])      # [n, 2] = [start, end) per query tile coordinate
+        lo, hi = win[idx, 0], win[idx, 1]
+        m &= (idx[None, :] >= lo[:, None]) & (idx[None, :] < hi[:, None])
+    return m

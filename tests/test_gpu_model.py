@@ -93,3 +93,30 @@ def test_wan_tiny_fp8_matches_oracle(tiny, quant):
     # the quantised forward must differ from the bf16 one (i.e. the fp8 path really ran) but stay close to it
     d_q = (ref.float() - base.float()).abs().mean().item()
     assert 0 < d_q < 0.1 * base.float().abs().mean().item() + 5e-2
+
+
+@pytest.mark.parametrize("window", [(3, 3, 3), (1, 3, 1)])
+def test_wan_tiny_sta_matches_oracle(tiny, window):
+    """Sliding-tile attention inside the full model on a token grid that is not a whole number of tiles (the situation of
+    BASELINE config 3: grid (21,30,52), tile (6,8,8)); oracle = the same model with dense attention under the sliding-tile mask
+    (oracle/vsa_oracle.py sta_mask_ragged; window rule of fastvideo-kernel/tests/support_flex_sta.py:29-59)."""
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    from oracle import vsa_oracle as V
+    H = tiny["config"]["num_heads"]
+    g = torch.Generator().manual_seed(11)
+    latent = torch.randn((1, 16, 7, 18, 34), generator=g).bfloat16()     # token grid (7, 9, 17) = 1071 tokens; tile (2,4,8): 4 x 3 x 3 tiles, all ragged
+    ctx, ts = tiny["cases"][0]["ctx"], tiny["cases"][0]["timestep"]
+    grid, tile = (7, 9, 17), (2, 4, 8)
+    mask = V.sta_mask_ragged(grid, window, tile)
+    assert not mask.all() and mask.any(dim=1).all()
+
+    def sta_attention(q, k, v, scale):   # [B,S,H,D]
+        return W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), scale, mask).transpose(1, 2).to(q.dtype)
+
+    orc = W.WanOracle(tiny["state_dict"], num_heads=H)
+    orc.attention = sta_attention
+    with torch.no_grad():
+        ref = orc.forward(latent, ctx, ts)
+    model = WanTransformer3DModelHip(tiny["state_dict"], num_heads=H, attention="sta", sta_window=window, sta_tile=tile)
+    y = model(latent.cuda(), ctx.cuda(), ts.cuda())
+    _cmp(y, ref, f"sta {window} output", mean_tol=2e-2)

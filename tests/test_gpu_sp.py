@@ -31,6 +31,7 @@ def _worker(rank, world, port, fx_path, out_q):
             outs.append(model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda()).cpu())
         if rank == 0:
             out_q.put((outs, (model.sp.lay.G, model.sp.lay.U)))
+            out_q.close(); out_q.join_thread()  # flush before teardown: a crash in runtime shutdown must not truncate the message
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -60,3 +61,53 @@ def test_sp_forward_equals_sp1(world, golden_dir):
         assert torch.equal(o, r), f"SP={world}: max diff {(o.float() - r.float()).abs().max().item()}"
         err = (o.float() - c["out"].float()).abs()
         assert err.max().item() < 0.1
+
+
+def _worker_sparse(rank, world, port, fx_path, mode, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = _sparse_forward(fx_path, mode)
+        if rank == 0:
+            out_q.put(out)
+            out_q.close(); out_q.join_thread()
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _sparse_forward(fx_path, mode):
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    fx = torch.load(fx_path, weights_only=False)
+    sd = dict(fx["state_dict"])
+    d = fx["config"]["num_heads"] * 128
+    g = torch.Generator().manual_seed(5)
+    for i in range(fx["config"]["num_layers"]):  # VSA compress gate weights (absent from the fixture)
+        sd[f"blocks.{i}.to_gate_compress.weight"] = (torch.randn((d, d), generator=g) * d**-0.5).bfloat16()
+        sd[f"blocks.{i}.to_gate_compress.bias"] = (torch.randn((d,), generator=g) * 0.02).bfloat16()
+    kw = dict(attention="vsa", vsa_sparsity=0.5) if mode == "vsa" else dict(attention="sta", sta_window=(1, 3, 1), sta_tile=(2, 4, 8))
+    model = WanTransformer3DModelHip(sd, num_heads=fx["config"]["num_heads"], device="cuda:0", **kw)
+    lat = torch.randn((1, 16, 7, 18, 34), generator=torch.Generator().manual_seed(11)).bfloat16()
+    c = fx["cases"][0]
+    return model(lat.cuda(), c["ctx"].cuda(), c["timestep"].cuda()).cpu()
+
+
+@pytest.mark.parametrize("mode", ["vsa", "sta"])
+def test_sp2_sparse_attention_equals_sp1(mode, golden_dir):
+    """VSA (with its compress gate travelling through the exchange) and sliding-tile attention under plain Ulysses SP=2 == SP=1."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    fx_path = os.path.join(golden_dir, "wan_tiny.pt")
+    ref = _sparse_forward(fx_path, mode)
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sparse, args=(r, 2, port, fx_path, mode, out_q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = out_q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.isfinite(out.float()).all()
+    assert torch.equal(out, ref), f"{mode} SP=2: max diff {(out.float() - ref.float()).abs().max().item()}"
