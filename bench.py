@@ -141,10 +141,23 @@ def main():
     # roofline of the dominant kernel (dense self-attention): algorithmic FLOPs per launch / mean launch duration
     attn_ms = [e0.elapsed_time(e1) for e0, e1, *_ in events]
     _, _, Sq, Skv, h = events[0]
-    flops_launch = 4.0 * Sq * Skv * h * cfg.head_dim
     mean_ms = sum(attn_ms) / len(attn_ms)
+    if args.attention == "dense":
+        flops_launch = 4.0 * Sq * Skv * h * cfg.head_dim
+        kname = "attn_pp2_kernel (dense self-attention, 8-wave ping-pong, 128-key tiles)"
+    else:
+        # sparse modes: the algorithmic work is the selected fraction of the dense score matrix (VSA: top-k of the 64-token blocks
+        # + the coarse branch, negligible; STA: the window's share of key tokens); the timed region is the whole attention
+        # (tile gather + coarse stage + block-sparse kernel + untile)
+        if args.attention == "vsa":
+            m = next(iter(v for k_, v in model._vsa_cache.items() if not (isinstance(k_, tuple) and k_ and k_[0] == "sta")))
+            dens = m["topk"] / m["variable_block_sizes"].numel() * (m["S_pad"] / Skv)**2
+        else:
+            dens = next(iter(v for k_, v in model._vsa_cache.items() if isinstance(k_, tuple) and k_ and k_[0] == "sta"))["density"]
+        flops_launch = 4.0 * Sq * Skv * h * cfg.head_dim * dens
+        kname = f"{args.attention} self-attention (gather + attn_fwd_kernel block-sparse + untile), density {dens:.3f} of dense"
     achieved = flops_launch / (mean_ms * 1e-3) / 1e12
-    roof = dict(bound="mfma", kernel="attn_pp2_kernel (dense self-attention, 8-wave ping-pong, 128-key tiles)", achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS,
+    roof = dict(bound="mfma", kernel=kname, achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS,
                 unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
                 flops_per_launch=flops_launch, mean_launch_ms=round(mean_ms, 4), launches=len(attn_ms),
                 share_of_step=round(sum(attn_ms) / args.steps / (elapsed / args.steps * 1e3), 3))

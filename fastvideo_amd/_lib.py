@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfvk_amd.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -36,7 +36,7 @@ SIGNATURES = {
     "fvk_gemm_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i32, vp, vp, i32, vp],
     "fvk_gemm_bf16_batched": [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i64, i32, f32, vp],
     "fvk_attn_dense_bf16": [C.POINTER(AttnArgs), vp],
-    "fvk_attn_block_sparse_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, vp],
+    "fvk_attn_block_sparse_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp],
     "fvk_attn_sta_bf16": [C.POINTER(AttnArgs), i32, i32, i32, i32, C.POINTER(C.c_int32), vp],
     "fvk_vsa_build_metadata_host": [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "fvk_gather_rows_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, vp],

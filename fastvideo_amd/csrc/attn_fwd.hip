@@ -351,17 +351,21 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
 }
 
 extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
-                                          const int32_t* kv_block_sizes, int max_kv, void* stream) {
+                                          const int32_t* kv_block_sizes, int max_kv, int q_block, void* stream) {
     int rc = check_common(a, "fvk_attn_block_sparse_bf16");
     if (rc) return rc;
     FVK_CHECK(q2k_idx && q2k_num && kv_block_sizes && max_kv > 0, FVK_ERR_ARG, "fvk_attn_block_sparse_bf16: null index arrays");
-    FVK_CHECK(a->Sq % 64 == 0 && a->Skv % 64 == 0, FVK_ERR_ARG,
-              "fvk_attn_block_sparse_bf16: Sq=%d and Skv=%d must be multiples of the 64-token block", a->Sq, a->Skv);
+    FVK_CHECK(q_block == 64 || q_block == 128, FVK_ERR_ARG, "fvk_attn_block_sparse_bf16: q_block=%d (64 or 128 query rows per list)", q_block);
+    FVK_CHECK(a->Sq % q_block == 0 && a->Skv % 64 == 0, FVK_ERR_ARG,
+              "fvk_attn_block_sparse_bf16: Sq=%d must be a multiple of q_block=%d and Skv=%d of the 64-token KV block", a->Sq, q_block, a->Skv);
     ModeArgs ma{};
     ma.q2k_idx = q2k_idx;
     ma.q2k_num = q2k_num;
     ma.kv_block_sizes = kv_block_sizes;
     ma.max_kv = max_kv;
+    // one workgroup per list: 2 waves (64 rows, the VSA block) or 4 waves (128 rows sharing every K/V tile: sliding-tile windows,
+    // where all query blocks of a tile attend the same KV blocks)
+    if (q_block == 128) return launch<4, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
     return launch<2, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
 }
 

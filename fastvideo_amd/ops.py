@@ -253,7 +253,7 @@ def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None):
     return o
 
 
-def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, layout="bhsd", return_lse=False):
+def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, layout="bhsd", return_lse=False, q_block=64):
     scale = q.shape[-1]**-0.5 if scale is None else scale
     vt = _vt_of(v, layout)
     o = torch.empty_like(q)
@@ -264,7 +264,7 @@ def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, lay
     q2k_idx = _chk(q2k_idx, torch.int32, "q2k_idx").contiguous()
     q2k_num = _chk(q2k_num, torch.int32, "q2k_num").contiguous()
     kv_block_sizes = _chk(kv_block_sizes, torch.int32, "kv_block_sizes").contiguous()
-    _lib.call("fvk_attn_block_sparse_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), q2k_idx.shape[-1], _stream())
+    _lib.call("fvk_attn_block_sparse_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), q2k_idx.shape[-1], int(q_block), _stream())
     return (o, lse) if return_lse else o
 
 

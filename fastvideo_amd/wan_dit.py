@@ -152,6 +152,7 @@ class WanTransformer3DModelHip:
             tok = tt[0] * tt[1] * tt[2]
             if tok % 64:
                 raise ValueError(f"sta tile {tt} must hold a multiple of 64 tokens")
+            qb = 128 if tok % 128 == 0 else 64  # query rows per block list: every query block of a tile shares the tile's window
             h = ops.vsa_build_metadata_host(grid, tt)
             nt = h["num_tiles"]
             sub = tok // 64
@@ -167,7 +168,7 @@ class WanTransformer3DModelHip:
                         tiles = [(x * nt[1] + y) * nt[2] + z for x in win(a, nt[0], self.sta_window[0])
                                  for y in win(b, nt[1], self.sta_window[1]) for z in win(c, nt[2], self.sta_window[2])]
                         blocks = [t * sub + s_ for t in tiles for s_ in range(sub) if bsz[t * sub + s_] > 0]
-                        lists += [blocks] * sub
+                        lists += [blocks] * (tok // qb)
             mx = max(len(l) for l in lists)
             idx = np.zeros((len(lists), mx), dtype=np.int32)
             num = np.zeros((len(lists),), dtype=np.int32)
@@ -178,11 +179,22 @@ class WanTransformer3DModelHip:
                      untile=h["untile_combined_index"].to(dev), block_sizes=torch.from_numpy(bsz).to(dev),
                      q2k_idx=torch.from_numpy(idx).to(dev)[None, None].expand(1, n_heads, -1, -1).contiguous(),
                      q2k_num=torch.from_numpy(num).to(dev)[None, None].expand(1, n_heads, -1).contiguous(),
-                     density=float(sum(bsz[b] for l in lists for b in l)) * 64 / (float(grid[0] * grid[1] * grid[2])**2))
+                     q_block=qb, density=float(sum(bsz[b] for l in lists for b in l)) * qb / (float(grid[0] * grid[1] * grid[2])**2))
             self._vsa_cache[("sta",) + key] = m
         return m
 
     def _attn_local(self, q, k, v, kv_len, grid, gate=None):
+        if self.attn_events is None or self.attention == "dense":
+            return self._attn_local_impl(q, k, v, kv_len, grid, gate)
+        # bench.py roofline leg for the sparse modes: HIP events around the whole attention (tile + kernels + untile)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        o = self._attn_local_impl(q, k, v, kv_len, grid, gate)
+        e1.record()
+        self.attn_events.append((e0, e1, kv_len, kv_len, q.shape[1]))
+        return o
+
+    def _attn_local_impl(self, q, k, v, kv_len, grid, gate=None):
         """q [Sq,h,D], k/v [Skv,h,D] (strided views ok) -> o [Sq,h,D] contiguous."""
         q4, k4, v4 = q.unsqueeze(0), k[:kv_len].unsqueeze(0), v[:kv_len].unsqueeze(0)
         if self.attention == "dense":
@@ -219,7 +231,7 @@ class WanTransformer3DModelHip:
         S = kv_len
         tile = lambda t: ops.gather_rows(t[:, :S].contiguous(), m["S_pad"], m["perm"], m["non_pad"], zero_init=True)  # [1,S_pad,h,D]
         o = ops.attn_block_sparse(tile(q4), tile(k4), tile(v4), m["q2k_idx"], m["q2k_num"], m["block_sizes"], scale=self.D**-0.5,
-                                  layout="bshd")
+                                  layout="bshd", q_block=m["q_block"])
         o = ops.gather_rows(o, S, m["untile"], None)
         if q.shape[0] != S:
             o = torch.cat([o, o.new_zeros((1, q.shape[0] - S, *o.shape[2:]))], 1)

@@ -134,12 +134,12 @@ typedef struct {
 /* dense: ref fastvideo/attention/backends/sdpa.py:122-147 / flash_attn.py:247-345 (the path replaced). */
 int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream);
 
-/* block-sparse (VSA sparse branch): query block i (64 rows) attends KV blocks q2k_idx[b,h,i,0..q2k_num[b,h,i])
- * (64 keys each, of which the first kv_block_sizes[j] are valid).  ref: fastvideo-kernel/csrc/attention/
- * block_sparse_h100.cu:66-272, triton_kernels/block_sparse_attn_triton.py:32-160.
- * q2k_idx int32 [B,H,Nq,max_kv], q2k_num int32 [B,H,Nq], kv_block_sizes int32 [Nkv]. Sq, Skv multiples of 64. */
+/* block-sparse (VSA sparse branch; sliding-tile windows on arbitrary canvases): query block i (q_block = 64 or 128 rows) attends KV
+ * blocks q2k_idx[b,h,i,0..q2k_num[b,h,i]) (64 keys each, of which the first kv_block_sizes[j] are valid).
+ * ref: fastvideo-kernel/csrc/attention/block_sparse_h100.cu:66-272, triton_kernels/block_sparse_attn_triton.py:32-160.
+ * q2k_idx int32 [B,H,Nq,max_kv], q2k_num int32 [B,H,Nq] with Nq = Sq / q_block, kv_block_sizes int32 [Nkv]. Skv multiple of 64. */
 int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
-                               const int32_t* kv_block_sizes, int max_kv, void* stream);
+                               const int32_t* kv_block_sizes, int max_kv, int q_block, void* stream);
 
 /* sliding-tile attention: tokens in tile-major order, tile = tile_t*tile_h*tile_w tokens (multiple of 64),
  * canvas of (ct,ch,cw) tiles; head h uses window (win[3h], win[3h+1], win[3h+2]) tiles with the clamped
