@@ -52,8 +52,12 @@ template <int DK> struct KGeom {
     static constexpr int STAGE_BYTES = TILE_BYTES + V_TILE_BYTES;
 };
 
-template <int NW, int MODE, int DK>
-__global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fvk_attn_args a, ModeArgs ma) {
+// NL = dedicated LOADER waves (0 = every wave issues its share of the LDS-DMA).  With 64-row query blocks (VSA) a workgroup has only
+// two compute waves, and 35 DMA wave-instructions per KV tile at ~60 cycles of issue each cost them more than the tile's MFMAs;
+// NL = 2 moves the whole tile stream to two extra waves that do nothing else (producer / consumer specialisation), synchronised by
+// the same one barrier per tile.
+template <int NW, int MODE, int DK, int NL>
+__global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 2 ? 1 : 2)) void attn_fwd_kernel(fvk_attn_args a, ModeArgs ma) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the body uses gfx950 LDS-DMA builtins the host pass cannot parse
     constexpr int K_ROW_BYTES = KGeom<DK>::ROW_BYTES, KC = KGeom<DK>::CHUNKS, K_TILE_BYTES = KGeom<DK>::TILE_BYTES;
     constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES, KS = DK / 16;
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
     };
 
     // ---- Q fragments (B operand): row q0 + l31, d = 16*ks + 8*hi .. +8 -----------------------------------
-    const int q0 = qb * BMQ + wave * 32;
+    const int q0 = qb * BMQ + (wave < NW ? wave : 0) * 32;  // (loader waves own no rows)
     int qrow = q0 + l31;
     const bool q_ok = qrow < a.Sq;
     qrow = q_ok ? qrow : a.Sq - 1;
@@ -146,11 +150,15 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)kp, 0, (int)((((long)a.Skv - 1) * a.k_ss + DK) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vtp, 0, (int)(256L * a.Skv_pad), 0x00020000);
-    constexpr int N_DMA = (KC + 18 + NW - 1) / NW;  // wave-instructions per wave per tile
+    constexpr int NI = NL ? NL : NW;                // waves that issue DMA
+    constexpr int N_DMA = (KC + 18 + NI - 1) / NI;  // wave-instructions per issuing wave per tile
+    const bool loader = NL ? wave >= NW : true;     // this wave issues DMA
+    const bool compute = wave < NW;                 // this wave owns 32 query rows
+    const int iw = NL ? wave - NW : wave;           // index among the issuing waves
     int dma_voff[N_DMA];
 #pragma unroll
     for (int i = 0; i < N_DMA; ++i) {
-        const int t = i * NW + wave;  // wave-instruction index within the stage
+        const int t = i * NI + iw;  // wave-instruction index within the stage
         if (t < KC) {
             const int g = t * 64 + lane;
             const int kr = g / KC, kc = g % KC;
@@ -173,6 +181,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
     const float c2 = a.scale * 1.4426950408889634f;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     typedef __attribute__((address_space(3))) void lds_void;
 #define ISSUE_DMA(KV0, ST)                                                                                   \
@@ -180,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
         const int ks_ = __builtin_amdgcn_readfirstlane((KV0) * k_tile_stride);                               \
         const int vs_ = __builtin_amdgcn_readfirstlane((KV0) * 2);                                           \
         _Pragma("unroll") for (int i = 0; i < N_DMA; ++i) {                                                  \
-            const int t_ = i * NW + wave;                                                                    \
+            const int t_ = i * NI + iw;                                                                      \
             if (t_ < KC) {                                                                                   \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)((ST) + t_ * 1024), 16, dma_voff[i], ks_, 0, 0); \
             } else if (t_ < KC + 18) {                                                                          \
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
     int kv0 = 0, valid = 64, kv0_n = 0, valid_n = 64;
     if (n_tiles > 0) {
         get_tile(0, kv0, valid);
-        ISSUE_DMA(kv0, smem)
+        if (loader) ISSUE_DMA(kv0, smem)
     }
     __syncthreads();
 
@@ -202,25 +211,40 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
         if (more) {
             get_tile(j + 1, kv0_n, valid_n);
             unsigned char* nxt = smem + ((j + 1) & 1) * STAGE_BYTES;
-            ISSUE_DMA(kv0_n, nxt)
+            if (loader) ISSUE_DMA(kv0_n, nxt)
         }
-        // ---- S^T = K · Q^T  (2 key blocks of 32 x 8 k-steps of 16) --------------------------------------
+        if (compute) {
+        // ---- S^T = K · Q^T  (2 key blocks of 32 x KS k-steps of 16): one software-pipelined stream, every ds_read_b128 issued FD MFMAs
+        // ahead of its use (sched_group_barrier pins the 1 MFMA : 1 read interleave; left alone hipcc emits read / wait / MFMA and
+        // every MFMA eats an LDS round trip) --------------------------------------------------------------------------------------
         f32x16 s[2];
+        constexpr int FD = 4;
+        {
+            bf16x8 fr[FD];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int i = 0; i < FD; ++i)
+                fr[i] = *reinterpret_cast<const bf16x8*>(cur + k_rbase + ((i & 1) * 32 * K_ROW_BYTES + (i >> 1) * 32));
+            __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(cur + k_rbase + (kb * 32 * K_ROW_BYTES + ks * 32));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[kb], 0, 0, 0);
+            for (int i = 0; i < 2 * KS; ++i) {
+                const int kb = i & 1, ks = i >> 1;
+                if (ks == 0) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % FD], qf[0], zero16, 0, 0, 0);
+                else s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i % FD], qf[ks], s[kb], 0, 0, 0);
+                const int n_ = i + FD;
+                if (n_ < 2 * KS)
+                    fr[n_ % FD] = *reinterpret_cast<const bf16x8*>(cur + k_rbase + ((n_ & 1) * 32 * K_ROW_BYTES + (n_ >> 1) * 32));
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (n_ < 2 * KS) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            __builtin_amdgcn_s_setprio(0);
         }
-        __builtin_amdgcn_s_setprio(0);
-        // ---- online softmax (row q = lane&31; this lane holds 32 of its 64 scores) ------------------------
+        // first V^T fragments: issued now, they land under the softmax
+        bf16x8 vr[FD];
+#pragma unroll
+        for (int i = 0; i < FD; ++i)
+            vr[i] = *reinterpret_cast<const bf16x8*>(cur + v_rbase + ((i & 3) * 32 * V_ROW_BYTES + (i >> 2) * 32));
+        // ---- online softmax (row q = lane&31; this lane holds 32 of its 64 scores, lane^32 the other 32) ------------------------
         if (valid < 64) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -230,56 +254,72 @@ __global__ __launch_bounds__(NW * 64, (NW == 2 ? 1 : 2)) void attn_fwd_kernel(fv
                     if (key >= valid) s[kb][r] = -INFINITY;
                 }
         }
-        float mx = s[0][0];
+        float mx4[4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int c = 0; c < 4; ++c) {
+            mx4[c] = fmaxf(s[c >> 1][(c & 1) * 8], s[c >> 1][(c & 1) * 8 + 1]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int r = 2; r < 8; r += 2) mx4[c] = fmaxf(fmaxf(mx4[c], s[c >> 1][(c & 1) * 8 + r]), s[c >> 1][(c & 1) * 8 + r + 1]);
+        }
+        float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+        {
+            const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1]));
+        }
         const float m_new = fmaxf(m_run, mx);
         if (!__all(m_new == m_run)) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+            asm volatile("s_nop 1" : "+v"(alpha));  // trans-op result -> VALU read wait state (hipcc pads nothing for inline asm)
             l_run *= alpha;
+            // single-issue v_mul_f32: hipcc SLP-packs these into v_pk_mul_f32, which crawls beside another wave's MFMAs (attn_pp2.hip)
 #pragma unroll
             for (int d = 0; d < 4; ++d)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                for (int r = 0; r < 16; ++r) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(o[d][r]) : "v"(alpha));
             m_run = m_new;
         }
         const float mc = m_run * c2;
-        float psum = 0.f;
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -mc));
                 s[kb][r] = p;
-                psum += p;
+                ps4[r & 3] += p;
             }
-        l_run += psum;
-        // ---- O^T += V^T · P^T  (4 d-blocks of 32 x 4 k-steps of 16 keys) ---------------------------------
+        l_run += (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+        bf16x8 pf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) pf[kk][jj] = (bf16_t)s[kk >> 1][(kk & 1) * 8 + jj];
+        // ---- O^T += V^T · P^T  (4 k-steps of 16 keys x 4 d-blocks of 32), same pipelined stream ------------------------------------
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 pf;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) pf[jj] = (bf16_t)s[kk >> 1][(kk & 1) * 8 + jj];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(cur + v_rbase + (d * 32 * V_ROW_BYTES + kk * 32));
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[d], 0, 0, 0);
-            }
+        for (int i = 0; i < 16; ++i) {
+            o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr[i % FD], pf[i >> 2], o[i & 3], 0, 0, 0);
+            const int n_ = i + FD;
+            if (n_ < 16) vr[n_ % FD] = *reinterpret_cast<const bf16x8*>(cur + v_rbase + ((n_ & 3) * 32 * V_ROW_BYTES + (n_ >> 2) * 32));
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            if (n_ < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
         }
         __builtin_amdgcn_s_setprio(0);
+        }  // compute
         if (more) {
             kv0 = kv0_n;
             valid = valid_n;
         }
         __syncthreads();
     }
+    if (!compute) return;
 
     // ---- epilogue ---------------------------------------------------------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    float l_tot;
+    {
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+        l_tot = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);
+    }
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (q_ok) {
         bf16_t* orow = op + (long)qrow * a.o_ss;
@@ -309,12 +349,12 @@ int check_common(const fvk_attn_args* a, const char* fn) {
     return FVK_OK;
 }
 
-template <int NW, int MODE, int DK = 128>
+template <int NW, int MODE, int DK = 128, int NL = 0>
 int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
     constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE, DK>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE, DK, NL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 2 * STAGE_BYTES) != hipSuccess) {
             fvk_set_error("fvk_attn: cannot set dynamic LDS size");
             return FVK_ERR_LAUNCH;
@@ -323,7 +363,7 @@ int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
     }
     const int bmq = NW * 32;
     const long nblk = (long)((a->Sq + bmq - 1) / bmq) * a->H * a->B;
-    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE, DK>), dim3((unsigned)nblk), dim3(NW * 64), 2 * STAGE_BYTES, s, *a, ma);
+    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE, DK, NL>), dim3((unsigned)nblk), dim3((NW + NL) * 64), 2 * STAGE_BYTES, s, *a, ma);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -366,7 +406,7 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     // one workgroup per list: 2 waves (64 rows, the VSA block) or 4 waves (128 rows sharing every K/V tile: sliding-tile windows,
     // where all query blocks of a tile attend the same KV blocks)
     if (q_block == 128) return launch<4, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
-    return launch<2, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
+    return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);  // 2 compute + 2 loader waves
 }
 
 extern "C" int fvk_attn_sta_bf16(const fvk_attn_args* a, int ct, int ch, int cw, int tile_tokens, const int32_t* win_host,
