@@ -1,0 +1,137 @@
+"""Denoising-step tail on MI355X: classifier-free-guidance combine + FlowUniPC multistep scheduler step
+(fastvideo/pipelines/stages/denoising.py:575-596 -> FlowUniPCMultistepScheduler.step,
+fastvideo/models/schedulers/scheduling_flow_unipc_multistep.py:649-724) as one fused HIP kernel per step (fvk_cfg_unipc_step).
+
+The host computes the step's scalar coefficients exactly as the reference does — on 0-d fp32 torch tensors on the CPU, where the
+reference keeps ``self.sigmas`` (``:133``, ``:262``) — and the kernel applies them with the reference's operation order, so the fp32
+latents are bit-identical to the eager scheduler (tests/test_gpu_sched.py).  solver_order <= 2, solver_type "bh2", predict_x0,
+flow_prediction, lower_order_final: the configuration the Wan pipelines use (fastvideo/pipelines/basic/wan/wan_pipeline.py)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+BF16 = torch.bfloat16
+
+
+class FlowUniPCStepper:
+
+    def __init__(self, num_inference_steps: int, shift: float = 3.0, num_train_timesteps: int = 1000, solver_order: int = 2,
+                 lower_order_final: bool = True, scalar_rounding: str = "bf16"):
+        # scalar_rounding: how a 0-d fp32 / Python scalar meets a bf16 tensor in `sigma_t * model_output` and `g * (text - uncond)`.
+        #   "bf16": the scalar is first cast to the tensors' dtype — what the reference's eager path does when the operands live on the
+        #           CPU (TensorIterator common-dtype cast); this is the behaviour the oracle and the golden vectors pin.
+        #   "fp32": the scalar stays fp32 inside the kernel, as the eager CUDA/HIP elementwise kernels do with a CPU scalar operand.
+        # The two differ by at most one bf16 ulp of the product.
+        if scalar_rounding not in ("bf16", "fp32"):
+            raise ValueError("scalar_rounding must be 'bf16' or 'fp32'")
+        self.scalar_rounding = scalar_rounding
+        if solver_order not in (1, 2):
+            raise ValueError("FlowUniPCStepper: solver_order must be 1 or 2")
+        # __init__ (:94-107) with shift, then set_timesteps (:207-232) which shifts again — the reference's behaviour when the
+        # pipeline builds the scheduler with shift=flow_shift and calls set_timesteps(num_inference_steps)
+        alphas = np.linspace(1, 1 / num_train_timesteps, num_train_timesteps)[::-1].copy()
+        s0 = torch.from_numpy(1.0 - alphas).to(dtype=torch.float32)
+        s0 = shift * s0 / (1 + (shift - 1) * s0)
+        sig = np.linspace(s0[0].item(), s0[-1].item(), num_inference_steps + 1).copy()[:-1]
+        sig = shift * sig / (1 + (shift - 1) * sig)
+        self.timesteps = torch.from_numpy(sig * num_train_timesteps).to(dtype=torch.int64)
+        self.sigmas = torch.from_numpy(np.concatenate([sig, [0]]).astype(np.float32))
+        self.order, self.lower_order_final = solver_order, lower_order_final
+        self.reset()
+
+    def reset(self):
+        self.step_index, self.lower_order_nums, self.this_order = 0, 0, 0
+        self._m = [None, None]     # converted model outputs: [older, newest]
+        self._last = None
+        self._bufs = None
+
+    @staticmethod
+    def _lam(sigma):
+        return torch.log(torch.clamp(1 - sigma, min=1e-12)) - torch.log(torch.clamp(sigma, min=1e-12))
+
+    def _bh(self, i_t, i_s0, i_hist, order, corrector):
+        """(c_x, c_m0, c_B, rho0, rho_last, rk) of a B(h) update (:413-470 / :553-612)."""
+        sigma_t, sigma_s0 = self.sigmas[i_t], self.sigmas[i_s0]
+        alpha_t = 1 - sigma_t
+        h = self._lam(sigma_t) - self._lam(sigma_s0)
+        rk = (self._lam(self.sigmas[i_hist]) - self._lam(sigma_s0)) / h if order > 1 else torch.tensor(1.0)
+        rks = torch.tensor(([rk] if order > 1 else []) + [1.0])
+        hh = -h
+        h_phi_1 = torch.expm1(hh)
+        h_phi_k = h_phi_1 / hh - 1
+        B_h = torch.expm1(hh)
+        R, b, fact = [], [], 1
+        for i in range(1, order + 1):
+            R.append(torch.pow(rks, i - 1))
+            b.append(h_phi_k * fact / B_h)
+            fact *= i + 1
+            h_phi_k = h_phi_k / hh - 1 / fact
+        if corrector:
+            rhos = torch.tensor([0.5]) if order == 1 else torch.linalg.solve(torch.stack(R), torch.tensor(b))
+            rho0, rho_last = (rhos[0] if order > 1 else torch.tensor(0.0)), rhos[-1]
+        else:
+            rho0, rho_last = torch.tensor(0.5), torch.tensor(0.0)   # order 2: rhos_p = [0.5] (:461-462)
+        return [float(v) for v in (sigma_t / sigma_s0, alpha_t * h_phi_1, alpha_t * B_h, rho0, rho_last, rk)]
+
+    @torch.no_grad()
+    def step(self, noise_pred_text, latents, noise_pred_uncond=None, guidance_scale: float = 1.0, want_bf16: bool = True):
+        """latents fp32 [..]; noise predictions bf16 (the DiT outputs).  Returns (next latents fp32, next latents bf16 or None)."""
+        k = self.step_index
+        if k >= len(self.timesteps):
+            raise RuntimeError("FlowUniPCStepper: stepped past the schedule")
+        if latents.dtype != torch.float32 or not latents.is_cuda or noise_pred_text.dtype != BF16:
+            raise RuntimeError("FlowUniPCStepper.step: latents must be fp32 and noise predictions bf16 ROCm tensors (no CPU fallback)")
+        latents = latents.contiguous()
+        n = latents.numel()
+        corr_order = self.this_order if (k > 0 and self._last is not None) else 0
+        cc = self._bh(k, k - 1, k - 2, corr_order, True) if corr_order else [0.0] * 6
+        this_order = min(self.order, len(self.timesteps) - k) if self.lower_order_final else self.order
+        self.this_order = min(this_order, self.lower_order_nums + 1)
+        pc = self._bh(k + 1, k, k - 1, self.this_order, False)
+        rnd = (lambda v: float(torch.tensor(float(v), dtype=torch.float32).bfloat16())) if self.scalar_rounding == "bf16" else float
+        coef = (C.c_float * 13)(rnd(guidance_scale), rnd(self.sigmas[k]), cc[0], cc[1], cc[2], cc[3], cc[4], cc[5],
+                                pc[0], pc[1], pc[2], pc[3], pc[5])
+        x0, sample_c, nxt = (torch.empty_like(latents) for _ in range(3))
+        nxt16 = torch.empty(latents.shape, dtype=BF16, device=latents.device) if want_bf16 else None
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        m0, m1 = self._m[1], self._m[0]
+        _lib.call("fvk_cfg_unipc_step", p(noise_pred_text.contiguous()), p(None if noise_pred_uncond is None else noise_pred_uncond.contiguous()),
+                  p(latents), p(self._last), p(m0), p(m1), p(x0), p(sample_c), p(nxt), p(nxt16), n, coef, int(corr_order),
+                  int(self.this_order), ops._stream())
+        self._m = [m0, x0]
+        self._last = sample_c
+        if self.lower_order_nums < self.order:
+            self.lower_order_nums += 1
+        self.step_index += 1
+        return nxt, nxt16
+
+
+class DenoisingLoopHip:
+    """The per-step body of the reference's ``DenoisingStage.forward`` (fastvideo/pipelines/stages/denoising.py:372-596) for Wan T2V:
+    latents (fp32) -> bf16 model input -> DiT forward(s) (conditional [+ unconditional for classifier-free guidance]) -> fused
+    CFG + FlowUniPC step.  ``transformer`` is a WanTransformer3DModelHip; everything on the token axis and the step tail are HIP
+    kernels, the loop itself is host control flow."""
+
+    def __init__(self, transformer, num_inference_steps: int, flow_shift: float = 3.0, guidance_scale: float = 1.0):
+        self.model, self.g = transformer, float(guidance_scale)
+        self.stepper = FlowUniPCStepper(num_inference_steps, shift=flow_shift)
+
+    @torch.no_grad()
+    def run(self, latents, prompt_embeds, negative_prompt_embeds=None, num_steps: int | None = None):
+        """latents fp32 [1,C,T,H,W]; embeds bf16 [1,L,text_dim].  Returns the denoised latents (fp32)."""
+        self.stepper.reset()
+        use_cfg = negative_prompt_embeds is not None and self.g != 1.0
+        x = latents.float()
+        x16 = x.to(BF16)
+        n = len(self.stepper.timesteps) if num_steps is None else num_steps
+        for i in range(n):
+            t = self.stepper.timesteps[i].to(device=x.device, dtype=torch.float32).reshape(1)
+            cond = self.model(x16, prompt_embeds, t)
+            uncond = self.model(x16, negative_prompt_embeds, t) if use_cfg else None
+            x, x16 = self.stepper.step(cond, x, uncond, self.g)
+        return x

@@ -198,6 +198,20 @@ int fvk_vae_conv_bf16(const void* in, const void* w, const void* bias, void* out
 int fvk_vae_rmsnorm_silu_bf16(const void* x, const float* gamma, void* out, long n_pix, int C, int HW, int ring, int slot0,
                               int silu, void* stream);
 
+/* ------------------------------------------------------------------ denoising-step tail (HBM-bound, one pass)
+ * CFG combine + FlowUniPC multistep update.  ref: fastvideo/pipelines/stages/denoising.py:575-596,
+ * fastvideo/models/schedulers/scheduling_flow_unipc_multistep.py:296-347 (convert), :364-489 (UniP), :491-617 (UniC), :649-724 (step).
+ *   np   = uncond ? bf16(uncond + bf16(g * bf16(text - uncond))) : text                     (bf16 tensors: every op rounds)
+ *   x0   = sample - float(bf16(sigma_t * np))                                               -> x0_out   (history for later steps)
+ *   xc   = corr_order ? cc_x*last_sample - cc_m0*m0 - cc_B*([c_rho0*(m1-m0)/c_rk +] c_rho_last*(x0-m0)) : sample  -> sample_c_out
+ *   next = pc_x*xc - pc_m0*x0 [- pc_B*(p_rho0*(m0-x0)/p_rk)]  (pred_order 2)               -> next_out (fp32), next_bf16_out (optional)
+ * fp32 arithmetic in exactly this order without contraction (bit-identical to the eager reference).  n elements; m0 / m1 = x0_out of
+ * the previous / second-previous step.  coef_host: HOST float[13] = g, sigma_t, cc_x, cc_m0, cc_B, c_rho0, c_rho_last, c_rk, pc_x,
+ * pc_m0, pc_B, p_rho0, p_rk. */
+int fvk_cfg_unipc_step(const void* noise_text, const void* noise_uncond, const float* sample, const float* last_sample, const float* m0,
+                       const float* m1, float* x0_out, float* sample_c_out, float* next_out, void* next_bf16_out, long n,
+                       const float* coef_host, int corr_order, int pred_order, void* stream);
+
 /* ------------------------------------------------------------------ patch / time embedding glue
  * ref: fastvideo/layers/visual_embedding.py:46-55 (PatchEmbed k=s=(1,2,2)), :136-157 (timestep_embedding),
  *      wanvideo.py:689-690, :761-764. */

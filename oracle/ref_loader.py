@@ -143,3 +143,16 @@ def init_wan_params(model, seed=0, modulation_std=0.0) -> None:
                 p.zero_()
                 if modulation_std > 0:
                     p.add_(torch.randn(p.shape, generator=g) * modulation_std)
+
+
+def load_unipc_scheduler():
+    """The REAL reference FlowUniPCMultistepScheduler class (fastvideo/models/schedulers/scheduling_flow_unipc_multistep.py),
+    importable on CPU through oracle/_diffusers_shim.py (diffusers itself is not installed here)."""
+    install()
+    from oracle import _diffusers_shim
+    for n in list(sys.modules):  # replace the generic attribute stubs by the functional shim
+        if n == "diffusers" or n.startswith("diffusers."):
+            del sys.modules[n]
+    _diffusers_shim.install()
+    mod = importlib.import_module("fastvideo.models.schedulers.scheduling_flow_unipc_multistep")
+    return mod.FlowUniPCMultistepScheduler
