@@ -66,7 +66,7 @@ def install() -> None:
     sch = types.ModuleType("diffusers.schedulers"); sch.__path__ = []
     su = types.ModuleType("diffusers.schedulers.scheduling_utils")
     su.KarrasDiffusionSchedulers, su.SchedulerMixin, su.SchedulerOutput = KarrasDiffusionSchedulers, SchedulerMixin, SchedulerOutput
-    ut = types.ModuleType("diffusers.utils"); ut.deprecate = deprecate
+    ut = types.ModuleType("diffusers.utils"); ut.deprecate = deprecate; ut.__path__ = []  # package: other submodules fall through to the generic stubs
     for n, m in (("diffusers", pkg), ("diffusers.configuration_utils", cu), ("diffusers.schedulers", sch),
                  ("diffusers.schedulers.scheduling_utils", su), ("diffusers.utils", ut)):
         sys.modules.setdefault(n, m)
