@@ -30,7 +30,7 @@ int gemm_pp_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
 int gemm_pp_fp8_launch(GemmArgs a, int epilogue, hipStream_t s);
 
 // capi.hip: integer knobs for within-process A/B measurements (fvk_set_tunable); defaults are the shipped configuration.
-enum Tunable { TUNE_GEMM_IMPL = 0, TUNE_ATTN_IMPL = 1, TUNE_COUNT = 8 };
+enum Tunable { TUNE_GEMM_IMPL = 0, TUNE_ATTN_IMPL = 1, TUNE_VAE_CONV_IMPL = 2, TUNE_COUNT = 8 };
 int tunable(int id);
 
 }  // namespace fvk

@@ -16,7 +16,7 @@
 // barrier so that one wave of every SIMD is in its MFMA segment while its partner loads fragments / issues DMA.
 // Wave tile 64(M) x 96(N): the decoder's channel counts are 96 / 192 / 384, so N tiles of 96 (WNW=1: 512 x 96 workgroup tile)
 // or 192 (WNW=2: 256 x 192) waste nothing, where a 256-wide tile would idle 25-62 % of the MFMAs.
-#include "fvk_common.h"
+#include "gemm_common.h"
 
 namespace {
 
@@ -360,6 +360,10 @@ __global__ __launch_bounds__(256) void vae_norm_kernel(const bf16_t* __restrict_
 
 }  // namespace
 
+int fvk_vae_conv3_launch(const void* in, const void* w, const void* bias, void* out, const void* residual, float* out_f32, int T, int H,
+                         int W, int Hin, int Win, int Cin, int Cout, int KT, int ring, int ring_start, long out_fs, long res_fs,
+                         long plane_stride, int ups, int epilogue, hipStream_t s);  // vae_conv3.hip
+
 extern "C" int fvk_vae_conv_bf16(const void* in, const void* w, const void* bias, void* out, const void* residual,
                                  float* out_f32, int T, int H, int W, int Cin, int Cout, int KT, int KH, int KW, int ring,
                                  int ring_start, long out_frame_stride, long res_frame_stride, long plane_stride, int upsample2x,
@@ -379,6 +383,10 @@ extern "C" int fvk_vae_conv_bf16(const void* in, const void* w, const void* bias
     const int Hin = upsample2x ? H / 2 : H, Win = upsample2x ? W / 2 : W;
     FVK_CHECK((long)ring * Hin * Win * Cin * 2 < 0xFFFFFF00L && (long)Cout * KT * KH * KW * Cin * 2 < 0xFFFFFF00L && (long)T * H * W < 0x7FFFFFFFL,
               FVK_ERR_ARG, "fvk_vae_conv_bf16: tensor exceeds the 32-bit buffer-offset range");
+    // 3x3 spatial taps: halo-reuse kernel (vae_conv3.hip); "vae_conv_impl" = 1 forces this file's per-tap gather kernel (A/B)
+    if (KH == 3 && fvk::tunable(fvk::TUNE_VAE_CONV_IMPL) != 1)
+        return fvk_vae_conv3_launch(in, w, bias, out, residual, out_f32, T, H, W, Hin, Win, Cin, Cout, KT, ring, ring_start, out_frame_stride,
+                                    res_frame_stride, plane_stride, upsample2x, epilogue, (hipStream_t)stream);
     ConvArgs a{};
     a.in = (const bf16_t*)in; a.w = (const bf16_t*)w; a.bias = (const bf16_t*)bias; a.out = (bf16_t*)out;
     a.residual = (const bf16_t*)residual; a.out_f32 = out_f32;

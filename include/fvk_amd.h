@@ -31,6 +31,7 @@ int fvk_abi_version(void);                 /* bumps when a signature changes */
 int fvk_device_arch(char* buf, int len);   /* gcnArchName of the current device ("gfx950...") */
 /* Integer knobs for within-process A/B measurements (scripts/microbench.py); 0 = shipped configuration.
  *   "gemm_impl": 0 auto (256x256 LDS-DMA ping-pong kernel when eligible), 1 force the 128x128 register-staged kernel
+ *   "vae_conv_impl": 0 auto (halo-reuse kernel for 3x3 spatial taps), 1 force the per-tap gather kernel
  *   "attn_impl": 0 auto (8-wave ping-pong kernel, 128-key tiles), 1 force the 4-wave kernel, 2.. measurement variants */
 int fvk_set_tunable(const char* name, int value);
 
