@@ -358,6 +358,60 @@ __global__ __launch_bounds__(256) void vae_norm_kernel(const bf16_t* __restrict_
     }
 }
 
+// Same op for C = 96 / 192 / 384 (the Wan2.1 decoder widths): a pixel is owned by 12 lanes holding C/12 = 8 / 16 / 32 channels each, five
+// pixels per wave (60 of 64 lanes busy instead of 48 with power-of-two groups); the 12-lane sum is xor-1, xor-2 (inside aligned quads)
+// plus the two other quads of the dozen.
+template <int CPL>  // channels per lane: 8, 16 or 32
+__global__ __launch_bounds__(256) void vae_norm12_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                         bf16_t* __restrict__ out, long n_pix, int HW, int ring, int slot0, int silu) {
+    constexpr int C = CPL * 12;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / 12, ll = lane - sub * 12;            // pixel within the wave (0..4; 5 = idle lanes 60..63), lane within the dozen
+    const long wave_g = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const long pix = wave_g * 5 + sub;
+    const bool act = sub < 5 && pix < n_pix;
+    float v[CPL];
+    float ss = 0.f;
+    if (act) {
+#pragma unroll
+        for (int j = 0; j < CPL / 8; ++j) {
+            const bf16x8 xv = ld_bf16x8(x + pix * C + ll * CPL + j * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[j * 8 + e] = (float)xv[e];
+                ss += v[j * 8 + e] * v[j * 8 + e];
+            }
+        }
+    }
+    ss += __shfl_xor(ss, 1, 64);
+    ss += __shfl_xor(ss, 2, 64);
+    {   // the dozen = three aligned quads: add the other two quads' sums
+        const int base = sub * 12, q = ll >> 2, r = ll & 3;
+        const float s1 = __shfl(ss, base + ((q + 1) % 3) * 4 + r, 64), s2 = __shfl(ss, base + ((q + 2) % 3) * 4 + r, 64);
+        ss += s1 + s2;
+    }
+    if (act) {
+        const float inv = sqrtf((float)C) / fmaxf(sqrtf(ss), 1e-12f);
+        const long t = pix / HW, hw = pix - t * HW;
+        int s = slot0 + (int)t;
+        s = s >= ring ? s - ring : s;
+        s = s >= ring ? s - ring : s;
+        bf16_t* o = out + ((long)s * HW + hw) * C + ll * CPL;
+#pragma unroll
+        for (int j = 0; j < CPL / 8; ++j) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + ll * CPL + j * 8), g1 = *reinterpret_cast<const f32x4*>(gamma + ll * CPL + j * 8 + 4);
+            bf16x8 y;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float r_ = v[j * 8 + e] * inv * (e < 4 ? g0[e] : g1[e - 4]);
+                if (silu) r_ = r_ / (1.0f + __expf(-r_));
+                y[e] = (bf16_t)r_;
+            }
+            st_bf16x8(o + j * 8, y);
+        }
+    }
+}
+
 }  // namespace
 
 int fvk_vae_conv3_launch(const void* in, const void* w, const void* bias, void* out, const void* residual, float* out_f32, int T, int H,
@@ -404,10 +458,19 @@ extern "C" int fvk_vae_rmsnorm_silu_bf16(const void* x, const float* gamma, void
     FVK_CHECK(x && gamma && out, FVK_ERR_ARG, "fvk_vae_rmsnorm_silu_bf16: null pointer");
     FVK_CHECK(C > 0 && C % 8 == 0 && C <= 512, FVK_ERR_ARG, "fvk_vae_rmsnorm_silu_bf16: C=%d must be a multiple of 8, <= 512", C);
     FVK_CHECK(n_pix > 0 && HW > 0 && ring > 0 && slot0 >= 0 && slot0 < ring, FVK_ERR_ARG, "fvk_vae_rmsnorm_silu_bf16: bad shape");
+    hipStream_t s = (hipStream_t)stream;
+    if (C == 96 || C == 192 || C == 384) {
+        const long waves = (n_pix + 4) / 5;
+        const unsigned blocks = (unsigned)((waves + 3) / 4);
+        if (C == 96) hipLaunchKernelGGL((vae_norm12_kernel<8>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, (bf16_t*)out, n_pix, HW, ring, slot0, silu);
+        else if (C == 192) hipLaunchKernelGGL((vae_norm12_kernel<16>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, (bf16_t*)out, n_pix, HW, ring, slot0, silu);
+        else hipLaunchKernelGGL((vae_norm12_kernel<32>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, (bf16_t*)out, n_pix, HW, ring, slot0, silu);
+        FVK_LAUNCH_CHECK();
+        return FVK_OK;
+    }
     const int G = C <= 128 ? 16 : (C <= 256 ? 32 : 64);
     const long threads = n_pix * G;
     const unsigned blocks = (unsigned)((threads + 255) / 256);
-    hipStream_t s = (hipStream_t)stream;
     if (G == 16) hipLaunchKernelGGL((vae_norm_kernel<16>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, (bf16_t*)out, n_pix, C, HW, ring, slot0, silu);
     else if (G == 32) hipLaunchKernelGGL((vae_norm_kernel<32>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, (bf16_t*)out, n_pix, C, HW, ring, slot0, silu);
     else hipLaunchKernelGGL((vae_norm_kernel<64>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, gamma, (bf16_t*)out, n_pix, C, HW, ring, slot0, silu);
