@@ -164,11 +164,23 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
     wait_vm<WS>();
     __builtin_amdgcn_s_barrier();
 
+#ifdef FVK_C3_PROBE  // timing probe build: workgroup 0 sums s_memtime deltas per step phase into out_f32 (as uint64) — EPI_BIAS launches only
+    unsigned long long pacc_[4] = {0, 0, 0, 0}, plast_ = 0;
+#define C3_STAMP(K)                                                               \
+    if (EPI == EPI_BIAS && a.out_f32 && blockIdx.x == 0) {                        \
+        const unsigned long long now_ = __builtin_readcyclecounter();            \
+        if ((K) != 0 || u > 0) pacc_[K] += now_ - plast_;                         \
+        plast_ = now_;                                                            \
+    }
+#else
+#define C3_STAMP(K)
+#endif
     int u = 0, rd_slot = 0;
     for (int s = 0; s < nslab; ++s) {
         const unsigned char* xs = smem + (s & 1) * SLAB;
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh, ++u) {
+            C3_STAMP(0)
             const unsigned char* wsb = smem + W_BASE + rd_slot * WSTEP;
             bf16x8 wf[2][3], xf[2][2];
             // fragment group g = (dw, ks): w rows nb at wsb + dw*TN*64 + row*64 + chunk; x pixels mb at xs + p*64 + chunk (both swizzled)
@@ -209,19 +221,26 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
             rd_slot = rd_slot == 2 ? 0 : rd_slot + 1;
 #undef C3_READ
             // everything issued before this step has landed (only this step's own pieces may still be in flight)
+            C3_STAMP(1)
             static_assert(WS + XS0 <= 12, "DMA issue slots per step exhausted");
             if (dh == 0) wait_vm<WS + XS0>();
             else if (dh == 1) wait_vm<WS + XS1>();
             else wait_vm<WS>();
+            C3_STAMP(2)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            C3_STAMP(3)
         }
     }
 #undef C3_ISSUE_X
 #undef C3_ISSUE_W
 #undef C3_ADVANCE_X
 #undef C3_ADVANCE_W
+#ifdef FVK_C3_PROBE
+    if (EPI == EPI_BIAS && a.out_f32 && blockIdx.x == 0 && lane == 0)
+        for (int i = 0; i < 4; ++i) reinterpret_cast<unsigned long long*>(a.out_f32)[wave * 4 + i] = pacc_[i];
+#endif
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // tail (dummy) pieces landed before LDS becomes epilogue staging
     __builtin_amdgcn_s_barrier();
 

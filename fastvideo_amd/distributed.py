@@ -107,21 +107,26 @@ class SequenceParallel:
         return recv.to(dev)
 
     def scatter_heads_gather_seq(self, q, k, v):
-        """q,k,v: this rank's shard [Sl, H, D] (batch 1).  Returns (q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all)."""
+        """q,k,v: this rank's shard [Sl, H, D] (batch 1).  Returns (q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all).
+        ONE all-to-all: the message for rank r' = (g', u') is [K | V (| Q)] of head group g' — Q only if u' is this shard's query block —
+        so a layer costs two collectives (this one and the output exchange) instead of four."""
         L = self.lay
         Sl, H, D = q.shape
         hg = L.heads_per_group
-        # chunk for destination rank r' = u'*G + g' is heads group g' : [G, Sl, hg, D]
-        def by_group(t):
-            return t.reshape(Sl, L.G, hg, D).permute(1, 0, 2, 3)
-        kv_splits = [Sl] * L.P
-        k_all = self._a2a(by_group(k).repeat(L.U, 1, 1, 1).reshape(L.P * Sl, hg, D), kv_splits, kv_splits, L.P * Sl)
-        v_all = self._a2a(by_group(v).repeat(L.U, 1, 1, 1).reshape(L.P * Sl, hg, D), kv_splits, kv_splits, L.P * Sl)
-        # q goes only to the rank row u == my block; comes only from the G shards of my block
-        q_in = [Sl if (rp // L.G) == L.u else 0 for rp in range(L.P)]
-        q_out = [Sl if (s // L.G) == L.u else 0 for s in range(L.P)]
-        q_blk = self._a2a(by_group(q).reshape(L.G * Sl, hg, D), q_in, q_out, L.G * Sl)
-        return q_blk, k_all, v_all
+        by_group = lambda t: t.reshape(Sl, L.G, hg, D).permute(1, 0, 2, 3)  # [G, Sl, hg, D]: chunk g' = heads of group g'
+        qg, kg, vg = by_group(q), by_group(k), by_group(v)
+        mine = [(rp // L.G) == L.u for rp in range(L.P)]        # as destination: gets my Q; as source: its Q comes to me
+        send = torch.cat([t for rp in range(L.P) for t in ((kg[rp % L.G], vg[rp % L.G], qg[rp % L.G]) if mine[rp]
+                                                           else (kg[rp % L.G], vg[rp % L.G]))], 0)
+        splits = [(3 if m else 2) * Sl for m in mine]
+        recv = self._a2a(send, splits, splits, sum(splits))
+        ks, vs, qs, off = [], [], [], 0
+        for s_ in range(L.P):
+            ks.append(recv[off:off + Sl]); vs.append(recv[off + Sl:off + 2 * Sl])
+            if mine[s_]:
+                qs.append(recv[off + 2 * Sl:off + 3 * Sl])
+            off += splits[s_]
+        return torch.cat(qs, 0), torch.cat(ks, 0), torch.cat(vs, 0)
 
     def scatter_seq_gather_heads(self, o_blk: torch.Tensor, Sl: int) -> torch.Tensor:
         """o_blk [G*Sl, hg, D] (query block u, head group g) -> this rank's shard [Sl, H, D]."""
