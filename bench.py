@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--attention", default="dense", choices=["dense", "vsa", "sta"])
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg4", "cfg5"],
+                    help="BASELINE.json workload: cfg2 (default, the contract line) Wan2.1-1.3B 81fx480p; cfg1 the 9x64x64 plumbing latent; "
+                         "cfg4 Wan2.2-A14B 81fx720p (one expert; SP=8 in the reference config); cfg5 Wan2.1-1.3B geometry at 129fx720p")
     ap.add_argument("--quant", default=None, choices=["fp8", "fp8_channel"],
                     help="fp8 linear path (BASELINE config 5's GEMM dtype); the contract line is the default bf16 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -100,10 +103,10 @@ def main():
     from fastvideo_amd import wan_config as WC
     from fastvideo_amd.wan_dit import WanTransformer3DModelHip
 
-    cfg = WC.WAN21_T2V_1_3B
+    cfg = WC.WAN22_T2V_A14B if args.config == "cfg4" else WC.WAN21_T2V_1_3B
     if args.layers:
         cfg = WC.WanConfig(cfg.name, cfg.num_heads, cfg.head_dim, cfg.ffn_dim, args.layers)
-    latent_shape = WC.LATENT_81F_480P
+    latent_shape = {"cfg1": WC.LATENT_CFG1, "cfg2": WC.LATENT_81F_480P, "cfg4": WC.LATENT_81F_720P, "cfg5": (1, 16, 33, 90, 160)}[args.config]
     L_text = 512
     S = (latent_shape[2] // 1) * (latent_shape[3] // 2) * (latent_shape[4] // 2)
 
@@ -166,7 +169,8 @@ def main():
     lay = model.sp.lay
     par = "sp1" if world == 1 else f"sp{world} 2-D Ulysses (head groups {lay.G} x query blocks {lay.U})"
     out = {
-        "metric": "DiT-step latent-tokens/s, Wan2.1-T2V-1.3B 81fx480p (one DiT forward per step)",
+        "metric": "DiT-step latent-tokens/s, Wan2.1-T2V-1.3B 81fx480p (one DiT forward per step)" if args.config == "cfg2" else
+                  f"DiT-step latent-tokens/s, BASELINE {args.config} (one DiT forward per step)",
         "value": round(S / (elapsed / args.steps), 1), "unit": "latent-tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if not args.quant else f"{args.quant} linears (e4m3fn MFMA) + bf16 attention", "data": "synthetic (randn latent, random-init weights)",
