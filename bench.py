@@ -160,8 +160,16 @@ def main():
         flops_launch = 4.0 * Sq * Skv * h * cfg.head_dim * dens
         kname = f"{args.attention} self-attention (gather + attn_fwd_kernel block-sparse + untile), density {dens:.3f} of dense"
     achieved = flops_launch / (mean_ms * 1e-3) / 1e12
+    traffic = None
+    if args.attention == "dense" and args.config == "cfg2" and world == 1:
+        # HBM-side bytes per launch of this kernel at this shape from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+        # gfx950 correction applied; counters cannot be collected inside the timed run)
+        try:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_attn_pp2.json")))["traffic_bytes_per_launch"]
+        except Exception:  # noqa: BLE001
+            traffic = None
     roof = dict(bound="mfma", kernel=kname, achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS,
-                unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None,
+                unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
                 flops_per_launch=flops_launch, mean_launch_ms=round(mean_ms, 4), launches=len(attn_ms),
                 share_of_step=round(sum(attn_ms) / args.steps / (elapsed / args.steps * 1e3), 3))
     fl = WC.algorithmic_flops(cfg, S, L_text)
