@@ -148,8 +148,51 @@ def sliding_tile_attention(q, k, v, window_size, text_length=0, has_text=False, 
     return ops.attn_sta(q, k, v, tiles, math.prod(tile_size), window_size, layout="bhsd")
 
 
+def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3)):
+    """Host-side (CPU, pure integer) index construction that turns sliding-tile attention on an ARBITRARY token grid into block-sparse
+    attention: the grid is padded up to whole tiles, tokens are gathered tile-major with each tile's real tokens first, and the
+    clamped-centre window rule (fastvideo-kernel/tests/support_flex_sta.py:44-51) selects, per query block, the 64-token KV blocks of
+    the tiles in the window — empty blocks dropped, partially filled ones carried with their size.
+    Returns a dict of CPU tensors: tile_partition_indices / non_pad_index / untile_combined_index (as build_vsa_metadata),
+    block_sizes int32 [n_blocks64], q2k_idx int32 [n_qblocks, max_kv] (ascending), q2k_num int32 [n_qblocks], q_block (64 or 128 query
+    rows per list), S_pad, num_tiles."""
+    import numpy as np
+    tok = tile_size[0] * tile_size[1] * tile_size[2]
+    if tok % 64:
+        raise ValueError(f"sliding-tile tile {tuple(tile_size)} must hold a multiple of 64 tokens")
+    qb = 128 if tok % 128 == 0 else 64  # every query block of a tile shares the tile's window
+    h = ops.vsa_build_metadata_host(tuple(grid), tuple(tile_size))
+    nt = h["num_tiles"]
+    sub = tok // 64
+    vbs = h["variable_block_sizes"].numpy()
+    bsz = np.clip(vbs[:, None] - 64 * np.arange(sub)[None, :], 0, 64).astype(np.int32).reshape(-1)
+
+    def win(q, n, k):
+        c = min(max(q, k // 2), (n - 1) - k // 2)
+        return range(max(c - k // 2, 0), min(c + k // 2 + 1, n))
+
+    lists = []
+    for a in range(nt[0]):
+        for b in range(nt[1]):
+            for c in range(nt[2]):
+                tiles = [(x * nt[1] + y) * nt[2] + z for x in win(a, nt[0], window[0]) for y in win(b, nt[1], window[1])
+                         for z in win(c, nt[2], window[2])]
+                blocks = [t * sub + s_ for t in tiles for s_ in range(sub) if bsz[t * sub + s_] > 0]
+                lists += [blocks] * (tok // qb)
+    mx = max(len(l) for l in lists)
+    idx = np.zeros((len(lists), mx), dtype=np.int32)
+    num = np.zeros((len(lists),), dtype=np.int32)
+    for i, l in enumerate(lists):
+        idx[i, :len(l)], num[i] = l, len(l)
+    n_tok = grid[0] * grid[1] * grid[2]
+    return dict(tile_partition_indices=h["tile_partition_indices"], non_pad_index=h["non_pad_index"],
+                untile_combined_index=h["untile_combined_index"], block_sizes=torch.from_numpy(bsz), q2k_idx=torch.from_numpy(idx),
+                q2k_num=torch.from_numpy(num), q_block=qb, S_pad=len(vbs) * tok, num_tiles=nt,
+                density=float(sum(int(bsz[b]) for l in lists for b in l)) * qb / float(n_tok)**2)
+
+
 __all__ = [
     "sliding_tile_attention", "video_sparse_attn", "block_sparse_attn", "block_sparse_attn_from_indices", "VSA_TILE_SIZE",
     "get_tile_partition_indices", "get_reverse_tile_partition_indices", "construct_variable_block_sizes",
-    "get_non_pad_index", "build_vsa_metadata",
+    "get_non_pad_index", "build_vsa_metadata", "sliding_tile_block_lists",
 ]

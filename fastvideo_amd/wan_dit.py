@@ -147,39 +147,13 @@ class WanTransformer3DModelHip:
         key = (grid, n_heads)
         m = self._vsa_cache.get(("sta",) + key)
         if m is None:
-            import numpy as np
-            tt = self.sta_tile
-            tok = tt[0] * tt[1] * tt[2]
-            if tok % 64:
-                raise ValueError(f"sta tile {tt} must hold a multiple of 64 tokens")
-            qb = 128 if tok % 128 == 0 else 64  # query rows per block list: every query block of a tile shares the tile's window
-            h = ops.vsa_build_metadata_host(grid, tt)
-            nt = h["num_tiles"]
-            sub = tok // 64
-            vbs = h["variable_block_sizes"].numpy()
-            bsz = np.clip(vbs[:, None] - 64 * np.arange(sub)[None, :], 0, 64).astype(np.int32).reshape(-1)   # per 64-block
-            def win(q, n, k):  # clamped-centre window on one axis (support_flex_sta.py:44-51)
-                c = min(max(q, k // 2), (n - 1) - k // 2)
-                return range(max(c - k // 2, 0), min(c + k // 2 + 1, n))
-            lists = []
-            for a in range(nt[0]):
-                for b in range(nt[1]):
-                    for c in range(nt[2]):
-                        tiles = [(x * nt[1] + y) * nt[2] + z for x in win(a, nt[0], self.sta_window[0])
-                                 for y in win(b, nt[1], self.sta_window[1]) for z in win(c, nt[2], self.sta_window[2])]
-                        blocks = [t * sub + s_ for t in tiles for s_ in range(sub) if bsz[t * sub + s_] > 0]
-                        lists += [blocks] * (tok // qb)
-            mx = max(len(l) for l in lists)
-            idx = np.zeros((len(lists), mx), dtype=np.int32)
-            num = np.zeros((len(lists),), dtype=np.int32)
-            for i, l in enumerate(lists):
-                idx[i, :len(l)], num[i] = l, len(l)
+            h = kernel_api.sliding_tile_block_lists(grid, self.sta_tile, self.sta_window)
             dev = self.device
-            m = dict(S_pad=len(vbs) * tok, perm=h["tile_partition_indices"].to(dev), non_pad=h["non_pad_index"].to(dev),
-                     untile=h["untile_combined_index"].to(dev), block_sizes=torch.from_numpy(bsz).to(dev),
-                     q2k_idx=torch.from_numpy(idx).to(dev)[None, None].expand(1, n_heads, -1, -1).contiguous(),
-                     q2k_num=torch.from_numpy(num).to(dev)[None, None].expand(1, n_heads, -1).contiguous(),
-                     q_block=qb, density=float(sum(bsz[b] for l in lists for b in l)) * qb / (float(grid[0] * grid[1] * grid[2])**2))
+            m = dict(S_pad=h["S_pad"], perm=h["tile_partition_indices"].to(dev), non_pad=h["non_pad_index"].to(dev),
+                     untile=h["untile_combined_index"].to(dev), block_sizes=h["block_sizes"].to(dev),
+                     q2k_idx=h["q2k_idx"].to(dev)[None, None].expand(1, n_heads, -1, -1).contiguous(),
+                     q2k_num=h["q2k_num"].to(dev)[None, None].expand(1, n_heads, -1).contiguous(),
+                     q_block=h["q_block"], density=h["density"])
             self._vsa_cache[("sta",) + key] = m
         return m
 

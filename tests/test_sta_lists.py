@@ -1,0 +1,51 @@
+"""Bit-exact check of the sliding-tile -> block-sparse index construction (fastvideo_amd.kernel_api.sliding_tile_block_lists, host /
+C-ABI integer code, no GPU): expanding the lists back to a token mask must reproduce the oracle's mask (oracle/vsa_oracle.py
+sta_mask_ragged = the reference's window rule, fastvideo-kernel/tests/support_flex_sta.py:29-59, on the padded tile grid) exactly."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vsa_oracle as V
+
+
+@pytest.mark.parametrize("grid,tile,window", [((7, 9, 17), (2, 4, 8), (3, 3, 3)), ((7, 9, 17), (2, 4, 8), (1, 3, 1)),
+                                              ((12, 16, 24), (6, 8, 8), (3, 1, 3)), ((5, 6, 9), (2, 2, 16), (3, 3, 1)),
+                                              ((4, 8, 8), (2, 4, 8), (5, 3, 3)), ((21, 30, 52), (6, 8, 8), (3, 3, 3))])
+def test_block_lists_expand_to_the_oracle_mask(grid, tile, window):
+    from fastvideo_amd import kernel_api as K
+    m = K.sliding_tile_block_lists(grid, tile, window)
+    S = grid[0] * grid[1] * grid[2]
+    perm, non_pad = m["tile_partition_indices"].numpy(), m["non_pad_index"].numpy()
+    bsz, idx, num, qb = m["block_sizes"].numpy(), m["q2k_idx"].numpy(), m["q2k_num"].numpy(), m["q_block"]
+    assert m["S_pad"] % qb == 0 and len(num) == m["S_pad"] // qb
+    assert all((np.diff(idx[i, :num[i]]) > 0).all() for i in range(len(num)))  # ascending, no duplicates
+    # padded position of every real token (tile-major, real tokens first in each tile) and back
+    pos_of_raster = np.empty(S, dtype=np.int64)
+    pos_of_raster[perm] = non_pad                     # tile(): dst[non_pad[i]] = src[perm[i]]
+    assert len(set(pos_of_raster.tolist())) == S
+    raster_of_pos = -np.ones(m["S_pad"], dtype=np.int64)
+    raster_of_pos[pos_of_raster] = np.arange(S)
+    # block sizes = number of real tokens in each 64-slot block
+    real = (raster_of_pos >= 0).reshape(-1, 64)
+    assert (real.sum(1) == bsz).all() and all(r[:c].all() and not r[c:].any() for r, c in zip(real, bsz))
+    if S > 6000:  # the cfg3 grid: check a sample of query rows (the dense mask would be 1 G entries)
+        rows = np.random.default_rng(0).choice(S, 300, replace=False)
+    else:
+        rows = np.arange(S)
+    ref = V.sta_mask_ragged(grid, window, tile).numpy()[rows] if S <= 6000 else None
+    got = np.zeros((len(rows), S), dtype=bool)
+    for i, r in enumerate(rows):
+        qblock = pos_of_raster[r] // qb
+        for b in idx[qblock, :num[qblock]]:
+            keys = raster_of_pos[b * 64:b * 64 + bsz[b]]
+            got[i, keys] = True
+    if ref is None:
+        nt = m["num_tiles"]
+        coord = np.stack(np.meshgrid(*[np.arange(n) for n in grid], indexing="ij"), -1).reshape(-1, 3) // np.array(tile)
+        ref = np.ones((len(rows), S), dtype=bool)
+        for ax in range(3):
+            w = np.array([V.sta_window(q, nt[ax], window[ax]) for q in range(nt[ax])])
+            lo, hi = w[coord[rows, ax], 0], w[coord[rows, ax], 1]
+            ref &= (coord[None, :, ax] >= lo[:, None]) & (coord[None, :, ax] < hi[:, None])
+    assert np.array_equal(got, ref)
+    assert 0 < m["density"] <= 1.5
