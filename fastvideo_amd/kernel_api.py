@@ -188,7 +188,8 @@ def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3)):
     return dict(tile_partition_indices=h["tile_partition_indices"], non_pad_index=h["non_pad_index"],
                 untile_combined_index=h["untile_combined_index"], block_sizes=torch.from_numpy(bsz), q2k_idx=torch.from_numpy(idx),
                 q2k_num=torch.from_numpy(num), q_block=qb, S_pad=len(vbs) * tok, num_tiles=nt,
-                density=float(sum(int(bsz[b]) for l in lists for b in l)) * qb / float(n_tok)**2)
+                density=float(sum(int(bsz[i * (qb // 64):(i + 1) * (qb // 64)].sum()) * sum(int(bsz[b]) for b in l)
+                                  for i, l in enumerate(lists))) / float(n_tok)**2)  # attended (query, key) pairs / S^2
 
 
 __all__ = [
