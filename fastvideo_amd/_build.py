@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfvk_amd.so")
-SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "fp8.hip", "attn_fwd.hip", "attn_pp.hip", "attn_pp2.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "sched_step.hip"]
+SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "fp8.hip", "attn_fwd.hip", "attn_pp.hip", "attn_pp2.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_post.hip", "sched_step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 FLAGS += os.environ.get("FVK_EXTRA_FLAGS", "").split()  # measurement builds only (e.g. -DFVK_ST_ABL=1 timing ablations)
 
@@ -41,7 +41,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        extra = ["-ffp-contract=off"] if src == "sched_step.hip" else []  # bit-exact fp32 scheduler arithmetic (no fused multiply-add)
+        extra = ["-ffp-contract=off"] if src in ("sched_step.hip", "vae_post.hip") else []  # bit-exact fp32 arithmetic (no fused multiply-add)
         cmd = [cc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for src, p in procs:

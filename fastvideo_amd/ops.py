@@ -336,6 +336,51 @@ def vae_conv(inp, w, bias, *, T, H, W, kt, ks, ring_start=0, out=None, out_frame
     return out if out_f32 is None else out_f32
 
 
+def vae_blend(a, b, extent, axis):
+    """In-place linear cross-fade of tile b's leading `extent` slices along `axis` with tile a's trailing ones
+    (fvk_vae_blend_f32; the reference's blend_t / blend_v / blend_h, common.py:94-114).  a, b: fp32 [C, T, H, W] tiles (or views
+    of them sliced along T): dims after `axis` contiguous, dims 1..axis-1 collapsing to one stride."""
+    _chk(a, torch.float32, "a"), _chk(b, torch.float32, "b")
+    if a.dim() != 4 or b.dim() != 4 or axis not in (1, 2, 3):
+        raise RuntimeError("vae_blend: expects [C,T,H,W] tiles and axis 1 (T), 2 (H) or 3 (W)")
+    if any(a.shape[d] != b.shape[d] for d in range(4) if d != axis):
+        raise RuntimeError(f"vae_blend: tiles {tuple(a.shape)} / {tuple(b.shape)} differ off the blend axis {axis}")
+    inner = 1
+    for d in range(3, axis, -1):
+        if a.stride(d) != inner or b.stride(d) != inner:
+            raise RuntimeError("vae_blend: dims after the blend axis must be contiguous")
+        inner *= a.shape[d]
+    outer1 = 1
+    for d in range(1, axis):
+        outer1 *= a.shape[d]
+
+    def stride1(t):
+        for d in range(1, axis - 1):
+            if t.stride(d) != t.stride(d + 1) * t.shape[d + 1]:
+                raise RuntimeError("vae_blend: dims between the channel and the blend axis do not collapse to one stride")
+        return t.stride(axis - 1) if axis > 1 else 0
+
+    _lib.call("fvk_vae_blend_f32", _p(a), _p(b), a.shape[0], outer1, inner, a.shape[axis], b.shape[axis], int(extent), a.stride(0),
+              stride1(a), a.stride(axis), b.stride(0), stride1(b), b.stride(axis), _stream())
+    return b
+
+
+def vae_postprocess_u8(pixels):
+    """fp32 planar pixels [3, T, H, W] (or [1, 3, T, H, W]) in [-1, 1] -> uint8 frames [T, H, W, 3]
+    (fvk_vae_postprocess_u8: (x/2 + 0.5).clamp(0,1) * 255 -> clamp -> truncate; decoding.py:210, video_generator.py:912-913)."""
+    _chk(pixels, torch.float32, "pixels")
+    if pixels.dim() == 5:
+        if pixels.shape[0] != 1:
+            raise RuntimeError("vae_postprocess_u8: batch must be 1")
+        pixels = pixels[0]
+    Cc, T, H, W = pixels.shape
+    if Cc != 3 or not pixels[0].is_contiguous() or (pixels.stride(0) < T * H * W):
+        raise RuntimeError(f"vae_postprocess_u8: expected planar [3,T,H,W] with contiguous planes, got {tuple(pixels.shape)} strides {pixels.stride()}")
+    out = torch.empty((T, H, W, 3), dtype=torch.uint8, device=pixels.device)
+    _lib.call("fvk_vae_postprocess_u8", _p(pixels), _p(out), T, H, W, pixels.stride(0), _stream())
+    return out
+
+
 def vae_rmsnorm_silu(x, gamma, out_ring, *, HW, slot0=0, silu=True):
     """x bf16 [n_pix, C] (contiguous) -> out_ring [ring, HW, C] at frame slots (slot0 + t) % ring (fvk_vae_rmsnorm_silu_bf16)."""
     _chk(x, BF16, "x"), _chk(out_ring, BF16, "out_ring")

@@ -17,6 +17,18 @@ MI355X-first layout instead of the reference's NCTHW tensors + ``torch.cat([cach
     (``:334-353``): the first chunk skips ``time_conv`` and leaves its history at zero.
 Same chunking as the reference: one latent frame per decoder pass, 1 pixel frame for the first and 4 for every later one.
 
+Beyond the cached decode, same kernels:
+  * ``streaming_decode(z, cache, is_first_chunk)`` / ``get_streaming_cache()`` (wanvae.py:1247-1292): the rings ARE the cache, so a
+    streaming cache is just the ring set kept alive between calls;
+  * the cache-less family reached with ``use_feature_cache=False`` (``ParallelTiledVAE.decode``, common.py:76-92): ``_decode`` of a
+    whole tile in one pass (T latent frames -> 4T pixel frames; zero rings = the 2-frame causal zero padding, ``time_conv`` on every
+    frame), ``spatial_tiled_decode`` / ``tiled_decode`` / ``parallel_tiled_decode`` with the reference's in-place cross-fades done by
+    ``fvk_vae_blend_f32`` (one launch per tile edge instead of 4 eager kernels per blended row) and the merged video assembled by
+    strided copies into one preallocated buffer (no ``torch.cat`` chains).  Tile-parallel decode shards the tile list over the SP
+    group exactly as the reference does, but every rank derives all tile shapes from the plan, so the exchange is ONE
+    ``all_gather_into_tensor`` over RCCL (the reference adds a size all_gather and an ``all_gather_object`` of shapes).
+  * ``postprocess_u8``: (x/2+0.5).clamp(0,1)*255 -> uint8 frames [T,H,W,3] in one pass (decoding.py:210, video_generator.py:912-913).
+
 Constructor input: a reference ``state_dict`` (reference parameter names ``decoder.*``, ``post_quant_conv.*``).
 No CPU / eager fallback: ROCm tensors only."""
 from __future__ import annotations
@@ -59,8 +71,20 @@ class _Site:
 class WanVaeDecoderHip:
 
     def __init__(self, state_dict: dict, dim_mult=(1, 2, 4, 4), num_res_blocks: int = 2, temperal_upsample=(True, True, False),
-                 device="cuda"):
+                 device="cuda", *, use_feature_cache: bool = True, tile_sample_min_height: int = 256, tile_sample_min_width: int = 256,
+                 tile_sample_min_num_frames: int = 16, tile_sample_stride_height: int = 192, tile_sample_stride_width: int = 192,
+                 tile_sample_stride_num_frames: int = 12, blend_num_frames: int | None = None, use_tiling: bool = False,
+                 use_temporal_tiling: bool = False, use_parallel_tiling: bool = False, sp_group=None):
         self.device = torch.device(device)
+        # VAEConfig / WanVAEConfig fields (configs/models/vaes/base.py:29-46, wanvae.py:72-82)
+        self.use_feature_cache = use_feature_cache
+        self.tile_sample_min_height, self.tile_sample_min_width = tile_sample_min_height, tile_sample_min_width
+        self.tile_sample_min_num_frames = tile_sample_min_num_frames
+        self.tile_sample_stride_height, self.tile_sample_stride_width = tile_sample_stride_height, tile_sample_stride_width
+        self.tile_sample_stride_num_frames = tile_sample_stride_num_frames
+        self.blend_num_frames = (tile_sample_min_num_frames - tile_sample_stride_num_frames) * 2 if blend_num_frames is None else blend_num_frames
+        self.use_tiling, self.use_temporal_tiling, self.use_parallel_tiling = use_tiling, use_temporal_tiling, use_parallel_tiling
+        self.sp_group = sp_group  # torch.distributed group of the sequence-parallel ranks (None = single rank)
         self.dim_mult, self.nres, self.t_up = tuple(dim_mult), num_res_blocks, tuple(temperal_upsample)
         sd, dev = state_dict, self.device
         self.f32 = lambda k: sd[k].detach().reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
@@ -109,18 +133,20 @@ class WanVaeDecoderHip:
             self.ups[i] = u
         self.g_out = self.f32("decoder.norm_out.gamma")
         self._sites = None
-        self._geom = None
+        self._tile_sites = (None, None)  # (geometry key, ring set) of the cache-less tile decode, reused while the geometry repeats
+        self.t_ratio = 2**sum(1 for i in range(len(self.dim_mult) - 1) if self.t_up[i])
+        self.s_ratio = 2**(len(self.dim_mult) - 1)
 
     # ------------------------------------------------------------------ per-decode state
-    def _make_sites(self, H, W):
-        """One ring per cached conv, zero-initialised (= the reference's empty feature cache)."""
+    def _make_sites(self, H, W, t0=1):
+        """One ring per cached conv, zero-initialised (= the reference's empty feature cache); t0 = latent frames per decoder pass."""
         dev = self.device
         sites = {}
-        t, h, w = 1, H, W
-        sites["conv_in"] = _Site(1, h, w, self.conv_in.cin, dev)
+        t, h, w = t0, H, W
+        sites["conv_in"] = _Site(t, h, w, self.conv_in.cin, dev)
         for p in ("decoder.mid_block.resnets.0.", "decoder.mid_block.resnets.1."):
-            sites[p + "1"] = _Site(1, h, w, self.res[p]["conv1"].cin, dev)
-            sites[p + "2"] = _Site(1, h, w, self.res[p]["conv2"].cin, dev)
+            sites[p + "1"] = _Site(t, h, w, self.res[p]["conv1"].cin, dev)
+            sites[p + "2"] = _Site(t, h, w, self.res[p]["conv2"].cin, dev)
         for i in range(len(self.dim_mult)):
             for j in range(self.nres + 1):
                 p = f"decoder.up_blocks.{i}.resnets.{j}."
@@ -158,31 +184,37 @@ class WanVaeDecoderHip:
         return self._cached_conv(S[p + "2"], r["conv2"], y, r["g2"], T, residual=h, out=out)
 
     def _mid_attn(self, x):
+        """WanAttentionBlock (wanvae.py:479-507): every frame attends over its own H*W pixels."""
         a = self.attn
-        _, H, W, C = x.shape
-        n = torch.empty((1, H * W, C), dtype=BF16, device=x.device)
+        T, H, W, C = x.shape
+        n = torch.empty((T, H * W, C), dtype=BF16, device=x.device)
         ops.vae_rmsnorm_silu(x, a["g"], n, HW=H * W, slot0=0, silu=False)
-        qkv = ops.gemm(n.view(H * W, C), a["qkv_w"], a["qkv_b"])
-        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
-        if C == 384:
-            o = ops.attn_dense_wide(q, k, v)
-        else:
-            o = ops.attn_dense(q[None, :, None], k[None, :, None], v[None, :, None]).reshape(H * W, C)
-        o = ops.gemm(o, a["proj_w"], a["proj_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x.view(H * W, C))
-        return o.view(1, H, W, C)
+        qkv = ops.gemm(n.view(T * H * W, C), a["qkv_w"], a["qkv_b"]).view(T, H * W, 3 * C)
+        o = torch.empty((T, H * W, C), dtype=BF16, device=x.device)
+        for t in range(T):
+            q, k, v = qkv[t, :, :C], qkv[t, :, C:2 * C], qkv[t, :, 2 * C:]
+            if C == 384:
+                o[t] = ops.attn_dense_wide(q, k, v)
+            else:
+                o[t] = ops.attn_dense(q[None, :, None], k[None, :, None], v[None, :, None]).reshape(H * W, C)
+        o = ops.gemm(o.view(T * H * W, C), a["proj_w"], a["proj_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x.view(T * H * W, C))
+        return o.view(T, H, W, C)
 
-    def _decoder_chunk(self, xin, first, out_f32, plane_stride, trace=None):
-        """One latent frame.  xin: view of conv_in's ring slot already holding the post-quant frame."""
+    def _decoder_pass(self, T0, skip_time_conv, keep_history, out_f32, plane_stride, trace=None):
+        """One decoder pass over the T0 latent frames already sitting in conv_in's ring.
+        cached decode : T0 = 1; the first chunk skips time_conv and leaves its history at zero ("Rep", wanvae.py:334-336); later
+                        chunks convolve against the history and then shift it (keep_history).
+        cache-less    : T0 = whole tile; time_conv on every frame against zero history that is never updated (wanvae.py:355-359)."""
         S = self._sites
         site = S["conv_in"]
-        x = ops.vae_conv(site.buf, self.conv_in.w, self.conv_in.b, T=1, H=site.H, W=site.W, kt=3, ks=3, ring_start=site.start)
-        site.start = (site.start + 1) % site.ring
-        x = self._res_block(x, "decoder.mid_block.resnets.0.", 1)
+        x = ops.vae_conv(site.buf, self.conv_in.w, self.conv_in.b, T=T0, H=site.H, W=site.W, kt=3, ks=3, ring_start=site.start)
+        site.start = (site.start + T0) % site.ring
+        x = self._res_block(x, "decoder.mid_block.resnets.0.", T0)
         x = self._mid_attn(x)
-        x = self._res_block(x, "decoder.mid_block.resnets.1.", 1)
+        x = self._res_block(x, "decoder.mid_block.resnets.1.", T0)
         if trace is not None:
             trace.append(("mid", x))
-        T = 1
+        T = T0
         n_up = len(self.dim_mult)
         for i in range(n_up):
             u = self.ups.get(i)
@@ -194,17 +226,17 @@ class WanVaeDecoderHip:
                 x = self._res_block(x, p, T, out=dst)
             if u is not None:
                 _, H, W, C = x.shape
-                if "tc" in u and not first:
+                if "tc" in u and not skip_time_conv:
                     buf = S[f"tc{i}"]
                     y = torch.empty((2 * T, H, W, C), dtype=BF16, device=x.device)
                     for jj in range(2):  # frame interleave: output channel half jj -> output frame 2t + jj
                         ops.vae_conv(buf[:T + 2], u["tc_w"][jj], u["tc_b"][jj], T=T, H=H, W=W, kt=3, ks=1, ring_start=0,
                                      out=y[jj], out_frame_stride=2 * H * W * C)
-                    # history <- the last two input frames (wanvae.py:343-351)
-                    if T == 1:
-                        buf[0].copy_(buf[1]); buf[1].copy_(buf[2])
-                    else:
-                        buf[0:2].copy_(buf[T:T + 2])
+                    if keep_history:  # history <- the last two input frames (wanvae.py:343-351)
+                        if T == 1:
+                            buf[0].copy_(buf[1]); buf[1].copy_(buf[2])
+                        else:
+                            buf[0:2].copy_(buf[T:T + 2])
                     x, T = y, 2 * T
                 rs = u["resample"]
                 x = ops.vae_conv(x.contiguous(), rs.w, rs.b, T=T, H=2 * H, W=2 * W, kt=1, ks=3, upsample2x=True)
@@ -213,35 +245,263 @@ class WanVaeDecoderHip:
         self._cached_conv(S["conv_out"], self.conv_out, x, self.g_out, T, out_f32=out_f32, plane_stride=plane_stride)
         return T
 
-    @torch.no_grad()
-    def decode(self, z: torch.Tensor, trace=None) -> torch.Tensor:
-        """z [1, z_dim, T, H, W] (de-normalised latents, as ``AutoencoderKLWan.decode`` receives them) ->
-        fp32 pixels [1, 3, 1 + 4 (T-1), 8H, 8W] in [-1, 1]."""
+    def _latents_cl(self, z):
+        """[1, z_dim, T, H, W] -> channels-last bf16 [T, H, W, 64] (zero-padded to the post-quant GEMM's K; layout plumbing)."""
         if z.device.type != "cuda":
             raise RuntimeError("WanVaeDecoderHip runs on a ROCm device only (no CPU fallback)")
         B, Cz, Tl, H, W = z.shape
         if B != 1 or Cz != self.z_dim:
             raise ValueError(f"decode: expected [1,{self.z_dim},T,H,W], got {tuple(z.shape)}")
-        dev = self.device
-        self._sites = self._make_sites(H, W)
-        n_sp = len(self.dim_mult) - 1
-        Ho, Wo = H * 2**n_sp, W * 2**n_sp
-        n_t = sum(1 for i in range(n_sp) if self.t_up[i])
-        Tout = 1 + (2**n_t) * (Tl - 1)
-        cout = self.conv_out.cout
-        out = torch.empty((cout, Tout, Ho, Wo), dtype=torch.float32, device=dev)
-        # latents: channels-last, zero-padded to the post-quant GEMM's K = 64 (layout plumbing)
-        zc = torch.zeros((Tl, H, W, 64), dtype=BF16, device=dev)
+        zc = torch.zeros((Tl, H, W, 64), dtype=BF16, device=self.device)
         zc[..., :Cz] = z[0].permute(1, 2, 3, 0).to(BF16)
-        site = self._sites["conv_in"]
+        return zc
+
+    def _out_geometry(self, H, W):
+        return H * self.s_ratio, W * self.s_ratio
+
+    def _chunked(self, zc, sites, fresh, out, trace=None):
+        """Frame-chunked cached decode of the latent frames zc into out [3, >= n, Ho, Wo]; returns the pixel-frame count."""
+        Tl, H, W, _ = zc.shape
+        self._sites = sites
+        site = sites["conv_in"]
+        plane = out.stride(0)
         t_out = 0
         for i in range(Tl):
             slot = (site.start + 2) % site.ring
             ops.gemm(zc[i].view(H * W, 64), self.pq_w, self.pq_b, out=site.buf[slot].view(H * W, -1))
             tr = [] if trace is not None else None
-            T = self._decoder_chunk(None, i == 0, out[:, t_out:], Tout * Ho * Wo, tr)
+            first = fresh and i == 0
+            t_out += self._decoder_pass(1, first, not first, out[:, t_out:], plane, tr)
             if trace is not None:
                 trace.append(tr)
-            t_out += T
         self._sites = None
+        return t_out
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, trace=None) -> torch.Tensor:
+        """z [1, z_dim, T, H, W] (de-normalised latents, as ``AutoencoderKLWan.decode`` receives them) ->
+        fp32 pixels [1, 3, 1 + 4 (T-1), 8H, 8W] in [-1, 1].  With ``use_feature_cache=False`` the reference's cache-less dispatch
+        (plain / spatial / temporal / tile-parallel, common.py:76-92) runs instead (wanvae.py:1213-1214)."""
+        if not self.use_feature_cache:
+            return self.decode_nocache(z)
+        zc = self._latents_cl(z)
+        Tl, H, W, _ = zc.shape
+        Ho, Wo = self._out_geometry(H, W)
+        Tout = 1 + self.t_ratio * (Tl - 1)
+        out = torch.empty((self.conv_out.cout, Tout, Ho, Wo), dtype=torch.float32, device=self.device)
+        n = self._chunked(zc, self._make_sites(H, W), True, out, trace)
+        assert n == Tout
         return out.unsqueeze(0)
+
+    # ------------------------------------------------------------------ streaming decode (wanvae.py:1247-1292)
+    def get_streaming_cache(self):
+        """The reference returns ``[None] * conv_num``; here the cache is the ring set, created on the first streaming call."""
+        return {"sites": None, "fresh": True, "geom": None}
+
+    @torch.no_grad()
+    def streaming_decode(self, z: torch.Tensor, cache: dict | None, is_first_chunk: bool = False):
+        """Decode the next latent frames of a stream; ``cache`` carries every conv's causal history between calls.  As in the
+        reference (non-light VAE), what makes the very first latent frame special is the EMPTY cache, not ``is_first_chunk``."""
+        if cache is None:
+            cache = self.get_streaming_cache()
+        zc = self._latents_cl(z)
+        Tl, H, W, _ = zc.shape
+        if cache["sites"] is None:
+            cache["sites"], cache["geom"] = self._make_sites(H, W), (H, W)
+        elif cache["geom"] != (H, W):
+            raise ValueError(f"streaming_decode: latent size {(H, W)} differs from the cache's {cache['geom']}")
+        Ho, Wo = self._out_geometry(H, W)
+        Tout = self.t_ratio * Tl - (self.t_ratio - 1 if cache["fresh"] else 0)
+        out = torch.empty((self.conv_out.cout, Tout, Ho, Wo), dtype=torch.float32, device=self.device)
+        n = self._chunked(zc, cache["sites"], cache["fresh"], out)
+        assert n == Tout
+        cache["fresh"] = False
+        return out.unsqueeze(0), cache
+
+    # ------------------------------------------------------------------ cache-less tile decode + tiling (common.py)
+    def enable_tiling(self, tile_sample_min_height=None, tile_sample_min_width=None, tile_sample_min_num_frames=None,
+                      tile_sample_stride_height=None, tile_sample_stride_width=None, tile_sample_stride_num_frames=None,
+                      blend_num_frames=None, use_tiling=None, use_temporal_tiling=None, use_parallel_tiling=None) -> None:
+        """common.py:376-428, including its reset of blend_num_frames to min - stride when none is given."""
+        self.use_tiling = True
+        self.tile_sample_min_height = tile_sample_min_height or self.tile_sample_min_height
+        self.tile_sample_min_width = tile_sample_min_width or self.tile_sample_min_width
+        self.tile_sample_min_num_frames = tile_sample_min_num_frames or self.tile_sample_min_num_frames
+        self.tile_sample_stride_height = tile_sample_stride_height or self.tile_sample_stride_height
+        self.tile_sample_stride_width = tile_sample_stride_width or self.tile_sample_stride_width
+        self.tile_sample_stride_num_frames = tile_sample_stride_num_frames or self.tile_sample_stride_num_frames
+        self.blend_num_frames = blend_num_frames if blend_num_frames is not None else \
+            self.tile_sample_min_num_frames - self.tile_sample_stride_num_frames
+        self.use_tiling = use_tiling or self.use_tiling
+        self.use_temporal_tiling = use_temporal_tiling or self.use_temporal_tiling
+        self.use_parallel_tiling = use_parallel_tiling or self.use_parallel_tiling
+
+    def disable_tiling(self) -> None:
+        self.use_tiling = False
+
+    def _latent_tiles(self):
+        s, t = self.s_ratio, self.t_ratio
+        return dict(mh=self.tile_sample_min_height // s, mw=self.tile_sample_min_width // s, mt=self.tile_sample_min_num_frames // t,
+                    sh=self.tile_sample_stride_height // s, sw=self.tile_sample_stride_width // s,
+                    st=self.tile_sample_stride_num_frames // t,
+                    bh=self.tile_sample_min_height - self.tile_sample_stride_height,
+                    bw=self.tile_sample_min_width - self.tile_sample_stride_width)
+
+    def _decode_tile(self, zc):
+        """``_decode`` (wanvae.py:1217-1224) of a channels-last latent tile [T, h, w, 64] -> planar fp32 [3, 4T, 8h, 8w]."""
+        Tl, H, W, _ = zc.shape
+        key, sites = self._tile_sites
+        if key != (Tl, H, W):
+            self._tile_sites, sites = (None, None), None  # drop the previous geometry's rings before allocating the next
+            sites = self._make_sites(H, W, Tl)
+            self._tile_sites = ((Tl, H, W), sites)
+        for v in sites.values():  # rings restart at slot 0: slots 0-1 are never written in this mode and stay zero
+            if isinstance(v, _Site):
+                v.start = 0
+        self._sites = sites
+        site = sites["conv_in"]
+        ops.gemm(zc.reshape(Tl * H * W, 64), self.pq_w, self.pq_b, out=site.buf[2:2 + Tl].view(Tl * H * W, -1))
+        Ho, Wo = self._out_geometry(H, W)
+        out = torch.empty((self.conv_out.cout, self.t_ratio * Tl, Ho, Wo), dtype=torch.float32, device=self.device)
+        n = self._decoder_pass(Tl, False, False, out, out.stride(0))
+        self._sites = None
+        assert n == out.shape[1]
+        return out
+
+    def _merge_spatial(self, tiles, L):
+        """_merge_spatial_tiles (common.py:260-273): cross-fade every tile with its upper and left neighbour (in place, in
+        the reference's order), then copy its [:stride, :stride] crop into the merged frame."""
+        sh, sw = self.tile_sample_stride_height, self.tile_sample_stride_width
+        heights = [min(r[0].shape[2], sh) for r in tiles]
+        widths = [min(t.shape[3], sw) for t in tiles[0]]
+        Cc, T = tiles[0][0].shape[:2]
+        out = torch.empty((Cc, T, sum(heights), sum(widths)), dtype=torch.float32, device=self.device)
+        y0 = 0
+        for i, row in enumerate(tiles):
+            x0 = 0
+            for j, tile in enumerate(row):
+                if i > 0:
+                    ops.vae_blend(tiles[i - 1][j], tile, L["bh"], 2)
+                if j > 0:
+                    ops.vae_blend(row[j - 1], tile, L["bw"], 3)
+                out[:, :, y0:y0 + heights[i], x0:x0 + widths[j]].copy_(tile[:, :, :sh, :sw])
+                x0 += widths[j]
+            y0 += heights[i]
+        return out
+
+    def _spatial_base(self, zc, L):
+        Tl, H, W, _ = zc.shape
+        tiles = [[self._decode_tile(zc[:, i:i + L["mh"], j:j + L["mw"]].contiguous()) for j in range(0, W, L["sw"])]
+                 for i in range(0, H, L["sh"])]
+        return self._merge_spatial(tiles, L)
+
+    def _temporal_merge(self, parts):
+        """The tail of tiled_decode / parallel_tiled_decode (common.py:363-373, 246-257): cross-fade consecutive temporal
+        slices over blend_num_frames frames, keep stride (+1 for the first) frames of each."""
+        st = self.tile_sample_stride_num_frames
+        keep = [min(p.shape[1], st + 1 if i == 0 else st) for i, p in enumerate(parts)]
+        Cc, _, Ho, Wo = parts[0].shape
+        out = torch.empty((Cc, sum(keep), Ho, Wo), dtype=torch.float32, device=self.device)
+        t0 = 0
+        for i, p in enumerate(parts):
+            if i > 0:
+                ops.vae_blend(parts[i - 1], p, self.blend_num_frames, 1)
+            out[:, t0:t0 + keep[i]].copy_(p[:, :keep[i]])
+            t0 += keep[i]
+        return out
+
+    def spatial_tiled_decode(self, zc):
+        """Wan override (wanvae.py:1233-1237): ParallelTiledVAE.spatial_tiled_decode minus the t_ratio - 1 leading frames."""
+        return self._spatial_base(zc, self._latent_tiles())[:, self.t_ratio - 1:]
+
+    def tiled_decode(self, zc):
+        """Wan override (wanvae.py:1226-1231) of ParallelTiledVAE.tiled_decode (common.py:347-374).  Mirrors the reference's
+        state change: every call doubles ``blend_num_frames`` persistently."""
+        self.blend_num_frames *= 2
+        L = self._latent_tiles()
+        parts = []
+        for i in range(0, zc.shape[0], L["st"]):
+            tile = zc[i:i + L["mt"] + 1]
+            if self.use_tiling and (tile.shape[2] > L["mw"] or tile.shape[1] > L["mh"]):
+                d = self.spatial_tiled_decode(tile)
+            else:
+                d = self._decode_tile(tile.contiguous())
+            parts.append(d[:, 1:] if i > 0 else d)
+        return self._temporal_merge(parts)[:, self.t_ratio - 1:]
+
+    def tile_plan(self, T, H, W):
+        """(t, h, w) latent origins of parallel_tiled_decode in global tile order + the tile grid (common.py:186-206)."""
+        L = self._latent_tiles()
+        nt, nh, nw = -(-T // L["st"]), -(-H // L["sh"]), -(-W // L["sw"])
+        return [(ti * L["st"], hi * L["sh"], wi * L["sw"]) for ti in range(nt) for hi in range(nh) for wi in range(nw)], (nt, nh, nw)
+
+    def _tile_out_shape(self, origin, T, H, W, L):
+        t0, h0, w0 = origin
+        tl, hl, wl = min(L["mt"] + 1, T - t0), min(L["mh"], H - h0), min(L["mw"], W - w0)
+        return (self.conv_out.cout, self.t_ratio * tl - (1 if t0 > 0 else 0), hl * self.s_ratio, wl * self.s_ratio)
+
+    def parallel_tiled_decode(self, zc):
+        """Wan override (wanvae.py:1239-1245) of ParallelTiledVAE.parallel_tiled_decode (common.py:166-258): rank r decodes the
+        r-th contiguous run of ceil(n / world) tiles; one fp32 all_gather_into_tensor of the flattened runs (padded to the longest);
+        every rank then merges all tiles.  Tile shapes follow from the plan, so no shape / size exchange is needed."""
+        import torch.distributed as dist
+        self.blend_num_frames *= 2
+        L = self._latent_tiles()
+        T, H, W, _ = zc.shape
+        plan, (nt, nh, nw) = self.tile_plan(T, H, W)
+        world = dist.get_world_size(self.sp_group) if self.sp_group is not None else 1
+        rank = dist.get_rank(self.sp_group) if self.sp_group is not None else 0
+        per = -(-len(plan) // world)
+        shapes = [self._tile_out_shape(o, T, H, W, L) for o in plan]
+        numel = [s[0] * s[1] * s[2] * s[3] for s in shapes]
+        run_len = [sum(numel[r * per:min((r + 1) * per, len(plan))]) for r in range(world)]
+        flat = torch.zeros(max(run_len), dtype=torch.float32, device=self.device)
+        off = 0
+        for k in range(rank * per, min((rank + 1) * per, len(plan))):
+            t0, h0, w0 = plan[k]
+            d = self._decode_tile(zc[t0:t0 + L["mt"] + 1, h0:h0 + L["mh"], w0:w0 + L["mw"]].contiguous())
+            if t0 > 0:
+                d = d[:, 1:]
+            flat[off:off + numel[k]].view(shapes[k]).copy_(d)
+            off += numel[k]
+        if world > 1:
+            allr = torch.empty(world * flat.numel(), dtype=torch.float32, device=self.device)
+            dist.all_gather_into_tensor(allr, flat, group=self.sp_group)
+            allr = allr.view(world, -1)
+        else:
+            allr = flat.view(1, -1)
+        decoded = []
+        for r in range(world):
+            off = 0
+            for k in range(r * per, min((r + 1) * per, len(plan))):
+                decoded.append(allr[r, off:off + numel[k]].view(shapes[k]))
+                off += numel[k]
+        parts = [self._merge_spatial([[decoded[(ti * nh + hi) * nw + wi] for wi in range(nw)] for hi in range(nh)], L) for ti in range(nt)]
+        return self._temporal_merge(parts)[:, self.t_ratio - 1:]
+
+    @torch.no_grad()
+    def decode_nocache(self, z: torch.Tensor) -> torch.Tensor:
+        """ParallelTiledVAE.decode (common.py:76-92).  Frame counts are the reference's, including its short temporal-tiling output."""
+        import torch.distributed as dist
+        zc = self._latents_cl(z)
+        T, H, W, _ = zc.shape
+        L = self._latent_tiles()
+        n_out = (T - 1) * self.t_ratio + 1
+        world = dist.get_world_size(self.sp_group) if self.sp_group is not None else 1
+        if self.use_tiling and self.use_parallel_tiling and world > 1:
+            y = self.parallel_tiled_decode(zc)
+        elif self.use_tiling and self.use_temporal_tiling and T > L["mt"]:
+            y = self.tiled_decode(zc)
+        elif self.use_tiling and (W > L["mw"] or H > L["mh"]):
+            y = self.spatial_tiled_decode(zc)
+        else:
+            y = self._decode_tile(zc)
+        self._tile_sites = (None, None)
+        return y[:, :n_out].unsqueeze(0)
+
+    # ------------------------------------------------------------------ pixels -> uint8 frames
+    @torch.no_grad()
+    def postprocess_u8(self, pixels: torch.Tensor) -> torch.Tensor:
+        """[1, 3, T, H, W] fp32 in [-1, 1] -> uint8 [T, H, W, 3]: DecodingStage's (x/2+0.5).clamp(0,1) followed by VideoGenerator's
+        on-device (x*255).clamp(0,255).to(uint8), in the frame-major channels-last layout the video writer consumes."""
+        return ops.vae_postprocess_u8(pixels)

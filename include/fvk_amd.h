@@ -213,6 +213,19 @@ int fvk_cfg_unipc_step(const void* noise_text, const void* noise_uncond, const f
                        const float* m1, float* x0_out, float* sample_c_out, float* next_out, void* next_bf16_out, long n,
                        const float* coef_host, int corr_order, int pred_order, void* stream);
 
+/* ------------------------------------------------------------------ VAE tile cross-fade + pixel post-processing (HBM-bound)
+ * ref: fastvideo/models/vaes/common.py:94-114 (blend_v / blend_h / blend_t: `extent` python-loop slice assignments per tile edge),
+ *      fastvideo/pipelines/stages/decoding.py:210, fastvideo/entrypoints/video_generator.py:912-913.
+ * fvk_vae_blend_f32: a, b fp32 of logical shape [outer0, outer1, len, inner] with explicit strides (inner contiguous; e.g. a planar
+ *   [C,T,H,W] tile or its [:, 1:] view blended along T, H or W), in place on b:
+ *   b[.., i, :] = a[.., len_a - e + i, :] * float(1 - i/e) + b[.., i, :] * float(i/e),  i < e = min(extent, len_a, len_b);
+ *   products and sum rounded separately (no FMA) = the eager reference bit for bit.
+ * fvk_vae_postprocess_u8: planar fp32 [3, T, H, W] in [-1, 1] (plane_stride elements between channels) -> u8 frames [T, H, W, 3]:
+ *   uint8(trunc(clamp(clamp(x / 2 + 0.5, 0, 1) * 255, 0, 255))). */
+int fvk_vae_blend_f32(const float* a, float* b, long outer0, long outer1, long inner, int len_a, int len_b, int extent, long a_stride0,
+                      long a_stride1, long a_axis_stride, long b_stride0, long b_stride1, long b_axis_stride, void* stream);
+int fvk_vae_postprocess_u8(const float* pixels, void* frames_u8, int T, int H, int W, long plane_stride, void* stream);
+
 /* ------------------------------------------------------------------ patch / time embedding glue
  * ref: fastvideo/layers/visual_embedding.py:46-55 (PatchEmbed k=s=(1,2,2)), :136-157 (timestep_embedding),
  *      wanvideo.py:689-690, :761-764. */
