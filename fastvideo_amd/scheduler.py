@@ -117,21 +117,39 @@ class DenoisingLoopHip:
     CFG + FlowUniPC step.  ``transformer`` is a WanTransformer3DModelHip; everything on the token axis and the step tail are HIP
     kernels, the loop itself is host control flow."""
 
-    def __init__(self, transformer, num_inference_steps: int, flow_shift: float = 3.0, guidance_scale: float = 1.0):
+    def __init__(self, transformer, num_inference_steps: int, flow_shift: float = 3.0, guidance_scale: float = 1.0,
+                 transformer_2=None, boundary_ratio: float | None = None, guidance_scale_2: float | None = None,
+                 num_train_timesteps: int = 1000):
+        """``transformer_2`` / ``boundary_ratio`` / ``guidance_scale_2``: Wan2.2-A14B's two experts — steps with
+        t >= boundary_ratio * num_train_timesteps run the high-noise expert with ``guidance_scale``, the rest run ``transformer_2``
+        with ``guidance_scale_2`` (denoising.py:251-256, 377-403).  Both experts stay resident (2 x 28 GB of bf16 weights in 288 GB
+        of HBM), so the reference's per-boundary CPU offload shuffle has no counterpart here."""
         self.model, self.g = transformer, float(guidance_scale)
-        self.stepper = FlowUniPCStepper(num_inference_steps, shift=flow_shift)
+        self.model_2 = transformer_2
+        self.g2 = float(guidance_scale if guidance_scale_2 is None else guidance_scale_2)
+        self.boundary_timestep = None if boundary_ratio is None else boundary_ratio * num_train_timesteps
+        if self.boundary_timestep is not None and transformer_2 is None:
+            raise ValueError("DenoisingLoopHip: boundary_ratio given without transformer_2 (the low-noise expert)")
+        self.stepper = FlowUniPCStepper(num_inference_steps, shift=flow_shift, num_train_timesteps=num_train_timesteps)
+
+    def expert_for(self, t: float):
+        """(model, guidance scale) of the step at timestep t (denoising.py:377-403)."""
+        if self.boundary_timestep is None or t >= self.boundary_timestep:
+            return self.model, self.g
+        return self.model_2, self.g2
 
     @torch.no_grad()
     def run(self, latents, prompt_embeds, negative_prompt_embeds=None, num_steps: int | None = None):
         """latents fp32 [1,C,T,H,W]; embeds bf16 [1,L,text_dim].  Returns the denoised latents (fp32)."""
         self.stepper.reset()
-        use_cfg = negative_prompt_embeds is not None and self.g != 1.0
         x = latents.float()
         x16 = x.to(BF16)
         n = len(self.stepper.timesteps) if num_steps is None else num_steps
         for i in range(n):
+            model, g = self.expert_for(float(self.stepper.timesteps[i]))
+            use_cfg = negative_prompt_embeds is not None and self.g > 1.0  # batch-level switch (pipeline_batch_info.py:270-272)
             t = self.stepper.timesteps[i].to(device=x.device, dtype=torch.float32).reshape(1)
-            cond = self.model(x16, prompt_embeds, t)
-            uncond = self.model(x16, negative_prompt_embeds, t) if use_cfg else None
-            x, x16 = self.stepper.step(cond, x, uncond, self.g)
+            cond = model(x16, prompt_embeds, t)
+            uncond = model(x16, negative_prompt_embeds, t) if use_cfg else None
+            x, x16 = self.stepper.step(cond, x, uncond, g)
         return x

@@ -78,3 +78,44 @@ def test_denoising_loop_two_steps_vs_oracle(golden_dir):
     err = (y - x).abs()
     print(f"denoising loop: max|err|={err.max().item():.4g} mean|err|={err.mean().item():.4g} ref_absmean={x.abs().mean().item():.4g}")
     assert err.mean().item() < 2e-2 and err.max().item() < 0.5
+
+
+def test_two_expert_loop_switches_at_the_boundary(golden_dir):
+    """Wan2.2-A14B style loop: steps with t >= boundary_ratio * 1000 use the high-noise expert and guidance_scale, the others the
+    low-noise expert and guidance_scale_2 (denoising.py:251-256, 377-403).  4 steps, shift 3 => t = 999, 899, 749, 499; boundary 0.875
+    => expert 1 for the first two steps, expert 2 afterwards.  vs the oracle DiTs + oracle scheduler driven the same way."""
+    _need_gpu()
+    from fastvideo_amd.scheduler import DenoisingLoopHip
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    from oracle import wan_oracle as W
+    from oracle.sched_oracle import FlowUniPCOracle, cfg_combine
+    fx = torch.load(os.path.join(golden_dir, "wan_tiny.pt"), weights_only=False)
+    H = fx["config"]["num_heads"]
+    c = fx["cases"][0]
+    sd2 = {k: v.clone() for k, v in fx["state_dict"].items()}
+    sd2["proj_out.weight"] = -0.5 * sd2["proj_out.weight"]          # a visibly different second expert
+    gen = torch.Generator().manual_seed(3)
+    lat = torch.randn(c["latent"].shape, generator=gen)
+    neg = torch.randn(c["ctx"].shape, generator=gen).bfloat16()
+    o1, o2 = W.WanOracle(fx["state_dict"], num_heads=H), W.WanOracle(sd2, num_heads=H)
+    sch = FlowUniPCOracle(4, shift=3.0)
+    x = lat.clone()
+    used = []
+    with torch.no_grad():
+        for i in range(3):
+            t = sch.timesteps[i].float().reshape(1)
+            orc, g = (o1, 4.0) if float(sch.timesteps[i]) >= 875.0 else (o2, 3.0)
+            used.append(1 if orc is o1 else 2)
+            x16 = x.bfloat16()
+            x = sch.step(cfg_combine(orc.forward(x16, c["ctx"], t), orc.forward(x16, neg, t), g), x)
+    assert used == [1, 1, 2]
+    m1, m2 = WanTransformer3DModelHip(fx["state_dict"], num_heads=H), WanTransformer3DModelHip(sd2, num_heads=H)
+    loop = DenoisingLoopHip(m1, 4, flow_shift=3.0, guidance_scale=4.0, transformer_2=m2, boundary_ratio=0.875, guidance_scale_2=3.0)
+    assert loop.expert_for(899.0) == (m1, 4.0) and loop.expert_for(749.0) == (m2, 3.0) and loop.expert_for(875.0)[0] is m1
+    y = loop.run(lat.cuda(), c["ctx"].cuda(), neg.cuda(), num_steps=3).cpu()
+    err = (y - x).abs()
+    print(f"two-expert loop: max|err|={err.max().item():.4g} mean|err|={err.mean().item():.4g}")
+    assert err.mean().item() < 3e-2 and err.max().item() < 0.75
+    # and the switch matters: the single-expert loop lands somewhere else
+    y1 = DenoisingLoopHip(m1, 4, flow_shift=3.0, guidance_scale=4.0).run(lat.cuda(), c["ctx"].cuda(), neg.cuda(), num_steps=3).cpu()
+    assert (y1 - x).abs().mean().item() > 4 * err.mean().item()
