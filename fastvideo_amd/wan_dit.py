@@ -239,25 +239,61 @@ class WanTransformer3DModelHip:
         Sl = x.shape[1]
         pos0 = rank * Sl
 
+        # modulation groups: row m of the local token block uses modulation row m // rpb (the kernels' rows_per_batch indexing).
+        #   scalar timestep [B]      : one row per batch element, rpb = Sl
+        #   per-token timesteps [B,S]: Wan2.2 TI2V (wanvideo.py:375-385, 690-712; built at denoising.py:441-446) and per-frame
+        #                              (causal / diffusion-forcing) schedules.  The embedder MLPs are row-independent, so tokens that
+        #                              share a timestep share a modulation row: one row per latent frame (rpb = tokens per frame) when
+        #                              the timestep is constant inside every frame and the local shard is frame-aligned, else one
+        #                              row per token (rpb = 1) — never the reference's [S, 6, d] fp32 tensor per layer unless needed.
+        rpb = Sl
+        if timestep.dim() == 2:
+            if B != 1 or timestep.shape[1] != S:
+                raise ValueError(f"per-token timestep must be [1, {S}], got {tuple(timestep.shape)}")
+            ts = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+            tpf = grid[1] * grid[2]
+            tf = ts.view(grid[0], tpf)
+            if Sl % tpf == 0 and bool((tf == tf[:, :1]).all()):
+                rpb, ng = tpf, Sl // tpf
+                tg = torch.zeros(P * ng, dtype=torch.float32, device=dev)
+                tg[:grid[0]] = tf[:, 0]
+                timestep = tg[rank * ng:(rank + 1) * ng]
+            else:
+                rpb = 1
+                tg = torch.zeros(P * Sl, dtype=torch.float32, device=dev)
+                tg[:S] = ts
+                timestep = tg[pos0:pos0 + Sl]
+        G = timestep.shape[0]
+
         # condition embedder (wanvideo.py:102-136)
         t_freq = ops.timestep_embedding(timestep.to(dev), self.freq_dim)
         h = ops.gemm(t_freq, w["time_embedder.mlp.fc_in.w"], w["time_embedder.mlp.fc_in.b"], epilogue=ops.EPI_SILU)
         temb = ops.gemm(h, w["time_embedder.mlp.fc_out.w"], w["time_embedder.mlp.fc_out.b"])
-        tproj = ops.gemm(ops.silu(temb), w["time_modulation.linear.w"], w["time_modulation.linear.b"]).view(B, 6, d)
+        tproj = ops.gemm(ops.silu(temb), w["time_modulation.linear.w"], w["time_modulation.linear.b"]).view(G, 6, d)
         ctx = encoder_hidden_states.to(device=dev, dtype=BF16)
         Lc = ctx.shape[1]
         c = ops.gemm(ctx.reshape(B * Lc, -1), w["text_embedder.fc_in.w"], w["text_embedder.fc_in.b"], epilogue=ops.EPI_GELU_TANH)
         c = ops.gemm(c, w["text_embedder.fc_out.w"], w["text_embedder.fc_out.b"])
         ckv = self._lin(c, {"ckv_w": getattr(self, "ckv_w", None), "ckv_q": getattr(self, "ckv_q", None), "ckv_s": getattr(self, "ckv_s", None)}, "ckv", self.ckv_b)  # [B*Lc, L*2d]: every layer's text K and V
 
-        # AdaLN vectors for all layers at once: e = table + temb.float()  -> [L,B,6,d] fp32 (wanvideo.py:386-390)
-        e = self.tables + tproj.float().unsqueeze(0)
-        shift_msa, scale_msa, gate_msa, c_shift, c_scale, c_gate = (e[:, :, j].contiguous() for j in range(6))
-        mul_msa, mul_c = 1 + scale_msa, 1.0 + c_scale
+        # AdaLN vectors e = table + temb.float() (wanvideo.py:386-390): [L,G,6,d] fp32 for all layers at once while that is small
+        # (G = batch or latent frames), per layer when there is one row per token
+        tproj32 = tproj.float()
+        if len(self.blocks) * G * 6 * d * 4 <= (1 << 30):
+            e_all = self.tables + tproj32.unsqueeze(0)
+            parts = [e_all[:, :, j].contiguous() for j in range(6)]
+            parts[1], parts[4] = 1 + parts[1], 1.0 + parts[4]
+            mods = lambda i: tuple(p_[i] for p_ in parts)
+        else:
+            def mods(i):
+                e_i = self.tables[i] + tproj32
+                sh, sc, ga, csh, csc, cga = (e_i[:, j].contiguous() for j in range(6))
+                return sh, 1 + sc, ga, csh, 1.0 + csc, cga
 
         x = x.reshape(B * Sl, d)
         for i, b in enumerate(self.blocks):
-            nh = ops.ln_modulate(x, mul=mul_msa[i], add=shift_msa[i], eps=self.eps, rows_per_batch=Sl)
+            shift_i, mul_i, gate_i, c_shift_i, mul_c_i, c_gate_i = mods(i)
+            nh = ops.ln_modulate(x, mul=mul_i, add=shift_i, eps=self.eps, rows_per_batch=rpb)
             if self.quant and b["n_qkv"] == 4:
                 qkv = torch.empty((B * Sl, 4 * d), dtype=BF16, device=dev)
                 self._lin(nh, b, "qkv", b["qkv_b"], out=qkv[:, :3 * d])
@@ -279,8 +315,8 @@ class WanTransformer3DModelHip:
                 else:
                     attn[bi * Sl:(bi + 1) * Sl] = o
             a_out = self._lin(attn, b, "o", b["o_b"])
-            nh, x = ops.ln_modulate(a_out, residual=x, gate=gate_msa[i], ln_w=b["ln2_w"], ln_b=b["ln2_b"], eps=self.eps,
-                                    want_residual=True, rows_per_batch=Sl)
+            nh, x = ops.ln_modulate(a_out, residual=x, gate=gate_i, ln_w=b["ln2_w"], ln_b=b["ln2_b"], eps=self.eps,
+                                    want_residual=True, rows_per_batch=rpb)
             if trace is not None:
                 trace[f"blocks.{i}.after_self_attn"] = x.view(B, Sl, d).clone()
             # cross attention over the text tokens (WanT2VCrossAttention, wanvideo.py:188-222)
@@ -291,17 +327,17 @@ class WanTransformer3DModelHip:
             co = ops.attn_dense(cq.view(B, Sl, H, D), ck.view(B, Lc, H, D), kv[:, d:].view(B, Lc, H, D), scale=D**-0.5,
                                 layout="bshd")
             c_out = self._lin(co.view(B * Sl, d), b, "co", b["co_b"])
-            nh, x = ops.ln_modulate(c_out, residual=x, mul=mul_c[i], add=c_shift[i], eps=self.eps, round_residual=True,
-                                    round_norm=True, want_residual=True, rows_per_batch=Sl)
+            nh, x = ops.ln_modulate(c_out, residual=x, mul=mul_c_i, add=c_shift_i, eps=self.eps, round_residual=True,
+                                    round_norm=True, want_residual=True, rows_per_batch=rpb)
             f = self._lin(nh, b, "f1", b["f1_b"], epilogue=ops.EPI_GELU_TANH)
-            x = self._lin(f, b, "f2", b["f2_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=c_gate[i], rows_per_batch=Sl)
+            x = self._lin(f, b, "f2", b["f2_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=c_gate_i, rows_per_batch=rpb)
             if trace is not None:
                 trace[f"blocks.{i}.out"] = x.view(B, Sl, d).clone()
 
         # output norm (bf16 modulation vectors, wanvideo.py:746-756), gather, projection, unpatchify
-        ss = self.out_table + temb.unsqueeze(1)           # [B,2,d] bf16
+        ss = self.out_table + temb.unsqueeze(1)           # [G,2,d] bf16
         shift, scale = ss[:, 0], ss[:, 1]
-        x = ops.ln_modulate(x, mul=(1.0 + scale).float(), add=shift.float(), eps=self.eps, round_norm=True, rows_per_batch=Sl)
+        x = ops.ln_modulate(x, mul=(1.0 + scale).float(), add=shift.float(), eps=self.eps, round_norm=True, rows_per_batch=rpb)
         x = sp.all_gather_unpad(x.view(B, Sl, d), S, dim=1)
         if trace is not None:
             trace["norm_out"] = x.clone()

@@ -120,3 +120,23 @@ def test_wan_tiny_sta_matches_oracle(tiny, window):
     model = WanTransformer3DModelHip(tiny["state_dict"], num_heads=H, attention="sta", sta_window=window, sta_tile=tile)
     y = model(latent.cuda(), ctx.cuda(), ts.cuda())
     _cmp(y, ref, f"sta {window} output", mean_tol=2e-2)
+
+
+def test_wan_tiny_per_token_timesteps_match_reference(tiny, golden_dir):
+    """Wan2.2 TI2V branch: timestep [1, S] (wanvideo.py:375-385, 690-712, 747-751) vs the REAL reference's outputs
+    (tests/golden/wan_tiny_ti2v.pt).  "ti2v" and "per_frame" take the one-modulation-row-per-latent-frame path, "per_token" the
+    one-row-per-token path; all three must also agree with feeding the same model one frame-constant row per token."""
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    fx = torch.load(os.path.join(golden_dir, "wan_tiny_ti2v.pt"), weights_only=False)
+    model = WanTransformer3DModelHip(tiny["state_dict"], num_heads=tiny["config"]["num_heads"])
+    for case in fx["cases"]:
+        y = model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda())
+        _cmp(y, case["out"], f"per-token timesteps ({case['kind']})")
+    # scalar timestep == the same timestep on every token (both grouping paths)
+    c = fx["cases"][0]
+    S = c["timestep"].shape[1]
+    y_sca = model(c["latent"].cuda(), c["ctx"].cuda(), torch.tensor([501.0]).cuda())
+    y_tok = model(c["latent"].cuda(), c["ctx"].cuda(), torch.full((1, S), 501.0).cuda())
+    assert torch.equal(y_sca, y_tok)
+    with pytest.raises(ValueError, match="per-token timestep"):
+        model(c["latent"].cuda(), c["ctx"].cuda(), torch.zeros((1, S + 1)).cuda())

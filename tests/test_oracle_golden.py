@@ -28,6 +28,24 @@ def test_wan_tiny_forward_bit_exact(tiny):
         assert torch.equal(y, case["out"])
 
 
+def test_wan_tiny_per_token_timesteps_bit_exact(tiny, golden_dir):
+    """Wan2.2 TI2V branch (timestep [B, S]; wanvideo.py:375-385, 690-712, 747-751) vs the real reference's outputs
+    (tests/golden/wan_tiny_ti2v.pt from oracle/make_golden_ti2v.py)."""
+    fx = torch.load(os.path.join(golden_dir, "wan_tiny_ti2v.pt"), weights_only=False)
+    o = W.WanOracle(tiny["state_dict"], num_heads=tiny["config"]["num_heads"])
+    assert [c["kind"] for c in fx["cases"]] == ["ti2v", "per_frame", "per_token"]
+    for case in fx["cases"]:
+        with torch.no_grad():
+            y = o.forward(case["latent"], case["ctx"], case["timestep"])
+        assert torch.equal(y, case["out"]), f"{case['kind']}: max diff {(y.float() - case['out'].float()).abs().max().item()}"
+    # a constant per-token timestep is the scalar-timestep forward
+    c = fx["cases"][0]
+    with torch.no_grad():
+        y_tok = o.forward(c["latent"], c["ctx"], torch.full((1, 48), 501.0))
+        y_sca = o.forward(c["latent"], c["ctx"], torch.tensor([501.0]))
+    assert torch.equal(y_tok, y_sca)
+
+
 def test_rope_tables(golden_dir):
     g = torch.load(os.path.join(golden_dir, "rope.pt"), weights_only=False)
     for key, ref in g.items():
