@@ -345,6 +345,8 @@ def vae_blend(a, b, extent, axis):
         raise RuntimeError("vae_blend: expects [C,T,H,W] tiles and axis 1 (T), 2 (H) or 3 (W)")
     if any(a.shape[d] != b.shape[d] for d in range(4) if d != axis):
         raise RuntimeError(f"vae_blend: tiles {tuple(a.shape)} / {tuple(b.shape)} differ off the blend axis {axis}")
+    if a.numel() == 0 or b.numel() == 0 or extent <= 0:
+        return b  # min(len_a, len_b, extent) == 0: the reference's loop body never runs (common.py:95-96)
     inner = 1
     for d in range(3, axis, -1):
         if a.stride(d) != inner or b.stride(d) != inner:

@@ -2,14 +2,14 @@
 family of AutoencoderKLWan (use_feature_cache=False) and the streaming decode.
 
 Run in the build container only:  ``python oracle/make_golden_vae_tiled.py``.
-Cases (same seeded base_dim-32 decoder as vae_tiny.pt, latent [1,16,6,5,5], 32-px tiles with 24-px stride => 2x2 spatial tiles,
-2 temporal tiles):
+Cases (same seeded base_dim-32 decoder as vae_tiny.pt, latent [1,16,7,5,5], 32-px tiles with 24-px stride => 2x2 spatial tiles,
+3 temporal tiles, the last of which holds a single latent frame and contributes no frame at all after the overrides' frame drops):
   plain      vae.decode with tiling off                   (_decode, common.py:92)
   spatial    use_tiling                                    (spatial_tiled_decode + Wan override)
   tiled0/1   use_tiling + use_temporal_tiling, 1st and 2nd call (blend_num_frames doubles per call, wanvae.py:1227)
   parallel   use_parallel_tiling on a 2-rank gloo group    (parallel_tiled_decode; sp world size/rank patched in, and
              all_gather_into_tensor routed through all_gather because gloo refuses the [world, N] output NCCL accepts)
-  stream     streaming_decode in two calls (3 + 3 latent frames)
+  stream     streaming_decode in two calls (3 + 4 latent frames)
 Full tensors are stored for tiled0 and parallel; the others are stored as sha256 of the fp32 bytes plus shape."""
 from __future__ import annotations
 
@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "vae_tiled.pt")
 TILES = dict(tile_sample_min_height=32, tile_sample_min_width=32, tile_sample_stride_height=24, tile_sample_stride_width=24)
-SEED, ZSHAPE, ZSEED = 3, (1, 16, 6, 5, 5), 11
+SEED, ZSHAPE, ZSEED = 3, (1, 16, 7, 5, 5), 11
 
 
 def latent():

@@ -55,7 +55,7 @@ def _worker(rank, world, port, path):
         dec = _host_decoder(sd, g["tiles"])
         dec.sp_group = dist.group.WORLD
         with torch.no_grad():
-            y = dec.parallel_tiled_decode(_latent_cl(z))[:, :21].unsqueeze(0)
+            y = dec.parallel_tiled_decode(_latent_cl(z))[:, :1 + 4 * (z.shape[2] - 1)].unsqueeze(0)
         assert dec.blend_num_frames == 8
         torch.save(y, f"{path}.{rank}")
         dist.barrier()
