@@ -140,3 +140,23 @@ def test_wan_tiny_per_token_timesteps_match_reference(tiny, golden_dir):
     assert torch.equal(y_sca, y_tok)
     with pytest.raises(ValueError, match="per-token timestep"):
         model(c["latent"].cuda(), c["ctx"].cuda(), torch.zeros((1, S + 1)).cuda())
+
+
+def test_loader_builds_the_same_model_from_safetensors(tiny, tmp_path, golden_dir):
+    """diffusers-format checkpoint directory -> fastvideo_amd.loader -> HIP model: same outputs as building from the state_dict."""
+    from fastvideo_amd import loader as L
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    from test_loader import _write_transformer  # tests/ is on sys.path (rootdir conftest, no package)
+    d = str(tmp_path / "transformer")
+    _write_transformer(d, tiny["state_dict"], 2)
+    c = tiny["cases"][0]
+    ref = WanTransformer3DModelHip(tiny["state_dict"], num_heads=tiny["config"]["num_heads"])(c["latent"].cuda(), c["ctx"].cuda(), c["timestep"].cuda())
+    for quant in (None, "fp8"):
+        m = L.load_wan_transformer(d, device="cuda", quantization=quant)
+        y = m(c["latent"].cuda(), c["ctx"].cuda(), c["timestep"].cuda())
+        if quant is None:
+            assert torch.equal(y, ref)
+        else:  # same quantised model as constructing with quantization="fp8" directly
+            y2 = WanTransformer3DModelHip(tiny["state_dict"], num_heads=tiny["config"]["num_heads"], quantization="fp8")(
+                c["latent"].cuda(), c["ctx"].cuda(), c["timestep"].cuda())
+            assert torch.equal(y, y2) and not torch.equal(y, ref)
