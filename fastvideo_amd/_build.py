@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfvk_amd.so")
-SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "fp8.hip", "attn_fwd.hip", "attn_pp.hip", "attn_pp2.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_post.hip", "sched_step.hip"]
+SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.hip", "fp8.hip", "attn_fwd.hip", "attn_pp.hip", "attn_pp2.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_post.hip", "sched_step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 FLAGS += os.environ.get("FVK_EXTRA_FLAGS", "").split()  # measurement builds only (e.g. -DFVK_ST_ABL=1 timing ablations)
 
@@ -33,6 +33,19 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB
+    # one builder at a time: under torch.distributed.run every rank calls build(), and a snapshot copy may have refreshed mtimes
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():  # another rank finished the build while this one waited
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()

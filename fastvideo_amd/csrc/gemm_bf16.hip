@@ -194,8 +194,13 @@ static int gemm_impl(const void* x, const void* w, const void* bias, void* out, 
                M, N, K, lda, ldc, rows_per_batch > 0 ? rows_per_batch : M, (M + BM - 1) / BM, (N + BN - 1) / BN,
                epi_scalar, x_bstride, w_bstride, out_bstride};
     hipStream_t s = (hipStream_t)stream;
-    // token-axis GEMMs go to the 256x256 LDS-DMA ping-pong kernel (gemm_pp.hip); this 128x128 kernel keeps the small / odd shapes
-    if (fvk::tunable(fvk::TUNE_GEMM_IMPL) != 1 && fvk::gemm_pp_eligible(a)) return fvk::gemm_pp_launch(a, epilogue, batch, s);
+    // token-axis GEMMs go to the 256x256 LDS-DMA kernels: gemm_ph.hip (K-step 64, the default) or gemm_pp.hip (K % 64 != 0, or forced
+    // with gemm_impl 2 / 3); this 128x128 kernel keeps the small / odd shapes (gemm_impl 1 forces it)
+    const int impl = fvk::tunable(fvk::TUNE_GEMM_IMPL);
+    if (impl != 1 && fvk::gemm_pp_eligible(a)) {
+        if ((impl == 0 || (impl & 7) == 4) && fvk::gemm_ph_eligible(a)) return fvk::gemm_ph_launch(a, epilogue, batch, s);
+        return fvk::gemm_pp_launch(a, epilogue, batch, s);
+    }
     FVK_CHECK(K % BK == 0, FVK_ERR_ARG, "fvk_gemm_bf16: K=%d must be a multiple of %d for this shape (M=%d N=%d)", K, BK, M, N);
     switch (epilogue) {
         case FVK_EPI_NONE: return launch<FVK_EPI_NONE>(a, batch, s);

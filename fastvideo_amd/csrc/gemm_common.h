@@ -29,6 +29,10 @@ bool gemm_pp_eligible(const GemmArgs& a);
 int gemm_pp_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
 int gemm_pp_fp8_launch(GemmArgs a, int epilogue, hipStream_t s);
 
+// gemm_ph.hip (K-step 64, unit-phased staging; gemm_impl 4)
+bool gemm_ph_eligible(const GemmArgs& a);
+int gemm_ph_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
+
 // capi.hip: integer knobs for within-process A/B measurements (fvk_set_tunable); defaults are the shipped configuration.
 enum Tunable { TUNE_GEMM_IMPL = 0, TUNE_ATTN_IMPL = 1, TUNE_VAE_CONV_IMPL = 2, TUNE_COUNT = 8 };
 int tunable(int id);

@@ -19,6 +19,7 @@
 //   * Workgroup ids are remapped so each XCD (private L2) owns a contiguous range of tiles, walked in groups of 8 m-tiles.
 // Rounding points equal gemm_bf16.hip: y = bf16(acc + bias), then the epilogue on float(y), then one more rounding.
 #include "gemm_common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -26,25 +27,18 @@ constexpr int TM = 256, TN = 256, TK = 32;
 constexpr int REGION = TM * TK * 2;        // 16 KiB: the x rows of a slot; the w rows follow
 constexpr int SLOT = 2 * REGION;           // 32 KiB
 constexpr int NSLOT = 4;
-constexpr int EPI_PITCH = 144;             // bytes per staged output row (64 bf16 + 16 B pad)
-constexpr int EPI_WAVE = 128 * EPI_PITCH;  // 18 432 B per wave
-constexpr int LDS_BYTES = 8 * EPI_WAVE;    // 147 456 B  (>= NSLOT * SLOT = 131 072)
+constexpr int LDS_BYTES = fvk::EPI_LDS_BYTES;  // 147 456 B  (>= NSLOT * SLOT = 131 072)
 static_assert(LDS_BYTES >= NSLOT * SLOT, "epilogue staging must cover the ring");
 
 using fvk::GemmArgs;
 
-__device__ __forceinline__ float gelu_tanh_fast(float x) {
-    // 0.5 x (1 + tanh(u)) == x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3); exp via v_exp_f32 (exp2).
-    const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
-    const float c1 = c0 * 0.044715f;
-    const float t = __builtin_amdgcn_exp2f(x * __builtin_fmaf(x * x, c1, c0));
-    return x * __builtin_amdgcn_rcpf(1.0f + t);
-}
-
 // FP8: x and w are OCP e4m3 bytes ([M,K] / [N,K], K-contiguous); a K-step is 64 elements = the same 64-B LDS rows, and the 16 bf16 MFMAs
 // of a step become 8 v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (2x the bf16 MFMA rate; the k order inside a fragment is
 // irrelevant as long as A and B use the same one — scripts/probes/mfma_fp8_layout.hip).  The epilogue applies the dequantisation scales.
-template <int EPI, bool FP8>
+// LATE (A/B variant, gemm_impl 3): the fragment reads of a LOAD segment are waited for AFTER the barrier, at the head of the MFMA
+// segment, so LDS latency overlaps the barrier wait; the refill distance then drops from three K-steps to two (the slot a step
+// refills was read two LOAD segments earlier, i.e. those reads are retired before the barrier in front of this LOAD segment).
+template <int EPI, bool FP8, bool LATE = false>
 __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -124,8 +118,9 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     // ---- prologue: three steps in flight, step 0 landed -------------------------------------------------------------
     PP_ISSUE(0)
     PP_ISSUE(1)
-    PP_ISSUE(2)
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (!LATE) PP_ISSUE(2)
+    if (LATE) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();  // stagger
 
@@ -143,12 +138,18 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
             xf[mb][0] = *reinterpret_cast<const bf16x8*>(slot + xb0 + mb * 2048);
             xf[mb][1] = *reinterpret_cast<const bf16x8*>(slot + xb1 + mb * 2048);
         }
-        PP_ISSUE(u + 3)  // overwrites step u-1's slot: every wave finished reading it before the barrier it just passed
-        if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // step u+1 landed (this wave's pieces)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // fragments in registers before the slot can be refilled
+        if (LATE) {
+            PP_ISSUE(u + 2)  // overwrites step u-2's slot
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // step u+1 landed (this wave's pieces)
+        } else {
+            PP_ISSUE(u + 3)  // overwrites step u-1's slot: every wave finished reading it before the barrier it just passed
+            if (grp == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // step u+1 landed (this wave's pieces)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // fragments in registers before the slot can be refilled
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
+        if (LATE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // MFMA segment
         __builtin_amdgcn_s_setprio(1);
         if (FP8) {
@@ -174,7 +175,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
                         acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb][ks], xf[mb][ks], acc[nb][mb], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
-        if (grp == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // step u+1 landed (this wave's pieces)
+        if (grp == 0) {  // step u+1 landed (this wave's pieces)
+            if (LATE) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -184,94 +188,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
     if (grp == 0) __builtin_amdgcn_s_barrier();       // pairs with the trailing barrier of the staggered group
     __builtin_amdgcn_s_barrier();
 
-    // ---- epilogue: acc[nb][mb][r] = D[n = nb*32 + (r&3) + 8(r>>2) + 4hi][m = mb*32 + l31] ----------------------------
-    unsigned char* st = smem + wave * EPI_WAVE;
-    const int ncol0 = n0 + wn * 64;
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int nl = nb * 32 + 8 * g + 4 * hi;
-            float b4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias && ncol0 + nl < a.N) {
-                const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + ncol0 + nl);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) b4[e] = (float)bv[e];
-            }
-            float sb4[4] = {1.f, 1.f, 1.f, 1.f};
-            if (FP8) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sb4[e] = a.scale_b_rowwise ? (ncol0 + nl + e < a.N ? a.scale_b[ncol0 + nl + e] : 0.f) : a.scale_b[0];
-            }
-#pragma unroll
-            for (int mb = 0; mb < 4; ++mb) {
-                bf16x4 y;
-                if (FP8) {
-                    // ref: torch._scaled_mm(x_fp8, w_fp8.t(), scale_a, scale_b, out_dtype=bf16) then `out + bias` in bf16
-                    // (fastvideo/layers/quantization/fp8_config.py:141-152): two roundings
-                    const int mrow = m0 + wm * 128 + mb * 32 + l31;
-                    const float sa = a.scale_a_rowwise ? (mrow < a.M ? a.scale_a[mrow] : 0.f) : a.scale_a[0];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float y0 = (float)(bf16_t)(acc[nb][mb][4 * g + e] * (sa * sb4[e]));
-                        y[e] = a.bias ? (bf16_t)(y0 + b4[e]) : (bf16_t)y0;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = (bf16_t)(acc[nb][mb][4 * g + e] + b4[e]);
-                }
-                *reinterpret_cast<bf16x4*>(st + (mb * 32 + l31) * EPI_PITCH + nl * 2) = y;
-            }
-        }
-    // the staging region is private to this wave: program order + the compiler's lgkmcnt wait are sufficient
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int row = it * 8 + (lane >> 3), ch = lane & 7;
-        const int m = m0 + wm * 128 + row, n = ncol0 + ch * 8;
-        bf16x8 y = *reinterpret_cast<const bf16x8*>(st + row * EPI_PITCH + ch * 16);
-        if (m < a.M && n < a.N) {
-            if (EPI == FVK_EPI_GELU_TANH) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (bf16_t)gelu_tanh_fast((float)y[e]);
-            } else if (EPI == FVK_EPI_SILU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (bf16_t)silu_f32((float)y[e]);
-            } else if (EPI == FVK_EPI_DIV) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fdiv_rn((float)y[e], a.epi_scalar);
-            } else if (EPI == FVK_EPI_RESIDUAL_GATE) {
-                const bf16x8 res = ld_bf16x8(a.residual + (long)m * a.ldc + n);
-                float gt[8];
-                if (a.gate) {
-                    const float* gp = a.gate + (long)(m / a.rows_per_batch) * a.N + n;
-                    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { gt[e] = g0[e]; gt[4 + e] = g1[e]; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) gt[e] = 1.0f;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fadd_rn((float)res[e], __fmul_rn((float)y[e], gt[e]));
-            }
-            st_bf16x8(a.out + (long)m * a.ldc + n, y);
-        }
-    }
+    fvk::gemm_tile_epilogue<EPI, FP8, true>(a, acc, smem, wave, lane, m0, n0);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int EPI, bool FP8 = false>
+template <int EPI, bool FP8 = false, bool LATE = false>
 int launch(const GemmArgs& a, int batch, hipStream_t s) {
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        if (hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, FP8, LATE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) {
             fvk_set_error("fvk_gemm_bf16 (pp): cannot set dynamic LDS size %d", LDS_BYTES);
             return FVK_ERR_LAUNCH;
         }
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_pp_kernel<EPI, FP8>), dim3(a.ntm * a.ntn, batch), dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_pp_kernel<EPI, FP8, LATE>), dim3(a.ntm * a.ntn, batch), dim3(512), LDS_BYTES, s, a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -308,6 +240,15 @@ int gemm_pp_fp8_launch(GemmArgs a, int epilogue, hipStream_t s) {
 int gemm_pp_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
     a.ntm = (a.M + TM - 1) / TM;
     a.ntn = (a.N + TN - 1) / TN;
+    if (fvk::tunable(fvk::TUNE_GEMM_IMPL) == 3) {
+        switch (epilogue) {
+            case FVK_EPI_NONE: return launch<FVK_EPI_NONE, false, true>(a, batch, s);
+            case FVK_EPI_GELU_TANH: return launch<FVK_EPI_GELU_TANH, false, true>(a, batch, s);
+            case FVK_EPI_SILU: return launch<FVK_EPI_SILU, false, true>(a, batch, s);
+            case FVK_EPI_DIV: return launch<FVK_EPI_DIV, false, true>(a, batch, s);
+            default: return launch<FVK_EPI_RESIDUAL_GATE, false, true>(a, batch, s);
+        }
+    }
     switch (epilogue) {
         case FVK_EPI_NONE: return launch<FVK_EPI_NONE>(a, batch, s);
         case FVK_EPI_GELU_TANH: return launch<FVK_EPI_GELU_TANH>(a, batch, s);
