@@ -126,6 +126,24 @@ def build_wan(num_heads=12, head_dim=128, ffn_dim=8960, num_layers=30, text_dim=
     return model
 
 
+def build_causal_wan(num_heads=12, head_dim=128, ffn_dim=8960, num_layers=30, text_dim=4096, seed=0, dtype=None, modulation_std=0.0,
+                     local_attn_size=-1, sink_size=0, num_frames_per_block=3, rope_cache_policy="absolute"):
+    """Reference ``CausalWanTransformer3DModel`` (fastvideo/models/dits/causal_wanvideo.py:345-417), same deterministic init as build_wan."""
+    import torch  # noqa: F401
+    init_distributed()
+    from fastvideo.configs.models.dits.wanvideo import WanVideoArchConfig, WanVideoConfig
+    from fastvideo.models.dits.causal_wanvideo import CausalWanTransformer3DModel
+    cfg = WanVideoConfig(arch_config=WanVideoArchConfig(num_attention_heads=num_heads, attention_head_dim=head_dim, ffn_dim=ffn_dim,
+                                                        num_layers=num_layers, text_dim=text_dim, local_attn_size=local_attn_size,
+                                                        sink_size=sink_size, num_frames_per_block=num_frames_per_block,
+                                                        rope_cache_policy=rope_cache_policy))
+    model = CausalWanTransformer3DModel(config=cfg, hf_config={}).float().eval()
+    init_wan_params(model, seed=seed, modulation_std=modulation_std)
+    if dtype is not None:
+        model = model.to(dtype)
+    return model
+
+
 def init_wan_params(model, seed=0, modulation_std=0.0) -> None:
     import torch
     g = torch.Generator().manual_seed(seed)
