@@ -18,8 +18,10 @@ def rope_dim_list(head_dim: int) -> list[int]:
     return [head_dim - 4 * (head_dim // 6), 2 * (head_dim // 6), 2 * (head_dim // 6)]
 
 
-def get_rotary_pos_embed(grid_thw, head_dim: int, theta: float = 10000.0, device="cpu"):
-    key = (tuple(grid_thw), head_dim, theta, str(device))
+def get_rotary_pos_embed(grid_thw, head_dim: int, theta: float = 10000.0, device="cpu", start_frame: int = 0):
+    """``start_frame`` shifts the temporal positions (``full_grid[0] += start_frame``, rotary_embedding.py:387-388): the causal
+    model's block-by-block rollout (causal_wanvideo.py:586-598; that path keeps float64 tables, the kernels take their fp32 cast)."""
+    key = (tuple(grid_thw), head_dim, theta, str(device), int(start_frame))
     hit = _CACHE.get(key)
     if hit is not None:
         _CACHE.move_to_end(key)
@@ -28,6 +30,8 @@ def get_rotary_pos_embed(grid_thw, head_dim: int, theta: float = 10000.0, device
     assert sum(dims) == head_dim
     axes = [torch.linspace(0, n, n + 1, dtype=torch.float32)[:n] for n in grid_thw]
     grid = torch.stack(torch.meshgrid(*axes, indexing="ij"), dim=0)
+    if start_frame > 0:
+        grid[0] += start_frame
     cos_l, sin_l = [], []
     for i, dim in enumerate(dims):
         pos = grid[i].reshape(-1)
