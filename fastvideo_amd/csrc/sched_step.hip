@@ -64,7 +64,51 @@ __global__ __launch_bounds__(256) void cfg_unipc_step_kernel(StepArgs a) {
     }
 }
 
+// DMD few-step sampling (DmdDenoisingStage, CausalDMDDenosingStage): x0 prediction + re-noising to the next timestep, one pass.
+// ref: fastvideo/models/utils.py:138-175 (pred_noise_to_pred_video: fp64 arithmetic, cast back to the model-output dtype),
+//      fastvideo/models/schedulers/scheduling_flow_match_euler_discrete.py:601-635 (add_noise: fp32, type_as(noise)),
+//      call sites fastvideo/pipelines/stages/denoising.py:1382-1395, causal_denoising.py:273-310.
+struct DmdArgs {
+    const bf16_t* pred; const void* noisy; const bf16_t* noise; bf16_t* video; bf16_t* next;
+    const double* sigma_t; const float* sigma_n;  // per frame (device): fp32 table values, sigma_t widened to fp64 by the host
+    long per_frame, n;
+    int noisy_f32;
+};
+
+__global__ __launch_bounds__(256) void dmd_step_kernel(DmdArgs a) {
+#pragma clang fp contract(off)
+    const long i0 = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= a.n) return;
+    const int cnt = (a.n - i0) < 4 ? (int)(a.n - i0) : 4;
+    for (int e = 0; e < cnt; ++e) {
+        const long i = i0 + e;
+        const long f = i / a.per_frame;
+        const double x = a.noisy_f32 ? (double)((const float*)a.noisy)[i] : (double)(float)((const bf16_t*)a.noisy)[i];
+        const double pv = x - a.sigma_t[f] * (double)(float)a.pred[i];  // product and difference rounded separately in fp64
+        const bf16_t v = (bf16_t)(float)pv;                             // torch's double -> bf16 conversion goes through float
+        a.video[i] = v;
+        if (a.next) {
+            const float sn = a.sigma_n[f];
+            a.next[i] = (bf16_t)add_(mul_(sub_(1.0f, sn), (float)v), mul_(sn, (float)a.noise[i]));
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int fvk_dmd_step(const void* pred_noise, const void* noisy_latent, int noisy_is_f32, const double* sigma_t, const void* noise,
+                            const float* sigma_next, void* pred_video_out, void* next_out, long frames, long per_frame, void* stream) {
+    FVK_CHECK(pred_noise && noisy_latent && sigma_t && pred_video_out && frames > 0 && per_frame > 0, FVK_ERR_ARG,
+              "fvk_dmd_step: null pointer / empty");
+    FVK_CHECK((next_out == nullptr) == (noise == nullptr) && (next_out == nullptr) == (sigma_next == nullptr), FVK_ERR_ARG,
+              "fvk_dmd_step: noise, sigma_next and next_out come together (all NULL on the last step)");
+    DmdArgs a{(const bf16_t*)pred_noise, noisy_latent, (const bf16_t*)noise, (bf16_t*)pred_video_out, (bf16_t*)next_out, sigma_t, sigma_next,
+              per_frame, frames * per_frame, noisy_is_f32};
+    const unsigned blocks = (unsigned)((a.n + 1023) / 1024);
+    hipLaunchKernelGGL(dmd_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
 
 // coef (HOST pointer, 13 floats): g, sigma_t, cc_x, cc_m0, cc_B, c_rho0, c_rho_last, c_rk, pc_x, pc_m0, pc_B, p_rho0, p_rk
 extern "C" int fvk_cfg_unipc_step(const void* noise_text, const void* noise_uncond, const float* sample, const float* last_sample,

@@ -213,6 +213,16 @@ int fvk_cfg_unipc_step(const void* noise_text, const void* noise_uncond, const f
                        const float* m1, float* x0_out, float* sample_c_out, float* next_out, void* next_bf16_out, long n,
                        const float* coef_host, int corr_order, int pred_order, void* stream);
 
+/* DMD few-step sampling step (HBM-bound, one pass): x0 prediction and re-noising to the next timestep.
+ * ref: fastvideo/models/utils.py:138-175 (pred_noise_to_pred_video), fastvideo/models/schedulers/scheduling_flow_match_euler_discrete.py:601-635
+ *      (add_noise); call sites fastvideo/pipelines/stages/denoising.py:1382-1395 (DmdDenoisingStage), causal_denoising.py:273-310.
+ *   video = bf16( float( double(noisy) - sigma_t[f] * double(pred_noise) ) )          fp64, product and difference rounded separately
+ *   next  = bf16( (1 - sigma_next[f]) * float(video) + sigma_next[f] * float(noise) )  fp32, no contraction   (optional: last step has none)
+ * pred_noise, noise, outputs: bf16 [frames, per_frame]; noisy_latent bf16 or fp32 (noisy_is_f32); sigma_t (fp64) / sigma_next (fp32): DEVICE
+ * arrays [frames] holding the scheduler's fp32 table values.  Bit-identical to the eager reference ops. */
+int fvk_dmd_step(const void* pred_noise, const void* noisy_latent, int noisy_is_f32, const double* sigma_t, const void* noise,
+                 const float* sigma_next, void* pred_video_out, void* next_out, long frames, long per_frame, void* stream);
+
 /* ------------------------------------------------------------------ VAE tile cross-fade + pixel post-processing (HBM-bound)
  * ref: fastvideo/models/vaes/common.py:94-114 (blend_v / blend_h / blend_t: `extent` python-loop slice assignments per tile edge),
  *      fastvideo/pipelines/stages/decoding.py:210, fastvideo/entrypoints/video_generator.py:912-913.

@@ -60,13 +60,17 @@ def deprecate(*args, **kwargs):
     return None
 
 
+class BaseOutput(dict):
+    """diffusers.utils.BaseOutput stand-in (scheduling_flow_match_euler_discrete.py:28 subclasses it for its step output)."""
+
+
 def install() -> None:
     pkg = types.ModuleType("diffusers"); pkg.__path__ = []
     cu = types.ModuleType("diffusers.configuration_utils"); cu.ConfigMixin, cu.register_to_config = ConfigMixin, register_to_config
     sch = types.ModuleType("diffusers.schedulers"); sch.__path__ = []
     su = types.ModuleType("diffusers.schedulers.scheduling_utils")
     su.KarrasDiffusionSchedulers, su.SchedulerMixin, su.SchedulerOutput = KarrasDiffusionSchedulers, SchedulerMixin, SchedulerOutput
-    ut = types.ModuleType("diffusers.utils"); ut.deprecate = deprecate; ut.__path__ = []  # package: other submodules fall through to the generic stubs
+    ut = types.ModuleType("diffusers.utils"); ut.deprecate = deprecate; ut.BaseOutput = BaseOutput; ut.__path__ = []  # package: other submodules fall through to the generic stubs
     for n, m in (("diffusers", pkg), ("diffusers.configuration_utils", cu), ("diffusers.schedulers", sch),
                  ("diffusers.schedulers.scheduling_utils", su), ("diffusers.utils", ut)):
         sys.modules.setdefault(n, m)

@@ -1,7 +1,7 @@
 // Stand-alone A/B harness for the GEMM kernels behind fvk_gemm_bf16 (no Python / torch: starts in a second on a fresh GPU box).
 //   build:  hipcc --offload-arch=gfx950 -O2 scripts/probes/gemm_harness.cpp -o scripts/probes/gemm_harness.bin \
 //               -Lfastvideo_amd -lfvk_amd -Wl,-rpath,'$ORIGIN/../../fastvideo_amd'
-//   run:    scripts/probes/gemm_harness.bin [impl ...]        (gemm_impl values; the first one is the reference for bit-exactness)
+//   run:    scripts/probes/gemm_harness.bin [impl ...] [--only=<shape substring>]   (gemm_impl values; the first is the bit-exactness reference)
 // For every shape: each impl's output is compared byte-for-byte with the first impl's, then the impls are timed interleaved
 // (3 rounds x 10 launches, HIP events) and the median TFLOP/s is printed as one JSON line.
 #include <hip/hip_runtime.h>
@@ -49,7 +49,11 @@ struct Shape { const char* name; int M, N, K, epi; bool bias; };
 
 int main(int argc, char** argv) {
     std::vector<int> impls;
-    for (int i = 1; i < argc; ++i) impls.push_back(atoi(argv[i]));
+    const char* only = nullptr;  // --only=<substring>: run the matching shapes only (PMC passes)
+    for (int i = 1; i < argc; ++i) {
+        if (strncmp(argv[i], "--only=", 7) == 0) only = argv[i] + 7;
+        else impls.push_back(atoi(argv[i]));
+    }
     if (impls.empty()) impls = {0, 3, 4};
     const int S = 32760, d = 1536, F = 8960;
     const Shape shapes[] = {
@@ -69,6 +73,7 @@ int main(int argc, char** argv) {
     CK(hipEventCreate(&e1));
     int rc = 0;
     for (const Shape& sh : shapes) {
+        if (only && !strstr(sh.name, only)) continue;
         const long nx = (long)sh.M * sh.K, nw = (long)sh.N * sh.K, no = (long)sh.M * sh.N;
         uint16_t *x, *w, *bias, *res, *out, *ref;
         float* gate;
