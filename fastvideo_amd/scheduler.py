@@ -153,3 +153,68 @@ class DenoisingLoopHip:
             uncond = model(x16, negative_prompt_embeds, t) if use_cfg else None
             x, x16 = self.stepper.step(cond, x, uncond, g)
         return x
+
+
+class FlowMatchEulerTables:
+    """``FlowMatchEulerDiscreteScheduler.__init__`` tables (scheduling_flow_match_euler_discrete.py:140-158): fp32 ``timesteps`` /
+    ``sigmas`` over the 1000 training timesteps with the static shift — what the DMD stages look sigmas up in (they build the scheduler
+    with shift=8.0 and never call set_timesteps: denoising.py:1257)."""
+
+    def __init__(self, shift: float = 8.0, num_train_timesteps: int = 1000):
+        t = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy()
+        t = torch.from_numpy(t).to(dtype=torch.float32)
+        sig = t / num_train_timesteps
+        sig = shift * sig / (1 + (shift - 1) * sig)
+        self.timesteps = sig * num_train_timesteps
+        self.sigmas = sig
+        self.num_train_timesteps = num_train_timesteps
+        self._t64 = self.timesteps.double()
+
+    def index_of(self, timestep) -> torch.Tensor:
+        """``argmin(|timesteps - t|)`` in fp64 per entry of ``timestep`` (utils.py:170-172; add_noise does it in the timestep's dtype,
+        :632 — identical for the integer / table-valued timesteps the stages pass)."""
+        t = torch.as_tensor(timestep).reshape(-1).double().cpu()
+        return torch.argmin((self._t64.unsqueeze(0) - t.unsqueeze(1)).abs(), dim=1)
+
+    def warp(self, steps) -> torch.Tensor:
+        """``warp_denoising_step`` (causal_denoising.py:81-83): integer DMD steps -> the shifted schedule's timesteps."""
+        table = torch.cat((self.timesteps, torch.tensor([0], dtype=torch.float32)))
+        return table[self.num_train_timesteps - torch.as_tensor(steps, dtype=torch.long)]
+
+
+class DmdStepper:
+    """One DMD sampling step on the GPU (fvk_dmd_step): ``pred_noise_to_pred_video`` (fastvideo/models/utils.py:138-175) and, unless it
+    is the last step, ``scheduler.add_noise(pred_video, noise, next_timestep)`` (scheduling_flow_match_euler_discrete.py:601-635) —
+    the step tail of ``DmdDenoisingStage`` (denoising.py:1382-1395) and ``CausalDMDDenosingStage`` (causal_denoising.py:273-310).
+    Bit-identical to the eager reference ops (tests/test_gpu_sched.py)."""
+
+    def __init__(self, shift: float = 8.0, num_train_timesteps: int = 1000):
+        self.tables = FlowMatchEulerTables(shift, num_train_timesteps)
+
+    def step(self, pred_noise, noisy_latent, timestep, noise=None, next_timestep=None):
+        """pred_noise bf16 [F, ...] (frames first, as the stages' ``flatten(0, 1)`` of [B, T, C, H, W]); noisy_latent same shape, bf16 or fp32;
+        timestep: scalar or [F].  Returns (pred_video bf16, next_latent bf16 or None)."""
+        if pred_noise.device.type != "cuda":
+            raise RuntimeError("DmdStepper runs on a ROCm device only (no CPU fallback)")
+        if pred_noise.dtype != BF16 or noisy_latent.dtype not in (BF16, torch.float32) or noisy_latent.shape != pred_noise.shape:
+            raise ValueError("DmdStepper.step: pred_noise bf16 and noisy_latent (bf16 | fp32) of one shape expected")
+        dev = pred_noise.device
+        pred_noise, noisy_latent = pred_noise.contiguous(), noisy_latent.contiguous()
+        frames = pred_noise.shape[0]
+        per_frame = pred_noise.numel() // frames
+        expand = lambda idx: idx.expand(frames) if idx.numel() == 1 else idx
+        it = expand(self.tables.index_of(timestep))
+        if it.numel() != frames:
+            raise ValueError(f"timestep has {it.numel()} entries for {frames} frames")
+        sigma_t = self.tables.sigmas[it].double().to(dev)
+        video = torch.empty_like(pred_noise)
+        nxt = sn = None
+        if noise is not None:
+            if next_timestep is None or noise.dtype != BF16 or noise.shape != pred_noise.shape:
+                raise ValueError("DmdStepper.step: bf16 noise of the latent's shape and next_timestep come together")
+            noise = noise.to(dev).contiguous()
+            sn = self.tables.sigmas[expand(self.tables.index_of(next_timestep))].to(dev).contiguous()
+            nxt = torch.empty_like(pred_noise)
+        _lib.call("fvk_dmd_step", ops._p(pred_noise), ops._p(noisy_latent), int(noisy_latent.dtype == torch.float32), ops._p(sigma_t),
+                  ops._p(noise), ops._p(sn), ops._p(video), ops._p(nxt), frames, per_frame, ops._stream())
+        return video, nxt

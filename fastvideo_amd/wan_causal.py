@@ -213,3 +213,64 @@ class CausalWanTransformer3DModelHip(WanTransformer3DModelHip):
         return self.forward_inference(hidden_states, encoder_hidden_states, timestep, kv_cache, **kw)
 
     __call__ = forward
+
+
+class CausalDenoisingLoopHip:
+    """Block-by-block DMD rollout of ``CausalDMDDenosingStage.forward`` (fastvideo/pipelines/stages/causal_denoising.py:62-349, the T2V
+    single-expert path): for every block of ``num_frames_per_block`` latent frames, the DMD steps (model forward against the KV cache ->
+    ``pred_noise_to_pred_video`` -> re-noise to the next step with fresh noise), then one forward at ``context_noise`` over the clean block
+    to rewrite its K / V in the cache.  Step tails are one HIP kernel each (scheduler.DmdStepper, bit-identical to the eager ops); the
+    latent never leaves the GPU.  ``noise_fn(shape_btchw, dtype) -> tensor`` supplies the re-noising draws (the reference draws
+    ``torch.randn(shape, dtype=pred_video.dtype, generator=batch.generator)`` and moves it to the device, :296-300)."""
+
+    def __init__(self, transformer: CausalWanTransformer3DModelHip, dmd_denoising_steps, flow_shift: float = 8.0, warp_denoising_step: bool = False,
+                 context_noise: int = 0, sliding_window_num_frames: int = 21):
+        from .scheduler import DmdStepper
+        self.model = transformer
+        self.stepper = DmdStepper(flow_shift)
+        steps = torch.tensor(list(dmd_denoising_steps), dtype=torch.long)
+        self.timesteps = self.stepper.tables.warp(steps) if warp_denoising_step else steps  # causal_denoising.py:79-84
+        self.context_noise = int(context_noise)
+        self.sliding_window_num_frames = sliding_window_num_frames
+
+    def cache_tokens(self, frame_seqlen: int) -> int:
+        """causal_denoising.py:365-368."""
+        m = self.model
+        return (m.local_attn_size if m.local_attn_size != -1 else self.sliding_window_num_frames) * frame_seqlen
+
+    @torch.no_grad()
+    def run(self, latents, prompt_embeds, noise_fn):
+        """latents [1, C, T, H, W] (noise, fp32 or bf16) -> denoised latents, same shape and dtype."""
+        m = self.model
+        dev = m.device
+        latents = latents.to(dev).clone()
+        B, C, T, Hh, Wd = latents.shape
+        nfb = m.num_frames_per_block
+        if T % nfb:
+            raise ValueError("num_frames must be divisible by num_frames_per_block for causal DMD denoising")
+        fs = (Hh // m.patch[1]) * (Wd // m.patch[2])
+        kv = m.init_kv_cache(self.cache_tokens(fs))
+        cc = m.init_crossattn_cache()
+        prompt_embeds = prompt_embeds.to(dev)
+        start = 0
+        nsteps = len(self.timesteps)
+        for _ in range(T // nfb):
+            cur = latents[:, :, start:start + nfb]                       # [1, C, nfb, H, W]
+            noisy = cur.permute(0, 2, 1, 3, 4).flatten(0, 1).contiguous()  # frames first [nfb, C, H, W]
+            for i in range(nsteps):
+                t_cur = self.timesteps[i]
+                x_in = noisy.view(1, nfb, C, Hh, Wd).permute(0, 2, 1, 3, 4).to(BF16)
+                pred = m.forward_inference(x_in, prompt_embeds, t_cur.reshape(1, 1), kv, cc, current_start=start * fs, start_frame=start)
+                pred_f = pred.permute(0, 2, 1, 3, 4).flatten(0, 1).contiguous()
+                if i < nsteps - 1:
+                    noise = noise_fn((1, nfb, C, Hh, Wd), BF16).to(dev).flatten(0, 1)
+                    _, noisy = self.stepper.step(pred_f, noisy, t_cur, noise, self.timesteps[i + 1])
+                else:
+                    noisy, _ = self.stepper.step(pred_f, noisy, t_cur)
+            clean = noisy.view(1, nfb, C, Hh, Wd).permute(0, 2, 1, 3, 4)
+            latents[:, :, start:start + nfb] = clean
+            # context re-run: rewrite this block's K / V from the clean latent (causal_denoising.py:318-349)
+            t_ctx = torch.full((1, 1), self.context_noise, dtype=torch.long)
+            m.forward_inference(clean.to(BF16), prompt_embeds, t_ctx, kv, cc, current_start=start * fs, start_frame=start)
+            start += nfb
+        return latents

@@ -208,3 +208,40 @@ class CausalWanOracle(W.WanOracle):
             trace["norm_out"] = x.clone()
         x = self._lin(x, "proj_out")
         return W.unpatchify(x, grid, self.patch, x.shape[-1] // (pt * ph * pw))
+
+
+def causal_dmd_rollout(oracle: CausalWanOracle, latents, ctx, dmd_steps, noise_list, num_frames_per_block: int, cache_frames: int,
+                       shift: float = 8.0, context_noise: int = 0):
+    """The block loop of ``CausalDMDDenosingStage.forward`` (causal_denoising.py:205-349, T2V single-expert path, no warp) on the oracle
+    model + oracle/dmd_oracle.py.  ``noise_list``: the re-noising draws in call order, each [1, nfb, C, H, W] bf16."""
+    from oracle import dmd_oracle as D
+    ts_tab, sg_tab = D.tables(shift)
+    latents = latents.clone()
+    B, C, T, Hh, Wd = latents.shape
+    fs = (Hh // oracle.patch[1]) * (Wd // oracle.patch[2])
+    kv = oracle.init_kv_cache(1, cache_frames * fs)
+    timesteps = torch.tensor(list(dmd_steps), dtype=torch.long)
+    noise_it = iter(noise_list)
+    start = 0
+    for _ in range(T // num_frames_per_block):
+        n = num_frames_per_block
+        cur = latents[:, :, start:start + n]
+        noise_btchw = cur.permute(0, 2, 1, 3, 4)
+        for i, t_cur in enumerate(timesteps):
+            noise_latents = noise_btchw.clone()
+            t_expand = t_cur.repeat(1)
+            pred = oracle.forward_inference(cur.to(BF16), ctx, t_cur * torch.ones((1, 1), dtype=torch.long), kv, current_start=start * fs,
+                                            start_frame=start).permute(0, 2, 1, 3, 4)
+            video = D.pred_noise_to_pred_video(pred.flatten(0, 1), noise_latents.flatten(0, 1), t_expand, ts_tab, sg_tab).unflatten(0, pred.shape[:2])
+            if i < len(timesteps) - 1:
+                nxt_t = timesteps[i + 1] * torch.ones([1], dtype=torch.long)
+                noise = next(noise_it)
+                noise_btchw = D.add_noise(video.flatten(0, 1), noise.flatten(0, 1), nxt_t, ts_tab, sg_tab).unflatten(0, video.shape[:2])
+                cur = noise_btchw.permute(0, 2, 1, 3, 4)
+            else:
+                cur = video.permute(0, 2, 1, 3, 4)
+        latents[:, :, start:start + n] = cur
+        oracle.forward_inference(cur.to(BF16), ctx, torch.ones((1, 1), dtype=torch.long) * int(context_noise), kv, current_start=start * fs,
+                                 start_frame=start)
+        start += n
+    return latents

@@ -105,3 +105,25 @@ def test_refuses_cpu_and_bad_arguments(fx):
     with pytest.raises(ValueError):  # global attention keeps at most 21 latent frames (causal_wanvideo.py:131-136)
         model(case["calls"][0]["latent"].cuda(), case["ctx"].cuda(), case["calls"][0]["timestep"].cuda(), kv_cache=model.init_kv_cache(64),
               current_start=21 * fx["frame_seqlen"], start_frame=21)
+
+
+def test_causal_dmd_rollout_matches_oracle_loop(fx):
+    """CausalDenoisingLoopHip (block loop of CausalDMDDenosingStage, causal_denoising.py:205-349) vs the same loop on the oracle model with
+    the oracle DMD arithmetic and the SAME re-noising draws: 3 blocks x 3 DMD steps + context re-runs, local window with a sink frame."""
+    from fastvideo_amd.wan_causal import CausalDenoisingLoopHip
+    case = fx["cases"][1]
+    g = torch.Generator().manual_seed(21)
+    lat = torch.randn(1, 16, 6, 8, 8, generator=g)
+    steps = [1000, 750, 400]
+    draws = [torch.randn(1, 2, 16, 8, 8, generator=g).bfloat16() for _ in range(3 * 2)]
+    orc = CO.CausalWanOracle(fx["state_dict"], num_heads=fx["config"]["num_heads"], local_attn_size=case["local_attn_size"],
+                             sink_size=case["sink_size"], ln_policy="cuda")
+    with torch.no_grad():
+        ref = CO.causal_dmd_rollout(orc, lat, case["ctx"], steps, draws, 2, case["local_attn_size"])
+    model = _model(fx, case)
+    it = iter(draws)
+    loop = CausalDenoisingLoopHip(model, steps)
+    y = loop.run(lat.cuda(), case["ctx"].cuda(), lambda shape, dtype: next(it))
+    assert y.shape == lat.shape and y.dtype == lat.dtype
+    _cmp(y, ref, "causal DMD rollout", atol=1.5e-1, rtol=2e-2, mean_tol=2e-2)
+    assert next(it, None) is None  # every draw consumed, in order

@@ -119,3 +119,19 @@ def test_two_expert_loop_switches_at_the_boundary(golden_dir):
     # and the switch matters: the single-expert loop lands somewhere else
     y1 = DenoisingLoopHip(m1, 4, flow_shift=3.0, guidance_scale=4.0).run(lat.cuda(), c["ctx"].cuda(), neg.cuda(), num_steps=3).cpu()
     assert (y1 - x).abs().mean().item() > 4 * err.mean().item()
+
+
+def test_dmd_step_bit_exact_vs_reference(golden_dir):
+    """fvk_dmd_step vs the REAL pred_noise_to_pred_video / FlowMatchEulerDiscreteScheduler.add_noise outputs (tests/golden/dmd.pt)."""
+    from fastvideo_amd.scheduler import DmdStepper
+    fx = torch.load(os.path.join(golden_dir, "dmd.pt"), weights_only=False)
+    st = DmdStepper(fx["shift"])
+    for c in fx["cases"]:
+        v, n = st.step(c["pred"].cuda(), c["noisy"].cuda(), c["t"], None if c["noise"] is None else c["noise"].cuda(), c["t_next"])
+        assert v.dtype == torch.bfloat16 and torch.equal(v.cpu(), c["video"])
+        if c["noise"] is None:
+            assert n is None
+        else:
+            assert torch.equal(n.cpu(), c["next"])
+    with pytest.raises(RuntimeError):
+        st.step(fx["cases"][0]["pred"], fx["cases"][0]["noisy"], fx["cases"][0]["t"])
