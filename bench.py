@@ -153,7 +153,7 @@ def main():
         # + the coarse branch, negligible; STA: the window's share of key tokens); the timed region is the whole attention
         # (tile gather + coarse stage + block-sparse kernel + untile)
         if args.attention == "vsa":
-            m = next(iter(v for k_, v in model._vsa_cache.items() if not (isinstance(k_, tuple) and k_ and k_[0] == "sta")))
+            m = next(iter(v for k_, v in model._vsa_cache.items() if not (isinstance(k_, tuple) and k_ and isinstance(k_[0], str))))
             dens = m["topk"] / m["variable_block_sizes"].numel() * (m["S_pad"] / Skv)**2
         else:
             dens = next(iter(v for k_, v in model._vsa_cache.items() if isinstance(k_, tuple) and k_ and k_[0] == "sta"))["density"]

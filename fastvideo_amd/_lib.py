@@ -40,6 +40,7 @@ SIGNATURES = {
     "fvk_attn_sta_bf16": [C.POINTER(AttnArgs), i32, i32, i32, i32, C.POINTER(C.c_int32), vp],
     "fvk_vsa_build_metadata_host": [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "fvk_gather_rows_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, vp],
+    "fvk_gather_rows_strided_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
     "fvk_block_mean_bf16": [vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, vp],
     "fvk_topk_mask": [vp, i32, vp, i32, i32, i32, vp],
     "fvk_map_to_index": [vp, vp, vp, i32, i32, vp],

@@ -51,13 +51,13 @@ namespace {
 
 // dst[b, di[i], :] = src[b, si[i], :]; one 16-B chunk per thread.
 __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* src, bf16_t* dst, const int32_t* si, const int32_t* di,
-                                                          int n, int chunks_per_row, long sbs, long dbs) {
+                                                          int n, int chunks_per_row, long sbs, long dbs, long srs, long drs) {
     const int b = blockIdx.y;
     const long total = (long)n * chunks_per_row;
     for (long c = blockIdx.x * 256L + threadIdx.x; c < total; c += (long)gridDim.x * 256L) {
         const int i = (int)(c / chunks_per_row), ch = (int)(c % chunks_per_row);
         const long s = si ? si[i] : i, d = di ? di[i] : i;
-        st_bf16x8(dst + b * dbs + d * chunks_per_row * 8L + ch * 8, ld_bf16x8(src + b * sbs + s * chunks_per_row * 8L + ch * 8));
+        st_bf16x8(dst + b * dbs + d * drs + ch * 8, ld_bf16x8(src + b * sbs + s * srs + ch * 8));
     }
 }
 
@@ -308,7 +308,24 @@ extern "C" int fvk_gather_rows_bf16(const void* src, void* dst, const int32_t* s
     if (B <= 0 || n <= 0) return FVK_OK;
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * row_elems / 8), B), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)src, (bf16_t*)dst, src_index, dst_index, n, row_elems / 8, src_batch_stride,
-                       dst_batch_stride);
+                       dst_batch_stride, (long)row_elems, (long)row_elems);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+extern "C" int fvk_gather_rows_strided_bf16(const void* src, void* dst, const int32_t* src_index, const int32_t* dst_index, int B, int n,
+                                            int row_elems, long src_row_stride, long dst_row_stride, long src_batch_stride,
+                                            long dst_batch_stride, void* stream) {
+    FVK_CHECK(src && dst, FVK_ERR_ARG, "fvk_gather_rows_strided_bf16: null pointer");
+    FVK_CHECK(row_elems > 0 && row_elems % 8 == 0 && src_row_stride % 8 == 0 && dst_row_stride % 8 == 0 && src_row_stride >= row_elems &&
+                  dst_row_stride >= row_elems,
+              FVK_ERR_ARG, "fvk_gather_rows_strided_bf16: row_elems=%d and the row strides must be multiples of 8, strides >= row", row_elems);
+    FVK_CHECK((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0, FVK_ERR_ARG,
+              "fvk_gather_rows_strided_bf16: 16-byte aligned pointers expected");
+    if (B <= 0 || n <= 0) return FVK_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long)n * row_elems / 8), B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)src, (bf16_t*)dst, src_index, dst_index, n, row_elems / 8, src_batch_stride,
+                       dst_batch_stride, src_row_stride, dst_row_stride);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }

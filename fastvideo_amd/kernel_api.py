@@ -109,22 +109,53 @@ def video_sparse_attn(q, k, v, variable_block_sizes, q_variable_block_sizes, top
     vbs = variable_block_sizes.to(device=q.device, dtype=torch.int32)
     qvbs = q_variable_block_sizes.to(device=q.device, dtype=torch.int32)
 
+    return _vsa_forward(q, k, v, vbs, qvbs, topk, compress_attn_weight, "bhsd", return_intermediates)
+
+
+def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=False):
+    """The VSA composition (fastvideo_kernel/ops.py:108-128) on tensors of either layout: "bhsd" (the package API) or "bshd" (what the model
+    host holds — strides go to the kernels, nothing is transposed or copied)."""
+    block_elements = 64
+    if layout == "bhsd":
+        batch, heads, q_seq_len, dim = q.shape
+        kv_seq_len = k.shape[2]
+    else:
+        batch, q_seq_len, heads, dim = q.shape
+        kv_seq_len = k.shape[1]
+    q_num_blocks, kv_num_blocks = q_seq_len // block_elements, kv_seq_len // block_elements
     # compression branch (ops.py:108-118): block means, coarse scores (bf16, /sqrt(D)), coarse attention
-    q_c = ops.block_mean(q, qvbs, block_elements)
-    k_c = ops.block_mean(k, vbs, block_elements)
-    v_c = ops.block_mean(v, vbs, block_elements)
+    q_c = ops.block_mean(q, qvbs, block_elements, layout=layout)
+    k_c = ops.block_mean(k, vbs, block_elements, layout=layout)
+    v_c = ops.block_mean(v, vbs, block_elements, layout=layout)
     scores = ops.gemm_batched(q_c.view(batch * heads, q_num_blocks, dim), k_c.view(batch * heads, kv_num_blocks, dim),
                               epilogue=ops.EPI_DIV, scalar=dim**0.5).view(batch, heads, q_num_blocks, kv_num_blocks)
     out_c = ops.attn_dense(q_c, k_c, v_c, scale=dim**-0.5, layout="bhsd")
     # sparse branch (ops.py:120-128): exact top-k mask -> ascending index lists -> block-sparse attention
     mask = ops.topk_mask(scores, min(int(topk), kv_num_blocks))
     idx, num = ops.map_to_index(mask)
-    out_s = ops.attn_block_sparse(q, k, v, idx, num, vbs, layout="bhsd")
-    out = ops.vsa_combine(out_c, out_s, compress_attn_weight, block_elements, layout="bhsd")
+    out_s = ops.attn_block_sparse(q, k, v, idx, num, vbs, layout=layout)
+    out = ops.vsa_combine(out_c, out_s, gate, block_elements, layout=layout)
     if return_intermediates:
         return out, dict(q_c=q_c, k_c=k_c, v_c=v_c, scores=scores, mask=mask, q2k_idx=idx, q2k_num=num, out_c=out_c,
                          out_s=out_s)
     return out
+
+
+def video_sparse_attn_bshd(q, k, v, variable_block_sizes, q_variable_block_sizes, topk, block_size=64, compress_attn_weight=None):
+    """ref: fastvideo_kernel ``video_sparse_attn_bshd`` (fastvideo-kernel/python/fastvideo_kernel/__init__.py:40-62): q,k,v(,gate)
+    [B,S_pad,H,D] bf16, tile-major, zero padded.  64-token blocks (the reference's bshd entry serves 128 / 256 only on its hardware)."""
+    if isinstance(block_size, (tuple, list)):
+        block_size = block_size[0] * block_size[1] * block_size[2]
+    if block_size != 64:
+        raise ValueError(f"fastvideo_amd implements the 64-token VSA block only (got block_elements={block_size})")
+    if q.shape[1] % 64 or k.shape[1] % 64 or v.shape[1] != k.shape[1]:
+        raise ValueError("q_seq_len and kv_seq_len must be divisible by block_elements=64 and k, v must agree")
+    _check_bf16(q, k, v)
+    vbs = variable_block_sizes.to(device=q.device, dtype=torch.int32)
+    qvbs = q_variable_block_sizes.to(device=q.device, dtype=torch.int32)
+    if vbs.numel() != k.shape[1] // 64 or qvbs.numel() != q.shape[1] // 64:
+        raise ValueError("variable block size lists do not match the block counts")
+    return _vsa_forward(q, k, v, vbs, qvbs, topk, compress_attn_weight, "bshd")
 
 
 _STA_CANVAS = {"30x48x80": (30, 48, 80), "36x48x48": (36, 48, 48), "18x48x80": (18, 48, 80)}
@@ -193,7 +224,7 @@ def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3)):
 
 
 __all__ = [
-    "sliding_tile_attention", "video_sparse_attn", "block_sparse_attn", "block_sparse_attn_from_indices", "VSA_TILE_SIZE",
+    "sliding_tile_attention", "video_sparse_attn", "video_sparse_attn_bshd", "block_sparse_attn", "block_sparse_attn_from_indices", "VSA_TILE_SIZE",
     "get_tile_partition_indices", "get_reverse_tile_partition_indices", "construct_variable_block_sizes",
     "get_non_pad_index", "build_vsa_metadata", "sliding_tile_block_lists",
 ]

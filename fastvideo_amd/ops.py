@@ -409,20 +409,28 @@ def vsa_build_metadata_host(dit_seq_shape, tile_size=(4, 4, 4)):
                 non_pad_index=npi, untile_combined_index=unt, num_tiles=tuple(nt))
 
 
-def gather_rows(src, n_dst_rows, src_index=None, dst_index=None, zero_init=False):
-    """src bf16 [B, Ns, ...row...] -> dst [B, n_dst_rows, ...row...]; dst[:, dst_index[i]] = src[:, src_index[i]]."""
+def gather_rows(src, n_dst_rows, src_index=None, dst_index=None, zero_init=False, out=None):
+    """src bf16 [B, Ns, ...row...] -> dst [B, n_dst_rows, ...row...]; dst[:, dst_index[i]] = src[:, src_index[i]].
+    src may be a view whose rows ([...row...] contiguous) are a fixed stride apart (a column block of the fused QKV buffer); ``out`` = a
+    preallocated contiguous destination (e.g. a persistent tile buffer whose pad rows were zeroed once)."""
     _chk(src, BF16, "src")
-    src = src.contiguous()
     B = src.shape[0]
     row = src[0, 0].numel()
-    alloc = torch.zeros if zero_init else torch.empty
-    dst = alloc((B, n_dst_rows, *src.shape[2:]), dtype=BF16, device=src.device)
+    inner_ok = src[0, 0].is_contiguous() and (B == 1 or src.stride(0) % 8 == 0) and src.stride(1) % 8 == 0 and src.stride(1) >= row
+    if not inner_ok:
+        src = src.contiguous()
+    if out is None:
+        alloc = torch.zeros if zero_init else torch.empty
+        out = alloc((B, n_dst_rows, *src.shape[2:]), dtype=BF16, device=src.device)
+    elif out.shape != (B, n_dst_rows, *src.shape[2:]) or out.dtype != BF16 or not out.is_contiguous():
+        raise RuntimeError("gather_rows: `out` must be a contiguous bf16 tensor of the destination shape")
     any_index = src_index if src_index is not None else dst_index
     n = n_dst_rows if any_index is None else any_index.numel()
     si = None if src_index is None else _chk(src_index, torch.int32, "src_index")
     di = None if dst_index is None else _chk(dst_index, torch.int32, "dst_index")
-    _lib.call("fvk_gather_rows_bf16", _p(src), _p(dst), _p(si), _p(di), B, n, row, src.stride(0), dst.stride(0), _stream())
-    return dst
+    _lib.call("fvk_gather_rows_strided_bf16", _p(src), _p(out), _p(si), _p(di), B, n, row, src.stride(1), row, src.stride(0), out.stride(0),
+              _stream())
+    return out
 
 
 def block_mean(x, vbs, block=64, layout="bhsd"):

@@ -157,6 +157,14 @@ class WanTransformer3DModelHip:
             self._vsa_cache[("sta",) + key] = m
         return m
 
+    def _tile_bufs(self, S_pad, h, n):
+        key = ("tilebuf", S_pad, h)
+        bufs = self._vsa_cache.get(key)
+        if bufs is None or len(bufs) < n:
+            bufs = [torch.zeros((1, S_pad, h, self.D), dtype=BF16, device=self.device) for _ in range(n)]
+            self._vsa_cache[key] = bufs
+        return bufs
+
     def _attn_local(self, q, k, v, kv_len, grid, gate=None):
         if self.attn_events is None or self.attention == "dense":
             return self._attn_local_impl(q, k, v, kv_len, grid, gate)
@@ -184,16 +192,18 @@ class WanTransformer3DModelHip:
             return o
         if self.attention == "vsa":
             # ref: VideoSparseAttentionImpl.preprocess_qkv / forward / postprocess_output (video_sparse_attn.py:254-342)
+            # Everything stays [1, S_pad, h, D] ("bshd"): the kernels take strides, so there is no transpose / contiguous copy; the four
+            # tile buffers are allocated (zeroed) once per shape and reused by every layer — pad rows are never written, so they stay
+            # zero (the reference keeps one such `tile_buf` per step too, video_sparse_attn.py:254-264)
             m = self._vsa_meta(grid)
             S = kv_len
-            tile = lambda t: ops.gather_rows(t[:, :S].contiguous(), m["S_pad"], m["tile_partition_indices"], m["non_pad_index"],
-                                             zero_init=True).transpose(1, 2)  # [1,h,S_pad,D] view (bhsd semantics)
-            tq, tk, tv = tile(q4), tile(k4), tile(v4)
-            tg = tile(gate.unsqueeze(0)) if gate is not None else None
+            bufs = self._tile_bufs(m["S_pad"], q.shape[1], 4 if gate is not None else 3)
+            tile = lambda t, j: ops.gather_rows(t[:, :S], m["S_pad"], m["tile_partition_indices"], m["non_pad_index"], out=bufs[j])
+            tq, tk, tv = tile(q4, 0), tile(k4, 1), tile(v4, 2)
+            tg = tile(gate.unsqueeze(0), 3) if gate is not None else None
             vbs = m["variable_block_sizes"]
-            o = kernel_api.video_sparse_attn(tq.contiguous(), tk.contiguous(), tv.contiguous(), vbs, vbs, m["topk"], (4, 4, 4),
-                                             None if tg is None else tg.contiguous())
-            o = ops.gather_rows(o.transpose(1, 2).contiguous(), S, m["untile_combined_index"], None)
+            o = kernel_api.video_sparse_attn_bshd(tq, tk, tv, vbs, vbs, m["topk"], 64, tg)
+            o = ops.gather_rows(o, S, m["untile_combined_index"], None)
             if q.shape[0] != S:
                 o = torch.cat([o, o.new_zeros((1, q.shape[0] - S, *o.shape[2:]))], 1)
             return o[0]
@@ -203,8 +213,9 @@ class WanTransformer3DModelHip:
         # block-sparse kernel — which serves any canvas (the reference kernels hard-code three).
         m = self._sta_meta(grid, q.shape[1])
         S = kv_len
-        tile = lambda t: ops.gather_rows(t[:, :S].contiguous(), m["S_pad"], m["perm"], m["non_pad"], zero_init=True)  # [1,S_pad,h,D]
-        o = ops.attn_block_sparse(tile(q4), tile(k4), tile(v4), m["q2k_idx"], m["q2k_num"], m["block_sizes"], scale=self.D**-0.5,
+        bufs = self._tile_bufs(m["S_pad"], q.shape[1], 3)
+        tile = lambda t, j: ops.gather_rows(t[:, :S], m["S_pad"], m["perm"], m["non_pad"], out=bufs[j])  # [1,S_pad,h,D]
+        o = ops.attn_block_sparse(tile(q4, 0), tile(k4, 1), tile(v4, 2), m["q2k_idx"], m["q2k_num"], m["block_sizes"], scale=self.D**-0.5,
                                   layout="bshd", q_block=m["q_block"])
         o = ops.gather_rows(o, S, m["untile"], None)
         if q.shape[0] != S:

@@ -161,6 +161,11 @@ int fvk_vsa_build_metadata_host(int T, int H, int W, int tt, int th, int tw, int
  * untile(): dst_index=NULL, src_index=untile_combined.  ref: video_sparse_attn.py:170-189, 285-290. */
 int fvk_gather_rows_bf16(const void* src, void* dst, const int32_t* src_index, const int32_t* dst_index, int B, int n,
                          int row_elems, long src_batch_stride, long dst_batch_stride, void* stream);
+/* same with explicit row strides (elements, multiples of 8): gathers straight out of a column block of the fused QKV(+gate) buffer
+ * (src_row_stride = 3d or 4d) into a persistent, pre-zeroed tile buffer — no `.contiguous()` copy, no per-layer memset. */
+int fvk_gather_rows_strided_bf16(const void* src, void* dst, const int32_t* src_index, const int32_t* dst_index, int B, int n,
+                                 int row_elems, long src_row_stride, long dst_row_stride, long src_batch_stride, long dst_batch_stride,
+                                 void* stream);
 /* x [B,S_pad,H,D] with strides -> out [B,H,Nblk,D] bf16 = bf16(fp32 sum over 64 rows / vbs[blk]). */
 int fvk_block_mean_bf16(const void* x, void* out, const int32_t* vbs, int B, int H, int n_blocks, int block, int D,
                         long x_bs, long x_ss, long x_hs, void* stream);
