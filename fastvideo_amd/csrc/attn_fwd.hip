@@ -56,8 +56,13 @@ template <int DK> struct KGeom {
 // two compute waves, and 35 DMA wave-instructions per KV tile at ~60 cycles of issue each cost them more than the tile's MFMAs;
 // NL = 2 moves the whole tile stream to two extra waves that do nothing else (producer / consumer specialisation), synchronised by
 // the same one barrier per tile.
-template <int NW, int MODE, int DK, int NL>
-__global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 2 ? 1 : 2)) void attn_fwd_kernel(fvk_attn_args a, ModeArgs ma) {
+// PAIRS = 2 (block-sparse VSA lists, NW = NL = 2): ONE 8-wave workgroup per CU serves TWO 64-row query blocks, each with its own KV
+// list, its own pair of compute waves + pair of loader waves and its own double-buffered stage; waves 0-3 are the compute waves and
+// 4-7 the loaders, so the in-order wave -> SIMD placement puts exactly one compute and one loader wave on every SIMD.  (Two
+// independent 4-wave workgroups per CU — the PAIRS = 1 form — land their compute waves on the SAME two SIMDs and leave the other
+// two matrix pipes to the loaders.)  The two pairs share the per-tile barrier and run max(list lengths) iterations.
+template <int NW, int MODE, int DK, int NL, int PAIRS = 1>
+__global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1 : 2)) void attn_fwd_kernel(fvk_attn_args a, ModeArgs ma) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the body uses gfx950 LDS-DMA builtins the host pass cannot parse
     constexpr int K_ROW_BYTES = KGeom<DK>::ROW_BYTES, KC = KGeom<DK>::CHUNKS, K_TILE_BYTES = KGeom<DK>::TILE_BYTES;
     constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES, KS = DK / 16;
@@ -69,10 +74,18 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 2 ? 1 : 2)) void attn
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (scalar branches, SGPR M0 base)
     const int l31 = lane & 31, hi = lane >> 5;
-    const int nqb = (a.Sq + BMQ - 1) / BMQ;
-    const int qb = blockIdx.x % nqb;
-    const int h = (blockIdx.x / nqb) % a.H;
-    const int b = blockIdx.x / (nqb * a.H);
+    static_assert(PAIRS == 1 || (MODE == MODE_BLOCKS && NL > 0), "query-block pairs: block-sparse lists with loader waves only");
+    constexpr int NCW = PAIRS * NW;  // compute waves come first, loader waves after
+    const bool compute = wave < NCW;                                 // this wave owns 32 query rows
+    const int pr = PAIRS == 1 ? 0 : (compute ? wave / NW : (wave - NCW) / (NL ? NL : 1));  // which query block of the workgroup
+    const int lw = compute ? wave % NW : 0;                          // index among the pair's compute waves
+    const int nqb = (a.Sq + BMQ - 1) / BMQ;                          // query blocks (= KV lists) per head
+    const int nwg = (nqb + PAIRS - 1) / PAIRS;                       // workgroups per head
+    const int qb = (blockIdx.x % nwg) * PAIRS + pr;
+    const bool pair_ok = PAIRS == 1 || qb < nqb;
+    const int h = (blockIdx.x / nwg) % a.H;
+    const int b = blockIdx.x / (nwg * a.H);
+    unsigned char* const smem_p = smem + pr * (2 * STAGE_BYTES);     // this pair's double-buffered stage
 
     const bf16_t* qp = (const bf16_t*)a.q + (long)b * a.q_bs + (long)h * a.q_hs;
     const bf16_t* kp = (const bf16_t*)a.k + (long)b * a.k_bs + (long)h * a.k_hs;
@@ -86,8 +99,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 2 ? 1 : 2)) void attn
     if (MODE == MODE_DENSE) {
         n_tiles = (a.Skv + 63) >> 6;
     } else if (MODE == MODE_BLOCKS) {
-        const long meta = ((long)b * a.H + h) * nqb + qb;
-        n_tiles = ma.q2k_num[meta];
+        const long meta = ((long)b * a.H + h) * nqb + (pair_ok ? qb : 0);
+        n_tiles = pair_ok ? ma.q2k_num[meta] : 0;
         blk_list = ma.q2k_idx + meta * ma.max_kv;
     } else {
         const int qt = (qb * BMQ) / ma.tile_tokens;
@@ -134,9 +147,9 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 2 ? 1 : 2)) void attn
     };
 
     // ---- Q fragments (B operand): row q0 + l31, d = 16*ks + 8*hi .. +8 -----------------------------------
-    const int q0 = qb * BMQ + (wave < NW ? wave : 0) * 32;  // (loader waves own no rows)
+    const int q0 = qb * BMQ + lw * 32;  // (loader waves own no rows)
     int qrow = q0 + l31;
-    const bool q_ok = qrow < a.Sq;
+    const bool q_ok = pair_ok && qrow < a.Sq;
     qrow = q_ok ? qrow : a.Sq - 1;
     bf16x8 qf[KS];
 #pragma unroll
@@ -152,9 +165,8 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 2 ? 1 : 2)) void attn
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vtp, 0, (int)(256L * a.Skv_pad), 0x00020000);
     constexpr int NI = NL ? NL : NW;                // waves that issue DMA
     constexpr int N_DMA = (KC + 18 + NI - 1) / NI;  // wave-instructions per issuing wave per tile
-    const bool loader = NL ? wave >= NW : true;     // this wave issues DMA
-    const bool compute = wave < NW;                 // this wave owns 32 query rows
-    const int iw = NL ? wave - NW : wave;           // index among the issuing waves
+    const bool loader = NL ? wave >= NCW : true;    // this wave issues DMA
+    const int iw = NL ? (wave - NCW) % NL : wave;   // index among the pair's issuing waves
     int dma_voff[N_DMA];
 #pragma unroll
     for (int i = 0; i < N_DMA; ++i) {
@@ -201,19 +213,25 @@ __global__ __launch_bounds__((NW + NL) * 64, ((NW + NL) == 2 ? 1 : 2)) void attn
     int kv0 = 0, valid = 64, kv0_n = 0, valid_n = 64;
     if (n_tiles > 0) {
         get_tile(0, kv0, valid);
-        if (loader) ISSUE_DMA(kv0, smem)
+        if (loader) ISSUE_DMA(kv0, smem_p)
     }
     __syncthreads();
 
-    for (int j = 0; j < n_tiles; ++j) {
-        const unsigned char* cur = smem + (j & 1) * STAGE_BYTES;
+    int n_loop = n_tiles;  // the workgroup's barrier count: the longer of the two lists
+    if (PAIRS == 2 && MODE == MODE_BLOCKS) {
+        const int qo = qb ^ 1;
+        const int n_other = qo < nqb ? ma.q2k_num[((long)b * a.H + h) * nqb + qo] : 0;
+        n_loop = n_other > n_loop ? n_other : n_loop;
+    }
+    for (int j = 0; j < n_loop; ++j) {
+        const unsigned char* cur = smem_p + (j & 1) * STAGE_BYTES;
         const bool more = (j + 1) < n_tiles;
         if (more) {
             get_tile(j + 1, kv0_n, valid_n);
-            unsigned char* nxt = smem + ((j + 1) & 1) * STAGE_BYTES;
+            unsigned char* nxt = smem_p + ((j + 1) & 1) * STAGE_BYTES;
             if (loader) ISSUE_DMA(kv0_n, nxt)
         }
-        if (compute) {
+        if (compute && j < n_tiles) {
         // ---- S^T = K · Q^T  (2 key blocks of 32 x KS k-steps of 16): one software-pipelined stream, every ds_read_b128 issued FD MFMAs
         // ahead of its use (sched_group_barrier pins the 1 MFMA : 1 read interleave; left alone hipcc emits read / wait / MFMA and
         // every MFMA eats an LDS round trip) --------------------------------------------------------------------------------------
@@ -349,21 +367,23 @@ int check_common(const fvk_attn_args* a, const char* fn) {
     return FVK_OK;
 }
 
-template <int NW, int MODE, int DK = 128, int NL = 0>
+template <int NW, int MODE, int DK = 128, int NL = 0, int PAIRS = 1>
 int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
     constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES;
+    constexpr int LDS = PAIRS * 2 * STAGE_BYTES;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE, DK, NL>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * STAGE_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE, DK, NL, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+            hipSuccess) {
             fvk_set_error("fvk_attn: cannot set dynamic LDS size");
             return FVK_ERR_LAUNCH;
         }
         configured = true;
     }
     const int bmq = NW * 32;
-    const long nblk = (long)((a->Sq + bmq - 1) / bmq) * a->H * a->B;
-    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE, DK, NL>), dim3((unsigned)nblk), dim3((NW + NL) * 64), 2 * STAGE_BYTES, s, *a, ma);
+    const long nlists = (a->Sq + bmq - 1) / bmq;
+    const long nblk = ((nlists + PAIRS - 1) / PAIRS) * a->H * a->B;
+    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE, DK, NL, PAIRS>), dim3((unsigned)nblk), dim3(PAIRS * (NW + NL) * 64), LDS, s, *a, ma);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -406,7 +426,10 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     // one workgroup per list: 2 waves (64 rows, the VSA block) or 4 waves (128 rows sharing every K/V tile: sliding-tile windows,
     // where all query blocks of a tile attend the same KV blocks)
     if (q_block == 128) return launch<4, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
-    return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);  // 2 compute + 2 loader waves
+    // 64-row lists (the VSA block): two lists per 8-wave workgroup, each with 2 compute + 2 loader waves ("attn_impl" 50 = the former
+    // one-list 4-wave workgroups, two per CU, for A/B)
+    if (fvk::tunable(fvk::TUNE_ATTN_IMPL) == 50) return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);
+    return launch<2, MODE_BLOCKS, 128, 2, 2>(a, ma, (hipStream_t)stream);
 }
 
 extern "C" int fvk_attn_sta_bf16(const fvk_attn_args* a, int ct, int ch, int cw, int tile_tokens, const int32_t* win_host,
