@@ -63,6 +63,12 @@ int main(int argc, char** argv) {
         {"out[S,1536,1536]+resgate", S, d, d, FVK_EPI_RESIDUAL_GATE, true},
         {"ffn_in[S,8960,1536]+gelu", S, F, d, FVK_EPI_GELU_TANH, true},
         {"ffn_out[S,1536,8960]+resgate", S, d, F, FVK_EPI_RESIDUAL_GATE, true},
+        {"sp8_qkv[4095,4608,1536]+bias", 4095, 3 * d, d, FVK_EPI_NONE, true},
+        {"sp8_out[4095,1536,1536]+resgate", 4095, d, d, FVK_EPI_RESIDUAL_GATE, true},
+        {"sp8_ffn_in[4095,8960,1536]+gelu", 4095, F, d, FVK_EPI_GELU_TANH, true},
+        {"sp8_ffn_out[4095,1536,8960]+resgate", 4095, d, F, FVK_EPI_RESIDUAL_GATE, true},
+        {"sp4_out[8190,1536,1536]+resgate", 8190, d, d, FVK_EPI_RESIDUAL_GATE, true},
+        {"sp4_ffn_out[8190,1536,8960]+resgate", 8190, d, F, FVK_EPI_RESIDUAL_GATE, true},
         {"4k^3", 4096, 4096, 4096, FVK_EPI_NONE, false},
         {"8k^3", 8192, 8192, 8192, FVK_EPI_NONE, false},
     };
@@ -107,7 +113,7 @@ int main(int argc, char** argv) {
             printf(", \"impl%d_mismatch\": %ld", impls[k], bad);
             if (bad) { printf(", \"impl%d_first\": [%ld, %ld]", impls[k], first / sh.N, first % sh.N); rc = 1; }
         }
-        const int rounds = 3, reps = sh.M >= 4096 ? 10 : 3;
+        const int rounds = 3, reps = sh.M >= 4000 ? 10 : 3;
         std::vector<std::vector<float>> ms(impls.size());
         for (int r = 0; r < rounds; ++r)
             for (size_t k = 0; k < impls.size(); ++k) {

@@ -15,6 +15,7 @@ run cfg1 --config cfg1 --steps 5 --warmup 2
 run cfg5_dense --config cfg5 --steps 2 --warmup 1
 run cfg5_vsa_fp8 --config cfg5 --attention vsa --quant fp8 --steps 2 --warmup 1
 run cfg4 --config cfg4 --steps 2 --warmup 1
+timeout 300 python scripts/causal_bench.py > "$OUT/causal_480p.log" 2>&1; echo "causal rc=$? $(tail -1 "$OUT/causal_480p.log" | cut -c1-500)"
 timeout 300 python scripts/vae_bench.py > "$OUT/vae_480p.log" 2>&1; echo "vae480 rc=$? $(tail -1 "$OUT/vae_480p.log" | cut -c1-300)"
 timeout 300 python scripts/vae_bench.py --frames 33 --h 90 --w 160 > "$OUT/vae_720p.log" 2>&1; echo "vae720 rc=$? $(tail -1 "$OUT/vae_720p.log" | cut -c1-300)"
 # PMC passes of the bf16 GEMM kernel at the FFN-out shape (separate runs, kernel-trace + pmc only)
