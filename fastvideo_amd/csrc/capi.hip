@@ -32,7 +32,7 @@ extern "C" int fvk_device_arch(char* buf, int len) {
 
 // ---- tunables (A/B switches for measurements; defaults = shipped configuration) ---------------------------------------
 static int g_tunables[fvk::TUNE_COUNT] = {0};
-static const char* const g_tunable_names[fvk::TUNE_COUNT] = {"gemm_impl", "attn_impl", "vae_conv_impl", nullptr};
+static const char* const g_tunable_names[fvk::TUNE_COUNT] = {"gemm_impl", "attn_impl", "vae_conv_impl", "vsa_impl", nullptr};
 
 int fvk::tunable(int id) { return (id >= 0 && id < fvk::TUNE_COUNT) ? g_tunables[id] : 0; }
 

@@ -34,7 +34,7 @@ bool gemm_ph_eligible(const GemmArgs& a);
 int gemm_ph_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
 
 // capi.hip: integer knobs for within-process A/B measurements (fvk_set_tunable); defaults are the shipped configuration.
-enum Tunable { TUNE_GEMM_IMPL = 0, TUNE_ATTN_IMPL = 1, TUNE_VAE_CONV_IMPL = 2, TUNE_COUNT = 8 };
+enum Tunable { TUNE_GEMM_IMPL = 0, TUNE_ATTN_IMPL = 1, TUNE_VAE_CONV_IMPL = 2, TUNE_VSA_IMPL = 3, TUNE_COUNT = 8 };
 int tunable(int id);
 
 }  // namespace fvk

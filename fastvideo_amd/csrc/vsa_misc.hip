@@ -6,7 +6,7 @@
 
 #include <vector>
 
-#include "fvk_common.h"
+#include "gemm_common.h"
 
 // ------------------------------------------------------------------------------------------------
 // host-side VSA metadata (pure integer; ref: fastvideo/attention/backends/video_sparse_attn.py:31-114, 226)
@@ -166,6 +166,78 @@ __global__ __launch_bounds__(256) void topk_mask_kernel(const void* scores, int 
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int idx = tid * VPT + i;
+        if (idx < n) {
+            bool sel = v[i] > thr;
+            if (v[i] == thr) {
+                ++before;  // inclusive cumulative count, as tl.cumsum
+                sel = before <= need;
+            }
+            mask[row * n + idx] = sel ? 1 : 0;
+        }
+    }
+}
+
+// Same algorithm with ONE WAVE per row (4 rows per workgroup): lane l owns the contiguous segment [l*VPT, (l+1)*VPT), every count is a
+// wave reduction (DPP shuffles, no LDS, no barrier) — the block-per-row form above spends its time in 2 x 34 workgroup barriers per row
+// (103 us per layer at 12 x 624 rows of 624; 25 920 rows of 2160 at 129f x 720p).  Identical comparisons in identical fp32 arithmetic,
+// identical tie rule => identical masks.
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int VPT>
+__global__ __launch_bounds__(256) void topk_mask_wave_kernel(const void* scores, int is_fp32, uint8_t* mask, int rows, int n, int topk) {
+    const int lane = threadIdx.x & 63;
+    const long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[VPT];
+    float lo = INFINITY, hi = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = lane * VPT + i;
+        if (idx < n) {
+            v[i] = is_fp32 ? ((const float*)scores)[row * n + idx] : (float)((const bf16_t*)scores)[row * n + idx];
+            if (v[i] > -INFINITY) lo = fminf(lo, v[i]);
+            hi = fmaxf(hi, v[i]);
+        } else {
+            v[i] = -INFINITY;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+    }
+    lo = fminf(lo, hi);
+    for (int it = 0; it < 32; ++it) {
+        const float mid = (lo + hi) * 0.5f;
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < VPT; ++i) c += (lane * VPT + i < n && v[i] >= mid) ? 1 : 0;
+        c = wave_sum_i(c);
+        if (c >= topk) lo = mid; else hi = mid;
+    }
+    const float thr = lo;
+    int n_above = 0, n_at = 0;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const bool ok = lane * VPT + i < n;
+        n_above += (ok && v[i] > thr) ? 1 : 0;
+        n_at += (ok && v[i] == thr) ? 1 : 0;
+    }
+    n_above = wave_sum_i(n_above);
+    const int need = topk - n_above;
+    int incl = n_at;  // inclusive prefix over lanes of the "== thr" counts
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    int before = incl - n_at;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int idx = lane * VPT + i;
         if (idx < n) {
             bool sel = v[i] > thr;
             if (v[i] == thr) {
@@ -347,6 +419,17 @@ extern "C" int fvk_topk_mask(const void* scores, int scores_is_fp32, uint8_t* ma
     if (rows <= 0) return FVK_OK;
     if (topk > n) topk = n;
     hipStream_t s = (hipStream_t)stream;
+    if (fvk::tunable(fvk::TUNE_VSA_IMPL) != 1) {  // shipped: one wave per row ("vsa_impl" 1 = the block-per-row kernel, A/B)
+        const int wv = (n + 63) / 64;
+#define FVK_TOPKW_CASE(V)                                                                                                             \
+    if (wv <= V) {                                                                                                                    \
+        hipLaunchKernelGGL((topk_mask_wave_kernel<V>), dim3((rows + 3) / 4), dim3(256), 0, s, scores, scores_is_fp32, mask, rows, n, topk); \
+        FVK_LAUNCH_CHECK();                                                                                                           \
+        return FVK_OK;                                                                                                                \
+    }
+        FVK_TOPKW_CASE(4) FVK_TOPKW_CASE(8) FVK_TOPKW_CASE(16) FVK_TOPKW_CASE(32) FVK_TOPKW_CASE(64) FVK_TOPKW_CASE(128)
+#undef FVK_TOPKW_CASE
+    }
     const int vpt = (n + 255) / 256;
 #define FVK_TOPK_CASE(V)                                                                                             \
     if (vpt <= V) {                                                                                                  \

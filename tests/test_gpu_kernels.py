@@ -247,16 +247,22 @@ def test_attn_sta(ops, canvas, tile, win):
 
 
 # ------------------------------------------------------------------ VSA pieces (integer parts bit exact)
-@pytest.mark.parametrize("n,topk", [(50, 9), (624, 125), (624, 63), (1440, 288), (7, 7), (300, 1)])
+@pytest.mark.parametrize("n,topk", [(50, 9), (624, 125), (624, 63), (1440, 288), (7, 7), (300, 1), (2160, 432), (8192, 100), (65, 64)])
 def test_topk_mask_bit_exact(ops, n, topk):
     sc = rnd((3, 5, n), 1, 2.0)  # bf16 scores have many exact ties
     sc[0, 0, :] = 0.5            # an all-equal row
+    sc[1, 1, :] = (torch.arange(n) % 3).to(sc.dtype)  # three values only: the tie rule decides almost everything
     ref = V.topk_mask_bisect(sc.float().numpy(), topk)
-    got = ops.topk_mask(sc.to(DEV), topk).cpu().numpy()
-    assert np.array_equal(got, ref)
-    assert (got.sum(-1) == min(topk, n)).all()
-    got32 = ops.topk_mask(sc.float().to(DEV), topk).cpu().numpy()
-    assert np.array_equal(got32, ref)
+    for impl in (0, 1):  # 0 = one wave per row (shipped), 1 = one workgroup per row
+        ops.set_tunable("vsa_impl", impl)
+        try:
+            got = ops.topk_mask(sc.to(DEV), topk).cpu().numpy()
+            got32 = ops.topk_mask(sc.float().to(DEV), topk).cpu().numpy()
+        finally:
+            ops.set_tunable("vsa_impl", 0)
+        assert np.array_equal(got, ref), impl
+        assert (got.sum(-1) == min(topk, n)).all()
+        assert np.array_equal(got32, ref), impl
 
 
 def test_map_to_index_and_gather(ops):
