@@ -92,11 +92,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # FVK_BENCH_SHARED_GPU=1 (test hook, numbers INVALID): all ranks share cuda:0 and exchange through gloo (host-staged) — exercises the
+    # multi-rank flow of this script on a one-GPU box; production = one rank per GPU over RCCL (backend "nccl")
+    shared = os.environ.get("FVK_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     import __graft_entry__ as G
     G.build()
@@ -137,7 +145,7 @@ def main():
     if not torch.isfinite(y.float()).all():
         raise SystemExit("non-finite output")
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if shared else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
@@ -190,6 +198,8 @@ def main():
     }
     if args.layers:
         out["INVALID"] = "debug run with fewer layers"
+    if shared:
+        out["INVALID"] = "test hook: ranks share one GPU and exchange through gloo"
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
