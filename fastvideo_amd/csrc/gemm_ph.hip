@@ -43,7 +43,7 @@ using fvk::GemmArgs;
 // bit 2 = no s_setprio around the MFMAs, bit 3 = prefetching gated-residual epilogue,
 // bit 4 = staged units retired every second phase (vmcnt(8) in odd phases only), bits 5-6 = m-tiles per walk group 8 / 4 / 16 / 2.
 // A/B: bit 0 +-0 %, bit 1 -1..2 %, bit 2 +1..2 % (+7 % at 4096^3), bit 3 +12 % on the K=1536 gated-residual GEMM (+3 % at K=8960),
-// bit 4 +1..3 %, walk group 4 = 8, 16 -2..4 %.
+// bit 4 +1..3 %, walk group 4 = 8, 16 -2..4 %.  bit 7 = persistent workgroups (min(tiles, 256) workgroups walk the tiles).
 template <int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -56,10 +56,19 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(GemmArgs a) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;  // wave tile: rows wm*128.., cols wn*64..
 
+    a.x += blockIdx.y * a.x_bstride;
+    a.w += blockIdx.y * a.w_bstride;
+    a.out += blockIdx.y * a.out_bstride;
+    // VAR bit 7: persistent workgroups — the launch has min(tiles, 256) workgroups and each walks tiles vb, vb + gridDim.x, ...
+    // (one launch-time dispatch per CU instead of one per tile); otherwise gridDim.x == tiles and the loop body runs once.
+    const int ntiles = a.ntm * a.ntn;
+    constexpr bool PERSIST = (VAR & 128) != 0;
+    int vb = blockIdx.x;
+    do {
     // ---- tile id: XCD-contiguous (block b runs on XCD b % 8), then groups of 8 m-tiles swept along n ----------------
     int tile_id;
     {
-        const int nwg = gridDim.x, bid = blockIdx.x;
+        const int nwg = ntiles, bid = vb;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
         tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
@@ -71,9 +80,6 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(GemmArgs a) {
     const int in_g = tile_id - gid * per_group;
     const int pid_m = first_m + in_g % gsz, pid_n = in_g / gsz;
     const int m0 = pid_m * TM, n0 = pid_n * TN;
-    a.x += blockIdx.y * a.x_bstride;
-    a.w += blockIdx.y * a.w_bstride;
-    a.out += blockIdx.y * a.out_bstride;
 
     // ---- LDS-DMA staging: every wave stages 16 consecutive rows (2 pieces of 8 rows x 128 B) of each unit ------------------
     //   X0: rows (wave>>2)*128 + (wave&3)*16    X1: + 64        W0: rows (wave>>1)*64 + (wave&1)*16    W1: + 32
@@ -262,6 +268,11 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(GemmArgs a) {
     __builtin_amdgcn_s_barrier();
 
     fvk::gemm_tile_epilogue<EPI, false, (VAR & 8) != 0>(a, acc, smem, wave, lane, m0, n0);
+    if (PERSIST && vb + (int)gridDim.x < ntiles) {  // another tile follows: every wave's staging reads are done before the ring is refilled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    } while (PERSIST && (vb += gridDim.x) < ntiles);  // tile loop (compiled out unless persistent)
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -275,7 +286,9 @@ int launch(const GemmArgs& a, int batch, hipStream_t s) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL((gemm_ph_kernel<EPI, VAR>), dim3(a.ntm * a.ntn, batch), dim3(512), LDS_BYTES, s, a);
+    const int tiles = a.ntm * a.ntn;
+    const int grid = (VAR & 128) ? (tiles < 256 ? tiles : 256) : tiles;  // 256 CUs, one resident workgroup each
+    hipLaunchKernelGGL((gemm_ph_kernel<EPI, VAR>), dim3(grid, batch), dim3(512), LDS_BYTES, s, a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -303,12 +316,16 @@ int launch_var(const GemmArgs& a, int epilogue, int batch, hipStream_t s) {
 int gemm_ph_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
     a.ntm = (a.M + TM - 1) / TM;
     a.ntn = (a.N + TN - 1) / TN;
-    // shipped configuration = VAR 28 (bits 2 + 3 + 4); gemm_impl = 4 + 8 * VAR selects a measurement variant
+    // shipped configuration = VAR 28 (bits 2 + 3 + 4) or 156 (+ bit 7, see below); gemm_impl = 4 + 8 * VAR selects a measurement variant
     const int impl = fvk::tunable(fvk::TUNE_GEMM_IMPL);
-    switch ((impl & 7) == 4 ? impl >> 3 : 28) {
+    // persistent workgroups (VAR 156) pay where a CU runs several SHORT tiles back to back: >= 2 rounds of tiles and K <= 2048
+    // (A/B gemm_harness_7: out-projection +4.8 %, QKV +1.3 %, FFN shapes +-0.5 %, single-round shapes -2..5 %)
+    const int shipped = (a.ntm * a.ntn >= 512 && a.K <= 2048) ? 156 : 28;
+    switch ((impl & 7) == 4 ? impl >> 3 : shipped) {
         case 0: return launch_var<0>(a, epilogue, batch, s);
         case 4: return launch_var<4>(a, epilogue, batch, s);
         case 12: return launch_var<12>(a, epilogue, batch, s);
+        case 156: return launch_var<156>(a, epilogue, batch, s);
         default: return launch_var<28>(a, epilogue, batch, s);
     }
 }
