@@ -390,6 +390,30 @@ def test_gemm_kernels_agree(ops, tunables):
     close(outs[0][2], ref, what="residual+gate (pp)")
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (777, 1000, 192), (1030, 520, 1536), (513, 256, 4096)])
+def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
+    """gemm_ph (shipped, K-step 64), its persistent-workgroup variant and gemm_pp (K-step 32) accumulate the same 16-k MFMA steps in the
+    same order: byte-identical outputs for every epilogue, with a gate whose batch boundary cuts through a wave's 128 rows, a strided A
+    operand (column block of a wider buffer) and the batched entry."""
+    B = 3
+    Mb = M // B * B
+    x, w, b = rnd((Mb, 2 * K), 1)[:, K // 2:K // 2 + K], rnd((N, K), 2, K**-0.5), rnd((N, ), 3)
+    res, gate = rnd((Mb, N), 4, 2.0), rnd((B, N), 5, 0.5, torch.float32)
+    xd = rnd((Mb, 2 * K), 1).to(DEV)[:, K // 2:K // 2 + K]  # row stride 2K
+    outs = {}
+    for impl in (0, 2, 1252):  # shipped gemm_ph | gemm_pp | gemm_ph persistent
+        tunables("gemm_impl", impl)
+        outs[impl] = [ops.gemm(xd, w.to(DEV), b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
+                               gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None).cpu()
+                      for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_GELU_TANH, ops.EPI_RESIDUAL_GATE)]
+        xb, wb = rnd((2, 150, K), 7), rnd((2, 140, K), 8)
+        outs[impl].append(ops.gemm_batched(xb.to(DEV), wb.to(DEV), ops.EPI_DIV, 11.0).cpu())
+    for impl in (2, 1252):
+        for i, (a_, b_) in enumerate(zip(outs[0], outs[impl])):
+            assert torch.equal(a_, b_), f"impl {impl}, output #{i}"
+    close(outs[0][0], _lin_ref(x, w, b), what=f"gemm_ph {Mb}x{N}x{K}")
+
+
 @pytest.mark.parametrize("impl", [0, 1, 2, 3])
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 700), (2, 3, 512, 130), (1, 1, 256, 64), (1, 2, 1030, 1999)])
 def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
