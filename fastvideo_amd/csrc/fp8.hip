@@ -41,6 +41,48 @@ __global__ __launch_bounds__(256) void fp8_absmax_kernel(const bf16_t* __restric
     }
 }
 
+// tensorwise absmax of a dense [M, K] tensor (lda == K): a flat stream of 16-B chunks, four independent loads in flight per thread and
+// iteration (the row-walking kernel above keeps one) — HBM-bound.  max is order-independent, so the result is identical.
+__global__ __launch_bounds__(256) void fp8_absmax_flat_kernel(const bf16_t* __restrict__ x, float* __restrict__ out, long n_chunks) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    float r = 0.f;
+    long c = tid;
+    for (; c + 3 * stride < n_chunks; c += 4 * stride) {
+        const bf16x8 v0 = ld_bf16x8(x + c * 8), v1 = ld_bf16x8(x + (c + stride) * 8), v2 = ld_bf16x8(x + (c + 2 * stride) * 8),
+                     v3 = ld_bf16x8(x + (c + 3 * stride) * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            r = fmaxf(fmaxf(r, fmaxf(fabsf((float)v0[e]), fabsf((float)v1[e]))), fmaxf(fabsf((float)v2[e]), fabsf((float)v3[e])));
+    }
+    for (; c < n_chunks; c += stride) {
+        const bf16x8 v = ld_bf16x8(x + c * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r = fmaxf(r, fabsf((float)v[e]));
+    }
+    // ONE atomic per workgroup (same-address atomics serialise at ~11 ns each: 4 per workgroup x 6 000 workgroups cost 270 us)
+    __shared__ float part[4];
+    r = wave_max(r);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
+}
+
+__device__ __forceinline__ int2 fp8_pack8(const bf16x8 v, float sb) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float d = (float)(bf16_t)__fdiv_rn((float)v[e], sb);
+        f[e] = fminf(fmaxf(d, -FP8_MAX), FP8_MAX);
+    }
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+    return make_int2(w0, w1);
+}
+
 template <bool ROWWISE>
 __global__ __launch_bounds__(256) void fp8_quantize_kernel(const bf16_t* __restrict__ x, const float* __restrict__ absmax,
                                                            unsigned char* __restrict__ q, float* __restrict__ scale_out, int M, int K,
@@ -54,19 +96,26 @@ __global__ __launch_bounds__(256) void fp8_quantize_kernel(const bf16_t* __restr
     const float scale = fmaxf(__fdiv_rn(am, FP8_MAX), FP8_MIN_SCALE);
     if (k == 0 && (ROWWISE || m == 0)) scale_out[ROWWISE ? m : 0] = scale;
     const float sb = (float)(bf16_t)scale;  // the reference divides by x_scale.to(x.dtype)
-    const bf16x8 v = ld_bf16x8(x + m * lda + k);
-    float f[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float d = (float)(bf16_t)__fdiv_rn((float)v[e], sb);
-        f[e] = fminf(fmaxf(d, -FP8_MAX), FP8_MAX);
+    *reinterpret_cast<int2*>(q + m * (long)K + k) = fp8_pack8(ld_bf16x8(x + m * lda + k), sb);
+}
+
+// tensorwise quantisation of a dense tensor: flat chunk stream, four chunks per thread and iteration (same arithmetic per element).
+__global__ __launch_bounds__(256) void fp8_quantize_flat_kernel(const bf16_t* __restrict__ x, const float* __restrict__ absmax,
+                                                                unsigned char* __restrict__ q, float* __restrict__ scale_out, long n_chunks) {
+    const long tid = (long)blockIdx.x * 256 + threadIdx.x, stride = (long)gridDim.x * 256;
+    const float scale = fmaxf(__fdiv_rn(absmax[0], FP8_MAX), FP8_MIN_SCALE);
+    if (tid == 0) scale_out[0] = scale;
+    const float sb = (float)(bf16_t)scale;
+    long c = tid;
+    for (; c + 3 * stride < n_chunks; c += 4 * stride) {
+        const bf16x8 v0 = ld_bf16x8(x + c * 8), v1 = ld_bf16x8(x + (c + stride) * 8), v2 = ld_bf16x8(x + (c + 2 * stride) * 8),
+                     v3 = ld_bf16x8(x + (c + 3 * stride) * 8);
+        *reinterpret_cast<int2*>(q + c * 8) = fp8_pack8(v0, sb);
+        *reinterpret_cast<int2*>(q + (c + stride) * 8) = fp8_pack8(v1, sb);
+        *reinterpret_cast<int2*>(q + (c + 2 * stride) * 8) = fp8_pack8(v2, sb);
+        *reinterpret_cast<int2*>(q + (c + 3 * stride) * 8) = fp8_pack8(v3, sb);
     }
-    int w0 = 0, w1 = 0;
-    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
-    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
-    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
-    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
-    *reinterpret_cast<int2*>(q + m * (long)K + k) = make_int2(w0, w1);
+    for (; c < n_chunks; c += stride) *reinterpret_cast<int2*>(q + c * 8) = fp8_pack8(ld_bf16x8(x + c * 8), sb);
 }
 
 }  // namespace
@@ -76,6 +125,22 @@ extern "C" int fvk_fp8_quantize_bf16(const void* x, void* q, float* scale, float
     FVK_CHECK(x && q && scale && absmax_scratch, FVK_ERR_ARG, "fvk_fp8_quantize_bf16: null pointer");
     FVK_CHECK(M > 0 && K > 0 && K % 8 == 0 && lda % 8 == 0, FVK_ERR_ARG, "fvk_fp8_quantize_bf16: M=%d K=%d lda=%ld (K, lda multiples of 8)", M, K, lda);
     hipStream_t s = (hipStream_t)stream;
+    if (!rowwise && lda == K) {  // dense tensorwise (every activation of the DiT): flat streaming kernels
+        if (hipMemsetAsync(absmax_scratch, 0, sizeof(float), s) != hipSuccess) {
+            fvk_set_error("fvk_fp8_quantize_bf16: memset failed");
+            return FVK_ERR_LAUNCH;
+        }
+        const long n_chunks = (long)M * (K / 8);
+        const long want = (n_chunks + 1023) / 1024;  // >= 4 chunks per thread
+        const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+        const unsigned blocks_a = blocks > 512 ? 512 : blocks;  // 2 workgroups per CU: <= 512 serialised atomics (~6 us)
+        hipLaunchKernelGGL(fp8_absmax_flat_kernel, dim3(blocks_a), dim3(256), 0, s, (const bf16_t*)x, absmax_scratch, n_chunks);
+        FVK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(fp8_quantize_flat_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, absmax_scratch, (unsigned char*)q, scale,
+                           n_chunks);
+        FVK_LAUNCH_CHECK();
+        return FVK_OK;
+    }
     const int blocks_a = M < 4096 ? (M + 3) / 4 : 1024;
     if (rowwise) {
         hipLaunchKernelGGL((fp8_absmax_kernel<true>), dim3((M + 3) / 4), dim3(256), 0, s, (const bf16_t*)x, absmax_scratch, M, K, lda);
