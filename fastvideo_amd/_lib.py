@@ -55,6 +55,7 @@ SIGNATURES = {
     "fvk_cfg_unipc_step": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, C.POINTER(C.c_float), i32, i32, vp],
     "fvk_dmd_step": [vp, vp, i32, vp, vp, vp, vp, vp, i64, i64, vp],
     "fvk_vae_conv_bf16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i64, i32, i32, vp],
+    "fvk_vae_conv_norm_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i64, i64, i32, vp, vp, i32, i32, i32, vp],
     "fvk_vae_rmsnorm_silu_bf16": [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp],
     "fvk_vae_blend_f32": [vp, vp, i64, i64, i64, i32, i32, i32, i64, i64, i64, i64, i64, i64, vp],
     "fvk_vae_postprocess_u8": [vp, vp, i32, i32, i32, i64, vp],

@@ -416,7 +416,8 @@ __global__ __launch_bounds__(256) void vae_norm12_kernel(const bf16_t* __restric
 
 int fvk_vae_conv3_launch(const void* in, const void* w, const void* bias, void* out, const void* residual, float* out_f32, int T, int H,
                          int W, int Hin, int Win, int Cin, int Cout, int KT, int ring, int ring_start, long out_fs, long res_fs,
-                         long plane_stride, int ups, int epilogue, hipStream_t s);  // vae_conv3.hip
+                         long plane_stride, int ups, int epilogue, hipStream_t s, const float* norm_gamma = nullptr, void* norm_out = nullptr,
+                         int norm_ring = 0, int norm_slot0 = 0, int norm_silu = 0, int write_raw = 1);  // vae_conv3.hip
 
 extern "C" int fvk_vae_conv_bf16(const void* in, const void* w, const void* bias, void* out, const void* residual,
                                  float* out_f32, int T, int H, int W, int Cin, int Cout, int KT, int KH, int KW, int ring,
@@ -451,6 +452,25 @@ extern "C" int fvk_vae_conv_bf16(const void* in, const void* w, const void* bias
     const int w96 = (Cout + 95) / 96 * 96, w192 = (Cout + 191) / 192 * 192;
     if (w192 <= w96) return launch_e<2>(a, epilogue, upsample2x != 0, (hipStream_t)stream);
     return launch_e<1>(a, epilogue, upsample2x != 0, (hipStream_t)stream);
+}
+
+// 3x3-tap conv with the consumer's RMS-norm (+SiLU) fused into the epilogue (Cout == 96): see include/fvk_amd.h
+extern "C" int fvk_vae_conv_norm_bf16(const void* in, const void* w, const void* bias, void* out, const void* residual, int T, int H, int W,
+                                      int Cin, int Cout, int KT, int ring, int ring_start, long out_frame_stride, long res_frame_stride,
+                                      int upsample2x, const float* norm_gamma, void* norm_out, int norm_ring, int norm_slot0, int norm_silu,
+                                      void* stream) {
+    FVK_CHECK(in && w && norm_gamma && norm_out, FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: null pointer");
+    FVK_CHECK(T > 0 && H > 0 && W > 0 && Cout == 96, FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: Cout=%d (the fused norm serves the 96-channel stage)", Cout);
+    FVK_CHECK(Cin > 0 && Cin % 32 == 0 && (KT == 1 || KT == 3), FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: Cin=%d KT=%d", Cin, KT);
+    FVK_CHECK(!upsample2x || (KT == 1 && H % 2 == 0 && W % 2 == 0), FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: upsample2x needs KT=1 and even H, W");
+    FVK_CHECK(ring >= T + KT - 1 && ring_start >= 0 && ring_start < ring, FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: ring=%d too small (T=%d KT=%d)", ring, T, KT);
+    FVK_CHECK(norm_ring >= T && norm_slot0 >= 0 && norm_slot0 < norm_ring, FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: bad norm ring %d / slot %d", norm_ring, norm_slot0);
+    const int Hin = upsample2x ? H / 2 : H, Win = upsample2x ? W / 2 : W;
+    FVK_CHECK((long)ring * Hin * Win * Cin * 2 < 0xFFFFFF00L && (long)Cout * KT * 9 * Cin * 2 < 0xFFFFFF00L && (long)T * H * W < 0x7FFFFFFFL,
+              FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: tensor exceeds the 32-bit buffer-offset range");
+    return fvk_vae_conv3_launch(in, w, bias, out, residual, nullptr, T, H, W, Hin, Win, Cin, Cout, KT, ring, ring_start, out_frame_stride,
+                                res_frame_stride, 0, upsample2x, residual ? EPI_RESIDUAL : EPI_BIAS, (hipStream_t)stream, norm_gamma, norm_out,
+                                norm_ring, norm_slot0, norm_silu, out != nullptr);
 }
 
 extern "C" int fvk_vae_rmsnorm_silu_bf16(const void* x, const float* gamma, void* out, long n_pix, int C, int HW, int ring, int slot0,

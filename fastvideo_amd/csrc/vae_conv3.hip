@@ -25,6 +25,10 @@ struct Conv3Args {
     int T, H, W, Hin, Win, Cin, Cout, KT;
     int ring, ring_start;
     int tiles_h, tiles_w, ntn;
+    // fused WanRMS_norm (+SiLU) of this conv's output into the CONSUMER conv's input ring (Cout == 96 only: one wave holds all channels of
+    // its 64 pixels): norm_out != NULL.  write_raw == 0 drops the un-normed store (conv1 -> norm2 -> conv2 inside a residual block).
+    const float* norm_gamma; bf16_t* norm_out;
+    int norm_ring, norm_slot0, norm_silu, write_raw;
 };
 
 enum { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_FINAL = 2 };
@@ -289,6 +293,66 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
                 *reinterpret_cast<bf16x4*>(st + (mb * 32 + l31) * EPI_PITCH + nl * 2) = y;
             }
         }
+    if (WNW == 1 && a.norm_out) {
+        // ---- fused RMS-norm (+SiLU): ref WanRMS_norm (wanvae.py:231-232) + SiLU (:418-419), same arithmetic as vae_norm12_kernel on the bf16-rounded
+        // conv output: inv = sqrt(C) / max(||x||_2, 1e-12); out = bf16(silu(x * inv * gamma)).  The staged tile is wave-private and a wave's LDS
+        // operations execute in order, so the passes below need no barrier.
+        // pass A: residual add (rounded to bf16 like the unfused epilogue) back into the staging tile (+ the raw store, unless dropped)
+        if (EPI == EPI_RESIDUAL || a.write_raw) {
+#pragma unroll 4
+            for (int it = 0; it < 12; ++it) {
+                const int id = it * 64 + lane;
+                const int px = id / 12, ch = id - px * 12;
+                const int h = h0 + 2 * wrow + (px >> 5), w = w0 + (px & 31), n = ncol0 + ch * 8;
+                if (h < a.H && w < a.W) {
+                    bf16x8 y = *reinterpret_cast<const bf16x8*>(st + px * EPI_PITCH + ch * 16);
+                    const long hw = (long)h * a.W + w;
+                    if (EPI == EPI_RESIDUAL) {
+                        const bf16x8 res = ld_bf16x8(a.residual + (long)t_out * a.res_fs + hw * a.Cout + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) y[e] = (bf16_t)((float)res[e] + (float)y[e]);
+                        *reinterpret_cast<bf16x8*>(st + px * EPI_PITCH + ch * 16) = y;
+                    }
+                    if (a.write_raw) st_bf16x8(a.out + (long)t_out * a.out_fs + hw * a.Cout + n, y);
+                }
+            }
+        }
+        // pass B: lane p owns staged pixel p: sum of squares over its 96 channels
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(st + lane * EPI_PITCH + c * 16);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
+        }
+        const float inv = sqrtf(96.0f) / fmaxf(sqrtf(ss), 1e-12f);
+        int slot = a.norm_slot0 + t_out;
+        slot = slot >= a.norm_ring ? slot - a.norm_ring : slot;
+        slot = slot >= a.norm_ring ? slot - a.norm_ring : slot;
+        // pass C: normalise, SiLU, store into the consumer's ring
+#pragma unroll 4
+        for (int it = 0; it < 12; ++it) {
+            const int id = it * 64 + lane;
+            const int px = id / 12, ch = id - px * 12;
+            const float inv_px = __shfl(inv, px, 64);
+            const int h = h0 + 2 * wrow + (px >> 5), w = w0 + (px & 31);
+            if (h < a.H && w < a.W) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(st + px * EPI_PITCH + ch * 16);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.norm_gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(a.norm_gamma + ch * 8 + 4);
+                bf16x8 y;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float r_ = (float)v[e] * inv_px * (e < 4 ? g0[e] : g1[e - 4]);
+                    // x * sigmoid(x) with the hardware reciprocal (1 ulp; the result is rounded to bf16): an IEEE division here costs the
+                    // epilogue ~10 VALU instructions per element with no MFMA left to hide behind
+                    if (a.norm_silu) r_ = r_ * __builtin_amdgcn_rcpf(1.0f + __expf(-r_));
+                    y[e] = (bf16_t)r_;
+                }
+                st_bf16x8(a.norm_out + ((long)slot * HW + (long)h * a.W + w) * 96 + ch * 8, y);
+            }
+        }
+        return;
+    }
 #pragma unroll 4
     for (int it = 0; it < 12; ++it) {
         const int id = it * 64 + lane;
@@ -353,8 +417,11 @@ int launch3_e(const Conv3Args& a, int epi, bool ups, hipStream_t s) {
 // called by fvk_vae_conv_bf16 (vae_conv.hip) for KH = KW = 3 after its argument checks
 int fvk_vae_conv3_launch(const void* in, const void* w, const void* bias, void* out, const void* residual, float* out_f32, int T, int H,
                          int W, int Hin, int Win, int Cin, int Cout, int KT, int ring, int ring_start, long out_fs, long res_fs,
-                         long plane_stride, int ups, int epilogue, hipStream_t s) {
+                         long plane_stride, int ups, int epilogue, hipStream_t s, const float* norm_gamma, void* norm_out, int norm_ring,
+                         int norm_slot0, int norm_silu, int write_raw) {
     Conv3Args a{};
+    a.norm_gamma = norm_gamma; a.norm_out = (bf16_t*)norm_out; a.norm_ring = norm_ring; a.norm_slot0 = norm_slot0; a.norm_silu = norm_silu;
+    a.write_raw = write_raw;
     a.in = (const bf16_t*)in; a.w = (const bf16_t*)w; a.bias = (const bf16_t*)bias; a.out = (bf16_t*)out;
     a.residual = (const bf16_t*)residual; a.out_f32 = out_f32;
     a.out_fs = out_fs; a.res_fs = res_fs; a.plane_stride = plane_stride;

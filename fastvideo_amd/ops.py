@@ -336,6 +336,39 @@ def vae_conv(inp, w, bias, *, T, H, W, kt, ks, ring_start=0, out=None, out_frame
     return out if out_f32 is None else out_f32
 
 
+def vae_conv_norm(inp, w, bias, gamma, norm_ring_buf, *, T, H, W, kt, norm_slot0, ring_start=0, out=None, out_frame_stride=None, residual=None,
+                  res_frame_stride=None, upsample2x=False, silu=True, want_raw=True):
+    """3x3-tap conv (Cout = 96) whose epilogue also writes WanRMS_norm(+SiLU) of the result into the consumer conv's input ring
+    (fvk_vae_conv_norm_bf16).  Returns the un-normed output [T,H,W,96] (None with want_raw=False: nothing but the ring is written)."""
+    _chk(inp, BF16, "inp"), _chk(w, BF16, "w"), _chk(norm_ring_buf, BF16, "norm_ring_buf")
+    gamma = _f32(gamma, "gamma")
+    ring, Hin, Win, Cin = inp.shape
+    Cout = w.shape[0]
+    if w.shape[1] != kt * 9 * Cin or not inp.is_contiguous() or not w.is_contiguous() or not norm_ring_buf.is_contiguous():
+        raise RuntimeError(f"vae_conv_norm: weight {tuple(w.shape)} does not match taps {kt}x3x3 x Cin {Cin} (or non-contiguous tensors)")
+    if (Hin, Win) != ((H // 2, W // 2) if upsample2x else (H, W)):
+        raise RuntimeError(f"vae_conv_norm: input spatial size {(Hin, Win)} inconsistent with output {(H, W)}")
+    if tuple(norm_ring_buf.shape[1:]) != (H, W, Cout):
+        raise RuntimeError(f"vae_conv_norm: consumer ring {tuple(norm_ring_buf.shape)} does not hold [*, {H}, {W}, {Cout}] frames")
+    if want_raw:
+        if out is None:
+            out = torch.empty((T, H, W, Cout), dtype=BF16, device=inp.device)
+        if out_frame_stride is None:
+            out_frame_stride = H * W * Cout
+    else:
+        out = None
+    if residual is not None:
+        _chk(residual, BF16, "residual")
+        if res_frame_stride is None:
+            res_frame_stride = H * W * Cout
+    if bias is not None:
+        _chk(bias, BF16, "bias")
+    _lib.call("fvk_vae_conv_norm_bf16", _p(inp), _p(w), _p(bias), _p(out), _p(residual), T, H, W, Cin, Cout, kt, ring, int(ring_start),
+              int(out_frame_stride or 0), int(res_frame_stride or 0), int(upsample2x), _p(gamma), _p(norm_ring_buf), norm_ring_buf.shape[0],
+              int(norm_slot0), int(silu), _stream())
+    return out
+
+
 def vae_blend(a, b, extent, axis):
     """In-place linear cross-fade of tile b's leading `extent` slices along `axis` with tile a's trailing ones
     (fvk_vae_blend_f32; the reference's blend_t / blend_v / blend_h, common.py:94-114).  a, b: fp32 [C, T, H, W] tiles (or views

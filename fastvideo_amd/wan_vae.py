@@ -74,10 +74,12 @@ class WanVaeDecoderHip:
                  device="cuda", *, use_feature_cache: bool = True, tile_sample_min_height: int = 256, tile_sample_min_width: int = 256,
                  tile_sample_min_num_frames: int = 16, tile_sample_stride_height: int = 192, tile_sample_stride_width: int = 192,
                  tile_sample_stride_num_frames: int = 12, blend_num_frames: int | None = None, use_tiling: bool = False,
-                 use_temporal_tiling: bool = False, use_parallel_tiling: bool = False, sp_group=None):
+                 use_temporal_tiling: bool = False, use_parallel_tiling: bool = False, sp_group=None, fuse_norm: bool = True):
         self.device = torch.device(device)
         # VAEConfig / WanVAEConfig fields (configs/models/vaes/base.py:29-46, wanvae.py:72-82)
         self.use_feature_cache = use_feature_cache
+        # RMS-norm + SiLU of the 96-channel (full-resolution) stage fused into the producing conv's epilogue (False = separate norm kernels, A/B)
+        self.fuse_norm = fuse_norm
         self.tile_sample_min_height, self.tile_sample_min_width = tile_sample_min_height, tile_sample_min_width
         self.tile_sample_min_num_frames = tile_sample_min_num_frames
         self.tile_sample_stride_height, self.tile_sample_stride_width = tile_sample_stride_height, tile_sample_stride_width
@@ -162,26 +164,45 @@ class WanVaeDecoderHip:
         return sites
 
     # ------------------------------------------------------------------ building blocks
-    def _cached_conv(self, site: _Site, conv: _Conv, x, gamma, T, residual=None, out=None, out_f32=None, plane_stride=0):
-        """norm+SiLU of x ([T,H,W,C] un-normed) into the ring, then the causal conv over [history | chunk]."""
+    FUSE_NORM_C = 96  # channel count whose RMS-norm + SiLU is fused into the producing conv's epilogue (fvk_vae_conv_norm_bf16)
+
+    def _can_fuse(self, conv: _Conv, nxt) -> bool:
+        return self.fuse_norm and nxt is not None and conv.w.shape[0] == self.FUSE_NORM_C and nxt[1].C == self.FUSE_NORM_C
+
+    def _cached_conv(self, site: _Site, conv: _Conv, x, gamma, T, residual=None, out=None, out_f32=None, plane_stride=0, nxt=None,
+                     want_raw=True):
+        """norm+SiLU of x ([T,H,W,C] un-normed) into the ring (gamma None: the producer's epilogue already wrote it there), then the causal
+        conv over [history | chunk].  nxt = (gamma', site') of the consumer: when fusable, this conv's epilogue also writes the consumer's
+        normalised input (and only that when want_raw is False)."""
         HW = site.H * site.W
         slot0 = (site.start + 2) % site.ring
         if gamma is not None:
             ops.vae_rmsnorm_silu(x, gamma, site.buf, HW=HW, slot0=slot0, silu=True)
-        y = ops.vae_conv(site.buf, conv.w, conv.b, T=T, H=site.H, W=site.W, kt=3, ks=3, ring_start=site.start, out=out,
-                         residual=residual, out_f32=out_f32, plane_stride=plane_stride)
+        if nxt is not None and out_f32 is None:
+            g2, s2 = nxt
+            y = ops.vae_conv_norm(site.buf, conv.w, conv.b, g2, s2.buf, T=T, H=site.H, W=site.W, kt=3, norm_slot0=(s2.start + 2) % s2.ring,
+                                  ring_start=site.start, out=out, residual=residual, want_raw=want_raw)
+        else:
+            y = ops.vae_conv(site.buf, conv.w, conv.b, T=T, H=site.H, W=site.W, kt=3, ks=3, ring_start=site.start, out=out,
+                             residual=residual, out_f32=out_f32, plane_stride=plane_stride)
         site.start = (site.start + T) % site.ring
         return y
 
-    def _res_block(self, x, p, T, out=None):
+    def _res_block(self, x, p, T, out=None, prenormed=False, nxt=None):
+        """WanResidualBlock.  prenormed: norm1(x) already sits in conv1's ring (written by the producer of x); nxt = (gamma, site) of the
+        consumer of this block's output, fused into conv2's epilogue when possible (returns whether it was)."""
         r, S = self.res[p], self._sites
         H, W = S[p + "1"].H, S[p + "1"].W
         if "sc_w" in r:
             h = ops.gemm(x.view(T * H * W, -1), r["sc_w"], r["sc_b"]).view(T, H, W, -1)
         else:
             h = x
-        y = self._cached_conv(S[p + "1"], r["conv1"], x, r["g1"], T)
-        return self._cached_conv(S[p + "2"], r["conv2"], y, r["g2"], T, residual=h, out=out)
+        mid = (r["g2"], S[p + "2"])
+        fuse_mid = self._can_fuse(r["conv1"], mid)
+        y = self._cached_conv(S[p + "1"], r["conv1"], x, None if prenormed else r["g1"], T, nxt=mid if fuse_mid else None, want_raw=False)
+        fuse_out = self._can_fuse(r["conv2"], nxt)
+        y = self._cached_conv(S[p + "2"], r["conv2"], y, None if fuse_mid else r["g2"], T, residual=h, out=out, nxt=nxt if fuse_out else None)
+        return y, fuse_out
 
     def _mid_attn(self, x):
         """WanAttentionBlock (wanvae.py:479-507): every frame attends over its own H*W pixels."""
@@ -209,13 +230,14 @@ class WanVaeDecoderHip:
         site = S["conv_in"]
         x = ops.vae_conv(site.buf, self.conv_in.w, self.conv_in.b, T=T0, H=site.H, W=site.W, kt=3, ks=3, ring_start=site.start)
         site.start = (site.start + T0) % site.ring
-        x = self._res_block(x, "decoder.mid_block.resnets.0.", T0)
+        x, _ = self._res_block(x, "decoder.mid_block.resnets.0.", T0)
         x = self._mid_attn(x)
-        x = self._res_block(x, "decoder.mid_block.resnets.1.", T0)
+        x, _ = self._res_block(x, "decoder.mid_block.resnets.1.", T0)
         if trace is not None:
             trace.append(("mid", x))
         T = T0
         n_up = len(self.dim_mult)
+        prenormed = False  # the producer of x already wrote norm1(x) into the next residual block's conv1 ring
         for i in range(n_up):
             u = self.ups.get(i)
             for j in range(self.nres + 1):
@@ -223,7 +245,14 @@ class WanVaeDecoderHip:
                 dst = None
                 if j == self.nres and u is not None and "tc" in u:
                     dst = S[f"tc{i}"][2:2 + T]  # last resnet of the block writes into the time_conv buffer (frames 2..)
-                x = self._res_block(x, p, T, out=dst)
+                if j < self.nres:  # consumer of this block's output: the next block's norm1 -> conv1, or norm_out -> conv_out
+                    pn = f"decoder.up_blocks.{i}.resnets.{j + 1}."
+                    nxt = (self.res[pn]["g1"], S[pn + "1"])
+                elif u is None and i == n_up - 1:
+                    nxt = (self.g_out, S["conv_out"])
+                else:
+                    nxt = None
+                x, prenormed = self._res_block(x, p, T, out=dst, prenormed=prenormed, nxt=nxt)
             if u is not None:
                 _, H, W, C = x.shape
                 if "tc" in u and not skip_time_conv:
@@ -239,10 +268,17 @@ class WanVaeDecoderHip:
                             buf[0:2].copy_(buf[T:T + 2])
                     x, T = y, 2 * T
                 rs = u["resample"]
-                x = ops.vae_conv(x.contiguous(), rs.w, rs.b, T=T, H=2 * H, W=2 * W, kt=1, ks=3, upsample2x=True)
+                pn = f"decoder.up_blocks.{i + 1}.resnets.0."
+                nxt = (self.res[pn]["g1"], S[pn + "1"]) if pn in self.res else None
+                if self._can_fuse(rs, nxt):  # the 2x-upsampling conv also writes norm1 of the next stage's first block
+                    x = ops.vae_conv_norm(x.contiguous(), rs.w, rs.b, nxt[0], nxt[1].buf, T=T, H=2 * H, W=2 * W, kt=1,
+                                          norm_slot0=(nxt[1].start + 2) % nxt[1].ring, upsample2x=True)
+                    prenormed = True
+                else:
+                    x = ops.vae_conv(x.contiguous(), rs.w, rs.b, T=T, H=2 * H, W=2 * W, kt=1, ks=3, upsample2x=True)
             if trace is not None:
                 trace.append((f"up{i}", x))
-        self._cached_conv(S["conv_out"], self.conv_out, x, self.g_out, T, out_f32=out_f32, plane_stride=plane_stride)
+        self._cached_conv(S["conv_out"], self.conv_out, x, None if prenormed else self.g_out, T, out_f32=out_f32, plane_stride=plane_stride)
         return T
 
     def _latents_cl(self, z):

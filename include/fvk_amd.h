@@ -198,6 +198,14 @@ int fvk_vsa_combine_bf16(const void* out_c, const void* out_s, const void* gate,
 int fvk_vae_conv_bf16(const void* in, const void* w, const void* bias, void* out, const void* residual, float* out_f32, int T,
                       int H, int W, int Cin, int Cout, int KT, int KH, int KW, int ring, int ring_start, long out_frame_stride,
                       long res_frame_stride, long plane_stride, int upsample2x, int epilogue, void* stream);
+/* fvk_vae_conv_bf16 (3x3 spatial taps, bias [+ residual]) with the CONSUMER's WanRMS_norm (+ SiLU) fused into the epilogue, Cout == 96
+ * (the full-resolution stage, where the separate norm pass moves 613 MB per call): the normalised tensor is written straight into the
+ * consumer conv's input ring norm_out [norm_ring, H*W, 96] at frame slots (norm_slot0 + t) % norm_ring.  out == NULL drops the un-normed
+ * store (conv1 -> norm2 -> conv2 inside a residual block, wanvae.py:418-431); otherwise both are written (the raw tensor feeds the next
+ * block's shortcut).  Arithmetic = fvk_vae_rmsnorm_silu_bf16 applied to the bf16-rounded conv output. */
+int fvk_vae_conv_norm_bf16(const void* in, const void* w, const void* bias, void* out, const void* residual, int T, int H, int W, int Cin,
+                           int Cout, int KT, int ring, int ring_start, long out_frame_stride, long res_frame_stride, int upsample2x,
+                           const float* norm_gamma, void* norm_out, int norm_ring, int norm_slot0, int norm_silu, void* stream);
 /* WanRMS_norm (+ SiLU): out = [silu]( x / max(||x||_2, 1e-12) * sqrt(C) * gamma ) per pixel (ref: wanvae.py:231-232, :418-419).
  * x [n_pix, C] bf16, gamma fp32 [C]; pixel p = (t = p / HW, hw) is written to frame slot (slot0 + t) % ring of `out`
  * ([ring, HW, C]) — i.e. straight into the consumer conv's input ring.  C % 8 == 0, C <= 512. */

@@ -158,3 +158,31 @@ def test_decode_wan21_geometry_vs_oracle(ops):
     z = rnd((1, 16, 2, 6, 4), 9)
     y_ref = WanVaeDecoderOracle(sd).decode(z)
     _decode_check(sd, z, y_ref, 8e-2)
+
+
+def test_fused_norm_equals_separate_norm_kernels():
+    """fvk_vae_conv_norm_bf16 (RMS-norm + SiLU of the 96-channel stage in the producing conv's epilogue) vs the separate norm kernel: same
+    arithmetic on the same bf16-rounded conv output; only the fp32 summation order of ||x||^2 differs, so pixels agree to float rounding."""
+    from fastvideo_amd.wan_vae import WanVaeDecoderHip
+    from fastvideo_amd.wan_config import wan_vae_param_spec
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for n, shp in wan_vae_param_spec(base_dim=96):
+        fan_in = 1
+        for d in shp[1:]:
+            fan_in *= d
+        if "gamma" in n:
+            sd[n] = torch.ones(shp) + 0.05 * torch.randn(shp, generator=g)
+        elif len(shp) >= 4:
+            sd[n] = (torch.rand(shp, generator=g) * 2 - 1) * (3.0 / fan_in)**0.5
+        else:
+            sd[n] = 0.02 * torch.randn(shp, generator=g)
+    z = torch.randn(1, 16, 3, 12, 20, generator=g).cuda()
+    outs = []
+    for fuse in (True, False):
+        dec = WanVaeDecoderHip(sd, fuse_norm=fuse)
+        outs.append(dec.decode(z).float().cpu())
+    assert outs[0].shape == (1, 3, 9, 96, 160)
+    err = (outs[0] - outs[1]).abs()
+    print(f"fused vs separate norm: max {err.max().item():.3g} mean {err.mean().item():.3g}")
+    assert err.max().item() < 3e-2 and err.mean().item() < 1.5e-3  # bf16 one-ulp flips propagate through the six 96-channel convs
