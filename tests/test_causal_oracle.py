@@ -79,3 +79,39 @@ def test_rollouts_vs_live_reference_bit_exact(fx):
             assert torch.equal(y, y_ref), f"{case['name']} call {j}: max diff {(y.float() - y_ref.float()).abs().max().item()}"
             for a, b in zip(kv_o, kv_r):
                 assert torch.equal(a["k"], b["k"]) and torch.equal(a["v"], b["v"])
+
+
+def test_product_cache_plan_equals_oracle_plan():
+    """The host's own copy of the cache bookkeeping (fastvideo_amd/wan_causal.py) against the oracle's restatement of
+    causal_wanvideo.py:123-173 over randomised rollouts: window sizes, sink frames, block sizes, context re-runs, cache sizes."""
+    import itertools
+    from fastvideo_amd import wan_causal as WCa
+    n = 0
+    for las, sink, fs, cf, nb in itertools.product([-1, 2, 4, 6], [0, 1, 2], [4, 16], [4, 6, 21], [1, 2, 3]):
+        if las != -1 and sink >= las:
+            continue
+        cache, ge, le, start = cf * fs, 0, 0, 0
+        for _ in range(12):
+            stop = False
+            for _rerun in (0, 1):
+                args = (las, sink, fs, cache, nb * fs, start * fs, ge, le)
+                try:
+                    b = CO.cache_update_plan(*args)
+                except ValueError:
+                    with pytest.raises(ValueError):
+                        WCa.cache_update_plan(*args)
+                    stop = True
+                    break
+                try:
+                    a = WCa.cache_update_plan(*args)
+                except ValueError:  # the product additionally refuses writes past the cache (the reference would raise inside torch)
+                    assert b["write"][1] > cache or b["write"][0] < 0
+                    stop = True
+                    break
+                assert a == b
+                ge, le = a["global_end"], a["local_end"]
+                n += 1
+            if stop:
+                break
+            start += nb
+    assert n > 3000
