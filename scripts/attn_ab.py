@@ -10,7 +10,7 @@ vt = ops.v_transpose(v); o = torch.empty_like(q)
 fl = 4.0 * S * S * H * D
 ref = None
 res = {i: [] for i in impls}
-for r in range(4):
+for r in range(int(os.environ.get("AB_ROUNDS", "4"))):
     for i in impls:
         ops.set_tunable("attn_impl", i)
         ops.attn_dense(q, k, vt=vt, out=o); torch.cuda.synchronize()
