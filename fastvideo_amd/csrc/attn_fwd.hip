@@ -425,7 +425,11 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     ma.max_kv = max_kv;
     // one workgroup per list: 2 waves (64 rows, the VSA block) or 4 waves (128 rows sharing every K/V tile: sliding-tile windows,
     // where all query blocks of a tile attend the same KV blocks)
-    if (q_block == 128) return launch<4, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
+    if (q_block == 128) {
+        // 4 compute waves that also issue the DMA, two workgroups per CU (shipped); "attn_impl" 51 = 4 compute + 4 loader waves, one per CU (A/B)
+        if (fvk::tunable(fvk::TUNE_ATTN_IMPL) == 51) return launch<4, MODE_BLOCKS, 128, 4>(a, ma, (hipStream_t)stream);
+        return launch<4, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
+    }
     // 64-row lists (the VSA block): two lists per 8-wave workgroup, each with 2 compute + 2 loader waves ("attn_impl" 50 = the former
     // one-list 4-wave workgroups, two per CU, for A/B)
     if (fvk::tunable(fvk::TUNE_ATTN_IMPL) == 50) return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);
