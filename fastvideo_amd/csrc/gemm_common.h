@@ -1,5 +1,6 @@
 // Argument block shared by the two bf16 GEMM kernels (gemm_bf16.hip: 128x128 register-staged tile for small / odd
-// shapes; gemm_pp.hip: 256x256 LDS-DMA ping-pong tile for the token-axis GEMMs) and the tunables registry.
+// shapes; gemm_ph.hip: 256x256 LDS-DMA tile with a 128-B-row K-step for the token-axis GEMMs; gemm_pp.hip: its 64-B-row predecessor, kept for
+// K % 64 != 0 and as the fp8 kernel) and the tunables registry.
 #pragma once
 #include "fvk_common.h"
 

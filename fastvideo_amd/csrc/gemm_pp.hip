@@ -1,4 +1,5 @@
-// bf16 GEMM for the token-axis projections of the DiT block (QKV / out / FFN / cross-attn), gfx950 only.
+// GEMM for the token-axis projections of the DiT block (QKV / out / FFN / cross-attn), gfx950 only: the fp8 (e4m3) kernel, and the bf16
+// kernel for K % 64 != 0 — for every other bf16 shape gemm_ph.hip (K-step 64, +8..19 %) is the shipped kernel; "gemm_impl" 2 forces this one.
 //   out[M,N] = epilogue( x[M,K] · w[N,K]^T + bias )      (same contract as gemm_bf16.hip; see include/fvk_amd.h)
 //
 // Design ("ping-pong"): one 512-thread workgroup per CU owns a 256(M) x 256(N) output tile; K is walked in steps of 32.
