@@ -154,7 +154,8 @@ def main():
     _, _, Sq, Skv, h = events[0]
     mean_ms = sum(attn_ms) / len(attn_ms)
     if args.attention == "dense":
-        flops_launch = 4.0 * Sq * Skv * h * cfg.head_dim
+        # launches may differ in head count (pipelined SP exchange: two head chunks per layer): total FLOPs / total time
+        flops_launch = sum(4.0 * sq_ * skv_ * h_ * cfg.head_dim for _, _, sq_, skv_, h_ in events) / len(events)
         kname = "attn_pp2_kernel (dense self-attention, 8-wave ping-pong, 128-key tiles)"
     else:
         # sparse modes: the algorithmic work is the selected fraction of the dense score matrix (VSA: top-k of the 64-token blocks
@@ -183,7 +184,8 @@ def main():
     fl = WC.algorithmic_flops(cfg, S, L_text)
     ms_per_step = elapsed / args.steps * 1e3
     lay = model.sp.lay
-    par = "sp1" if world == 1 else f"sp{world} 2-D Ulysses (head groups {lay.G} x query blocks {lay.U})"
+    par = "sp1" if world == 1 else (f"sp{world} 2-D Ulysses (head groups {lay.G} x query blocks {lay.U}), "
+                                    f"{'pipelined (2 head chunks, asynchronous)' if model.sp.overlap else 'plain'} exchange")
     out = {
         "metric": "DiT-step latent-tokens/s, Wan2.1-T2V-1.3B 81fx480p (one DiT forward per step)" if args.config == "cfg2" else
                   f"DiT-step latent-tokens/s, BASELINE {args.config} (one DiT forward per step)",

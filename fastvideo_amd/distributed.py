@@ -24,6 +24,7 @@ the attention itself is injected (``attn_fn``): the product passes the HIP kerne
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass
 
 import torch
@@ -64,6 +65,13 @@ class SequenceParallel:
         # gloo cannot move device memory: stage through the host (used by the 2-process single-GPU parity test;
         # production runs use backend "nccl" = RCCL, which takes device pointers directly)
         self._stage_host = P > 1 and dist.get_backend(group) == "gloo"
+        # Pipelined exchange: the head group of a rank is split in two chunks whose exchanges are issued asynchronously, so chunk B's
+        # all-to-all and chunk A's output exchange ride under the other chunk's attention kernel.  FVK_SP_OVERLAP = 1 / 0 forces it on / off;
+        # default: on over RCCL, off over gloo.  The FIRST pipelined call is checked against the plain exchange (bit-identical by
+        # construction: heads are independent); any rank seeing a difference switches every rank back to the plain exchange.
+        env = os.environ.get("FVK_SP_OVERLAP", "auto")
+        self.overlap = P > 1 and (env == "1" or (env == "auto" and not self._stage_host))
+        self._overlap_checked = False
 
     # -- sharding with zero padding (ref: distributed/utils.py:63-123, communication_op.py:61-91) ---------------
     def padded_len(self, S: int) -> int:
@@ -106,20 +114,42 @@ class SequenceParallel:
                                group=self.group)
         return recv.to(dev)
 
+    def _a2a_async(self, send: torch.Tensor, in_splits, out_splits, out_rows: int):
+        """Issue the exchange and return a thunk that completes it (RCCL: the collective runs on the process group's own stream and
+        ``wait()`` orders the caller's stream behind it without blocking the host; gloo: host-staged, completes at the thunk)."""
+        if self._stage_host:
+            dev, send_h = send.device, send.cpu().contiguous()
+            recv = send_h.new_empty((out_rows, *send_h.shape[1:]))
+            work = dist.all_to_all_single(recv, send_h, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group, async_op=True)
+            return lambda: (work.wait(), recv.to(dev))[1]
+        send = send.contiguous()
+        recv = send.new_empty((out_rows, *send.shape[1:]))
+        work = dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group, async_op=True)
+        return lambda: (work.wait(), recv, send)[1]  # `send` stays referenced until the exchange has been waited for
+
     def scatter_heads_gather_seq(self, q, k, v):
         """q,k,v: this rank's shard [Sl, H, D] (batch 1).  Returns (q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all).
         ONE all-to-all: the message for rank r' = (g', u') is [K | V (| Q)] of head group g' — Q only if u' is this shard's query block —
         so a layer costs two collectives (this one and the output exchange) instead of four."""
+        return self._unpack_qkv(*self._pack_qkv(q, k, v), sync=True)
+
+    def _pack_qkv(self, q, k, v):
+        """q, k, v [Sl, G*hg, D] (heads group-major) -> (send buffer, splits, Sl) of exchange #1."""
         L = self.lay
         Sl, H, D = q.shape
-        hg = L.heads_per_group
+        hg = H // L.G
         by_group = lambda t: t.reshape(Sl, L.G, hg, D).permute(1, 0, 2, 3)  # [G, Sl, hg, D]: chunk g' = heads of group g'
         qg, kg, vg = by_group(q), by_group(k), by_group(v)
         mine = [(rp // L.G) == L.u for rp in range(L.P)]        # as destination: gets my Q; as source: its Q comes to me
         send = torch.cat([t for rp in range(L.P) for t in ((kg[rp % L.G], vg[rp % L.G], qg[rp % L.G]) if mine[rp]
                                                            else (kg[rp % L.G], vg[rp % L.G]))], 0)
         splits = [(3 if m else 2) * Sl for m in mine]
-        recv = self._a2a(send, splits, splits, sum(splits))
+        return send, splits, Sl
+
+    def _unpack_qkv(self, send, splits, Sl, sync=False, done=None):
+        L = self.lay
+        mine = [(rp // L.G) == L.u for rp in range(L.P)]
+        recv = self._a2a(send, splits, splits, sum(splits)) if sync else done()
         ks, vs, qs, off = [], [], [], 0
         for s_ in range(L.P):
             ks.append(recv[off:off + Sl]); vs.append(recv[off + Sl:off + 2 * Sl])
@@ -132,10 +162,38 @@ class SequenceParallel:
         """o_blk [G*Sl, hg, D] (query block u, head group g) -> this rank's shard [Sl, H, D]."""
         L = self.lay
         hg, D = o_blk.shape[1], o_blk.shape[2]
+        o_in, o_out = self._o_splits(Sl)
+        recv = self._a2a(o_blk.contiguous(), o_in, o_out, L.G * Sl)      # [G(g), Sl, hg, D]
+        return recv.reshape(L.G, Sl, hg, D).permute(1, 0, 2, 3).reshape(Sl, L.G * hg, D).contiguous()
+
+    def _o_splits(self, Sl: int):
+        L = self.lay
         o_in = [Sl if (rp // L.G) == L.u else 0 for rp in range(L.P)]   # rows j*Sl.. go to shard owner u*G+j
         o_out = [Sl if (s // L.G) == L.u else 0 for s in range(L.P)]    # from (g, u) for every g
-        recv = self._a2a(o_blk.contiguous(), o_in, o_out, L.G * Sl)      # [G(g), Sl, hg, D]
-        return recv.reshape(L.G, Sl, hg, D).permute(1, 0, 2, 3).reshape(Sl, L.H, D).contiguous()
+        return o_in, o_out
+
+    def _attention_pipelined(self, q, k, v, S: int, attn_fn):
+        """FVK_SP_OVERLAP: two head chunks per group, every exchange asynchronous (see __init__).  Heads are independent in attention, so
+        the result is the un-chunked one bit for bit."""
+        L = self.lay
+        Sl, H, D = q.shape
+        hg = L.heads_per_group
+        cuts = [(0, (hg + 1) // 2), ((hg + 1) // 2, hg)]
+        sub = lambda t, a, b: t.reshape(Sl, L.G, hg, D)[:, :, a:b].reshape(Sl, L.G * (b - a), D)
+        pend = []
+        for a, b in cuts:  # issue both input exchanges up front
+            send, splits, _ = self._pack_qkv(sub(q, a, b), sub(k, a, b), sub(v, a, b))
+            pend.append((send, splits, self._a2a_async(send, splits, splits, sum(splits))))
+        outs = []
+        for (a, b), (send, splits, done) in zip(cuts, pend):
+            q_blk, k_all, v_all = self._unpack_qkv(send, splits, Sl, done=done)
+            o_blk = attn_fn(q_blk, k_all, v_all, S).contiguous()
+            o_in, o_out = self._o_splits(Sl)
+            outs.append((b - a, self._a2a_async(o_blk, o_in, o_out, L.G * Sl)))  # rides under the next chunk's attention
+        out = q.new_empty((Sl, L.G, hg, D))
+        for (a, b), (hc, done) in zip(cuts, outs):
+            out[:, :, a:b] = done().reshape(L.G, Sl, hc, D).permute(1, 0, 2, 3)
+        return out.reshape(Sl, H, D)
 
     def attention(self, q, k, v, S: int, attn_fn, extra=None):
         """Distributed self-attention for one batch element.
@@ -145,6 +203,21 @@ class SequenceParallel:
         if L.P == 1:
             return attn_fn(q, k, v, S) if extra is None else attn_fn(q, k, v, S, extra)
         Sl = q.shape[0]
+        if self.overlap and extra is None and L.heads_per_group >= 2:
+            o = self._attention_pipelined(q, k, v, S, attn_fn)
+            if self._overlap_checked:
+                return o
+            self._overlap_checked = True
+            ref = self.scatter_seq_gather_heads(attn_fn(*self.scatter_heads_gather_seq(q, k, v), S), Sl)
+            ok = torch.tensor([1 if torch.equal(o, ref) else 0], dtype=torch.int32, device="cpu" if self._stage_host else o.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+            if int(ok.item()) != 1:
+                import warnings
+                warnings.warn("fastvideo_amd: the pipelined sequence-parallel exchange disagreed with the plain exchange on its first call; "
+                              "falling back to the plain exchange (set FVK_SP_OVERLAP=0 to silence)")
+                self.overlap = False
+                return ref
+            return o
         q_blk, k_all, v_all = self.scatter_heads_gather_seq(q, k, v)
         if extra is None:
             o_blk = attn_fn(q_blk, k_all, v_all, S)

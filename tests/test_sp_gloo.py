@@ -26,15 +26,19 @@ def _attn_fn(q, k, v, kv_len):
     return o[0].transpose(0, 1).to(q.dtype)
 
 
-def _worker(rank, world, port, H, S, D, q, k, v, out_q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, H, S, D, q, k, v, out_q, overlap=False):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FVK_SP_OVERLAP="1" if overlap else "0")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from fastvideo_amd.distributed import SequenceParallel
         sp = SequenceParallel(H)
+        assert sp.overlap == overlap
         assert sp.lay.G * sp.lay.U == world and H % sp.lay.G == 0
         ql, kl, vl = (sp.shard(t[None], dim=1)[0] for t in (q, k, v))
         ol = sp.attention(ql, kl, vl, S, _attn_fn)
+        if overlap and sp.lay.heads_per_group >= 2:  # the first pipelined call checked itself against the plain exchange and kept the mode
+            assert sp._overlap_checked and sp.overlap
+            assert torch.equal(sp.attention(ql, kl, vl, S, _attn_fn), ol)
         full = sp.all_gather_unpad(ol[None], S, dim=1)[0]
         # shard + gather round trip of a [B,S,d] activation (ragged S -> zero padded)
         x = torch.arange(2 * S * 6, dtype=torch.float32).view(2, S, 6)
@@ -46,8 +50,11 @@ def _worker(rank, world, port, H, S, D, q, k, v, out_q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("overlap", [False, True])
 @pytest.mark.parametrize("world,H,S", [(2, 2, 37), (2, 3, 40), (4, 2, 45), (4, 12, 64), (2, 12, 33)])
-def test_sp_attention_equals_single_process(world, H, S):
+def test_sp_attention_equals_single_process(world, H, S, overlap):
+    """overlap=True: FVK_SP_OVERLAP — the rank's head group split in two chunks with asynchronous exchanges (odd head counts per group
+    included: 12 heads on 4 ranks = 3 per group -> chunks of 2 and 1; one head per group falls back to the plain exchange)."""
     D = 16
     g = torch.Generator().manual_seed(world * 100 + H)
     q, k, v = (torch.randn((S, H, D), generator=g) for _ in range(3))
@@ -55,7 +62,7 @@ def test_sp_attention_equals_single_process(world, H, S):
     ctx = mp.get_context("spawn")
     out_q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, H, S, D, q, k, v, out_q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, S, D, q, k, v, out_q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     full, roundtrip_ok, (G, U) = out_q.get(timeout=120)
