@@ -66,11 +66,12 @@ class SequenceParallel:
         # production runs use backend "nccl" = RCCL, which takes device pointers directly)
         self._stage_host = P > 1 and dist.get_backend(group) == "gloo"
         # Pipelined exchange: the head group of a rank is split in two chunks whose exchanges are issued asynchronously, so chunk B's
-        # all-to-all and chunk A's output exchange ride under the other chunk's attention kernel.  FVK_SP_OVERLAP = 1 / 0 forces it on / off;
-        # default: on over RCCL, off over gloo.  The FIRST pipelined call is checked against the plain exchange (bit-identical by
-        # construction: heads are independent); any rank seeing a difference switches every rank back to the plain exchange.
-        env = os.environ.get("FVK_SP_OVERLAP", "auto")
-        self.overlap = P > 1 and (env == "1" or (env == "auto" and not self._stage_host))
+        # all-to-all and chunk A's output exchange ride under the other chunk's attention kernel.  OPT-IN (FVK_SP_OVERLAP=1): two attention
+        # launches per layer on ONE stream also split the attention grid (192 workgroups at SP = 8 become 128 + 64 on 256 CUs, each a full
+        # pass over the keys), which costs more than the exchange it hides until the two launches run on separate streams — to be measured on
+        # an 8-GPU node.  The FIRST pipelined call is checked against the plain exchange (bit-identical by construction: heads are
+        # independent); any rank seeing a difference switches every rank back to the plain exchange.
+        self.overlap = P > 1 and os.environ.get("FVK_SP_OVERLAP") == "1"
         self._overlap_checked = False
 
     # -- sharding with zero padding (ref: distributed/utils.py:63-123, communication_op.py:61-91) ---------------
