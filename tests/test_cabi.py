@@ -37,6 +37,26 @@ def test_errors_surface_as_runtime_error(lib):
         lib.call("fvk_vsa_build_metadata_host", 0, 1, 1, 4, 4, 4, None, None, None, None, None)
 
 
+def test_argument_checks_of_the_newer_entries(lib):
+    """Argument validation happens on the host before any launch, so it is testable without a GPU: every refusal names its entry point."""
+    import ctypes as C
+    buf = (C.c_char * 4096)()
+    p = C.cast(buf, C.c_void_p)
+    with pytest.raises(RuntimeError, match="fvk_dmd_step"):      # noise / sigma_next / next_out must come together
+        lib.call("fvk_dmd_step", p, p, 0, p, p, None, p, None, 1, 8, None)
+    with pytest.raises(RuntimeError, match="fvk_dmd_step"):
+        lib.call("fvk_dmd_step", None, p, 0, p, None, None, p, None, 1, 8, None)
+    with pytest.raises(RuntimeError, match="fvk_gather_rows_strided_bf16"):  # row stride smaller than the row
+        lib.call("fvk_gather_rows_strided_bf16", p, p, None, None, 1, 4, 64, 32, 64, 0, 0, None)
+    with pytest.raises(RuntimeError, match="fvk_vae_conv_norm_bf16"):       # the fused norm serves Cout == 96 only
+        lib.call("fvk_vae_conv_norm_bf16", p, p, None, p, None, 1, 8, 8, 32, 192, 3, 3, 0, 0, 0, 0, p, p, 3, 0, 1, None)
+    with pytest.raises(RuntimeError, match="fvk_vae_conv_norm_bf16"):       # consumer ring shorter than the chunk
+        lib.call("fvk_vae_conv_norm_bf16", p, p, None, p, None, 4, 8, 8, 32, 96, 3, 6, 0, 0, 0, 0, p, p, 3, 0, 1, None)
+    with pytest.raises(RuntimeError, match="unknown tunable"):
+        lib.call("fvk_set_tunable", b"no_such_knob", 1)
+    lib.call("fvk_set_tunable", b"vsa_impl", 0)
+
+
 @pytest.mark.parametrize("shape", [(8, 16, 16), (9, 10, 7), (5, 7, 3), (2, 2, 2), (21, 30, 52)])
 def test_vsa_metadata_host_bit_exact(lib, shape):
     from fastvideo_amd import ops
