@@ -218,3 +218,39 @@ class DmdStepper:
         _lib.call("fvk_dmd_step", ops._p(pred_noise), ops._p(noisy_latent), int(noisy_latent.dtype == torch.float32), ops._p(sigma_t),
                   ops._p(noise), ops._p(sn), ops._p(video), ops._p(nxt), frames, per_frame, ops._stream())
         return video, nxt
+
+
+class DmdDenoisingLoopHip:
+    """Few-step DMD sampling loop of ``DmdDenoisingStage.forward`` (fastvideo/pipelines/stages/denoising.py:1322-1401; the FastWan
+    pipelines): per step one DiT forward on the bf16 latent, ``pred_noise_to_pred_video``, and — except after the last step — re-noising
+    to the next timestep with a fresh draw.  The step tail is one HIP kernel (``DmdStepper``), bit-identical to the eager ops; the latent
+    stays on the GPU.  ``noise_fn(shape_btchw, dtype) -> tensor`` supplies the draws (the reference: ``torch.randn(latents.shape,
+    dtype=pred_video.dtype, generator=batch.generator[0])`` moved to the device, ``:1388-1391``)."""
+
+    def __init__(self, transformer, dmd_denoising_steps, flow_shift: float = 8.0):
+        self.model = transformer
+        self.stepper = DmdStepper(flow_shift)
+        self.timesteps = torch.tensor(list(dmd_denoising_steps), dtype=torch.long)
+
+    @torch.no_grad()
+    def run(self, latents, prompt_embeds, noise_fn):
+        """latents [1, C, T, H, W] (initial noise, fp32 or bf16) -> denoised latents [1, C, T, H, W] bf16 (the dtype the reference's loop ends
+        in: ``pred_video`` takes the model output's dtype)."""
+        dev = self.model.device
+        B, C, T, H, W = latents.shape
+        if B != 1:
+            raise ValueError("DmdDenoisingLoopHip: one sample per call")
+        prompt_embeds = prompt_embeds.to(dev)
+        cur = latents.to(dev).permute(0, 2, 1, 3, 4).flatten(0, 1).contiguous()  # frames first [T, C, H, W], as the stage's flatten(0, 1)
+        n = len(self.timesteps)
+        for i in range(n):
+            t = self.timesteps[i]
+            x_in = cur.view(1, T, C, H, W).permute(0, 2, 1, 3, 4).to(BF16)
+            pred = self.model(x_in, prompt_embeds, t.reshape(1).float().to(dev))
+            pred_f = pred.permute(0, 2, 1, 3, 4).flatten(0, 1).contiguous()
+            if i < n - 1:
+                noise = noise_fn((1, T, C, H, W), BF16).to(dev).flatten(0, 1)
+                _, cur = self.stepper.step(pred_f, cur, t, noise, self.timesteps[i + 1])
+            else:
+                cur, _ = self.stepper.step(pred_f, cur, t)
+        return cur.view(1, T, C, H, W).permute(0, 2, 1, 3, 4).contiguous()

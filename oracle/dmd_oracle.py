@@ -40,3 +40,23 @@ def add_noise(clean_latent, noise, timestep, timesteps, sigmas):
     tid = torch.argmin((timesteps.unsqueeze(0) - timestep.unsqueeze(1)).abs(), dim=1)
     sigma = sigmas[tid].reshape(-1, 1, 1, 1)
     return ((1 - sigma) * clean_latent + sigma * noise).type_as(noise)
+
+
+def dmd_rollout(model_fn, latents_bcthw, dmd_steps, noise_list, shift: float = 8.0):
+    """The loop of ``DmdDenoisingStage.forward`` (denoising.py:1322-1401) around ``model_fn(latent_bcthw_bf16, timestep[1]) -> pred_bcthw``
+    (e.g. the oracle DiT) with the re-noising draws given in call order ([1, T, C, H, W] bf16 each).  Returns [1, C, T, H, W]."""
+    ts_tab, sg_tab = tables(shift)
+    timesteps = torch.tensor(list(dmd_steps), dtype=torch.long)
+    latents = latents_bcthw.permute(0, 2, 1, 3, 4)  # the stage keeps [B, T, C, H, W]
+    it = iter(noise_list)
+    for i, t in enumerate(timesteps):
+        noise_latents = latents.clone()
+        t_expand = t.repeat(1)
+        pred = model_fn(latents.to(torch.bfloat16).permute(0, 2, 1, 3, 4), t_expand).permute(0, 2, 1, 3, 4)
+        video = pred_noise_to_pred_video(pred.flatten(0, 1), noise_latents.flatten(0, 1), t_expand, ts_tab, sg_tab).unflatten(0, pred.shape[:2])
+        if i < len(timesteps) - 1:
+            nxt = timesteps[i + 1] * torch.ones([1], dtype=torch.long)
+            latents = add_noise(video.flatten(0, 1), next(it).flatten(0, 1), nxt, ts_tab, sg_tab).unflatten(0, video.shape[:2])
+        else:
+            latents = video
+    return latents.permute(0, 2, 1, 3, 4)
