@@ -323,8 +323,6 @@ int gemm_ph_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
     const int shipped = 28;
     switch ((impl & 7) == 4 ? impl >> 3 : shipped) {
         case 0: return launch_var<0>(a, epilogue, batch, s);
-        case 4: return launch_var<4>(a, epilogue, batch, s);
-        case 12: return launch_var<12>(a, epilogue, batch, s);
         case 156: return launch_var<156>(a, epilogue, batch, s);
         default: return launch_var<28>(a, epilogue, batch, s);
     }
