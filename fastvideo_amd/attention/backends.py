@@ -43,6 +43,11 @@ def _require_bf16_cuda(*ts):
                                f"(got {t.dtype} on {t.device}); there is no eager fallback")
 
 
+def _i32(t: torch.Tensor, device) -> torch.Tensor:
+    """Index tensors of the reference's metadata are int64 (vsa_utils.py); the kernels take int32 on the device."""
+    return t if (t.dtype == torch.int32 and t.device == device) else t.to(device=device, dtype=torch.int32)
+
+
 # ------------------------------------------------------------------ dense (replaces SDPA / flash-attn on ROCm)
 class HipDenseAttentionImpl(AttentionImpl):
     """ref: SDPAImpl (fastvideo/attention/backends/sdpa.py:108-147) / FlashAttentionImpl (flash_attn.py:247-345)."""
@@ -58,10 +63,18 @@ class HipDenseAttentionImpl(AttentionImpl):
         self.softmax_scale = head_size**-0.5 if softmax_scale is None else softmax_scale
 
     def forward(self, query, key, value, attn_metadata=None):
-        _require_bf16_cuda(query, key, value)
         if attn_metadata is not None and getattr(attn_metadata, "attn_mask", None) is not None:
             raise NotImplementedError("HipDenseAttentionImpl: attention masks are not supported")
-        return ops.attn_dense(query, key, value, scale=self.softmax_scale, layout="bshd")
+        # ref: FlashAttentionImpl.forward (flash_attn.py:255-266): non-half activations that leak into attention are cast through
+        # bf16 for the kernel and restored on output (the reference's own tests run fp32 tensors through this backend)
+        orig_dtype = query.dtype
+        if orig_dtype != torch.bfloat16:
+            if orig_dtype != torch.float32:  # fp16 would silently lose mantissa bits in a bf16 kernel: refused
+                raise RuntimeError(f"HipDenseAttentionImpl: unsupported dtype {orig_dtype} (bf16, or fp32 cast through bf16)")
+            query, key, value = query.to(torch.bfloat16), key.to(torch.bfloat16), value.to(torch.bfloat16)
+        _require_bf16_cuda(query, key, value)
+        out = ops.attn_dense(query, key, value, scale=self.softmax_scale, layout="bshd")
+        return out if out.dtype == orig_dtype else out.to(orig_dtype)
 
 
 class HipDenseAttentionBackend(AttentionBackend):
@@ -141,11 +154,22 @@ class HipVideoSparseAttentionImpl(AttentionImpl):
         self.prefix = prefix
 
     def tile(self, x, md: VideoSparseAttentionMetadata):
+        """ref: VideoSparseAttentionImpl.tile (video_sparse_attn.py:254-281): zero-padded tile-major copy of [B,S,H,D]; with
+        ``cache_tile_buf`` the buffer lives on the per-step metadata (pad rows are zeroed once, never written afterwards)."""
         s_pad = math.prod(md.num_tiles) * math.prod(VSA_TILE_SIZE)
-        return ops.gather_rows(x, s_pad, md.tile_partition_indices, md.non_pad_index, zero_init=True)
+        perm, npi = _i32(md.tile_partition_indices, x.device), _i32(md.non_pad_index, x.device)
+        if not getattr(md, "cache_tile_buf", False):
+            return ops.gather_rows(x, s_pad, perm, npi, zero_init=True)
+        buf = getattr(md, "tile_buf", None)
+        shape = (x.shape[0], s_pad, *x.shape[2:])
+        if buf is None or tuple(buf.shape) != shape or buf.dtype != x.dtype or buf.device != x.device:
+            buf = torch.zeros(shape, dtype=x.dtype, device=x.device)
+            md.tile_buf = buf
+        return ops.gather_rows(x, s_pad, perm, npi, out=buf)
 
     def untile(self, x, md: VideoSparseAttentionMetadata):
-        return ops.gather_rows(x, md.total_seq_length, md.untile_combined_index, None)
+        total = getattr(md, "total_seq_length", None) or md.untile_combined_index.numel()
+        return ops.gather_rows(x, total, _i32(md.untile_combined_index, x.device), None)
 
     def preprocess_qkv(self, qkv, attn_metadata):
         return self.tile(qkv, attn_metadata)
@@ -157,11 +181,12 @@ class HipVideoSparseAttentionImpl(AttentionImpl):
         _require_bf16_cuda(query, key, value)
         md = attn_metadata
         topk = compute_topk(md.VSA_sparsity, md.variable_block_sizes.numel())
-        t = lambda z: z.transpose(1, 2).contiguous()
-        out = kernel_api.video_sparse_attn(t(query), t(key), t(value), md.variable_block_sizes, md.variable_block_sizes, topk,
-                                           block_size=VSA_TILE_SIZE,
-                                           compress_attn_weight=None if gate_compress is None else t(gate_compress))
-        return out.transpose(1, 2)
+        # the kernels take strides: the [B, S_pad, H, D] tensors go in as they are — the reference's four
+        # ``transpose(1, 2).contiguous()`` copies per layer (video_sparse_attn.py:296-303) have no counterpart
+        if gate_compress is not None:
+            _require_bf16_cuda(gate_compress)
+        return kernel_api.video_sparse_attn_bshd(query, key, value, md.variable_block_sizes, md.variable_block_sizes, topk,
+                                                 block_size=VSA_TILE_SIZE, compress_attn_weight=gate_compress)
 
 
 class HipVideoSparseAttentionBackend(AttentionBackend):

@@ -22,8 +22,13 @@ def get_attn_backend_cls(selected_backend, head_size: int, dtype) -> str:
         raise ValueError(f"Invalid attention backend for MI355X: {name}")
     if head_size != 128:
         raise ValueError(f"MI355X HIP attention kernels support head_size 128 only (got {head_size})")
-    if dtype not in (torch.bfloat16, None):
-        raise ValueError(f"MI355X HIP attention kernels are bf16 only (got {dtype})")
+    # The layer asks with its COMPUTE dtype (attention/layer.py:61-62: get_compute_dtype() = torch.get_default_dtype() unless a mixed
+    # precision policy is set), i.e. usually fp32 while the activations arrive as bf16 under autocast.  So fp32 is accepted at
+    # SELECTION time; at call time the dense Impl casts fp32 tensors through bf16 like FlashAttentionImpl (flash_attn.py:255-266), the
+    # sparse Impls raise on anything but bf16 (the reference's sparse kernels are bf16-only, block_sparse_h100.cu:700-717); fp16 is
+    # refused outright (a bf16 kernel would silently drop three mantissa bits).
+    if dtype not in (torch.bfloat16, torch.float32, None):
+        raise ValueError(f"MI355X HIP attention kernels compute in bf16 (got {dtype})")
     return _BACKENDS[name]
 
 

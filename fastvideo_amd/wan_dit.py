@@ -157,8 +157,10 @@ class WanTransformer3DModelHip:
             self._vsa_cache[("sta",) + key] = m
         return m
 
-    def _tile_bufs(self, S_pad, h, n):
-        key = ("tilebuf", S_pad, h)
+    def _tile_bufs(self, S_pad, h, n, grid, mode):
+        # keyed by the GRID, not by S_pad: two grids can share S_pad with their pad rows in different places ((8,8,8) and (7,8,8)
+        # both pad to 512), and pad rows are zeroed only at allocation — block means divide the sum over all 64 rows
+        key = ("tilebuf", mode, tuple(grid), S_pad, h)
         bufs = self._vsa_cache.get(key)
         if bufs is None or len(bufs) < n:
             bufs = [torch.zeros((1, S_pad, h, self.D), dtype=BF16, device=self.device) for _ in range(n)]
@@ -197,7 +199,7 @@ class WanTransformer3DModelHip:
             # zero (the reference keeps one such `tile_buf` per step too, video_sparse_attn.py:254-264)
             m = self._vsa_meta(grid)
             S = kv_len
-            bufs = self._tile_bufs(m["S_pad"], q.shape[1], 4 if gate is not None else 3)
+            bufs = self._tile_bufs(m["S_pad"], q.shape[1], 4 if gate is not None else 3, grid, "vsa")
             tile = lambda t, j: ops.gather_rows(t[:, :S], m["S_pad"], m["tile_partition_indices"], m["non_pad_index"], out=bufs[j])
             tq, tk, tv = tile(q4, 0), tile(k4, 1), tile(v4, 2)
             tg = tile(gate.unsqueeze(0), 3) if gate is not None else None
@@ -213,7 +215,7 @@ class WanTransformer3DModelHip:
         # block-sparse kernel — which serves any canvas (the reference kernels hard-code three).
         m = self._sta_meta(grid, q.shape[1])
         S = kv_len
-        bufs = self._tile_bufs(m["S_pad"], q.shape[1], 3)
+        bufs = self._tile_bufs(m["S_pad"], q.shape[1], 3, grid, "sta")
         tile = lambda t, j: ops.gather_rows(t[:, :S], m["S_pad"], m["perm"], m["non_pad"], out=bufs[j])  # [1,S_pad,h,D]
         o = ops.attn_block_sparse(tile(q4, 0), tile(k4, 1), tile(v4, 2), m["q2k_idx"], m["q2k_num"], m["block_sizes"], scale=self.D**-0.5,
                                   layout="bshd", q_block=m["q_block"])

@@ -2,9 +2,11 @@
 
 TEST INFRASTRUCTURE ONLY.  Nothing under ``fastvideo_amd/`` may import this
 module; it is used by ``oracle/make_golden.py`` (fixture generation, run in the
-build container where ``/root/reference`` is mounted) and by the ``-m "not gpu"``
-tests that pin ``oracle/wan_oracle.py`` against the reference itself.  On the
-GPU box ``/root/reference`` does not exist and :func:`available` returns False.
+build container where ``/root/reference`` is mounted), by the ``-m "not gpu"``
+tests that pin ``oracle/wan_oracle.py`` against the reference itself, and by
+``bench.py: cpu_baseline`` (kind "reference").  On the GPU box ``/root/reference``
+does not exist; the git-ignored copy staged by ``oracle/stage_ref.py`` under
+``oracle/_ref/reference`` is used when present, else :func:`available` is False.
 
 Recipe = SURVEY.md Appendix A:
   * pre-register an empty ``fastvideo`` package so ``fastvideo/__init__.py``
@@ -24,7 +26,18 @@ import os
 import sys
 import types
 
-REF_ROOT = os.environ.get("FVK_REFERENCE_ROOT", "/root/reference")
+_STAGED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "reference")  # oracle/stage_ref.py's copy (GPU box)
+
+
+def _default_root() -> str:
+    if "FVK_REFERENCE_ROOT" in os.environ:
+        return os.environ["FVK_REFERENCE_ROOT"]
+    if os.path.isdir("/root/reference/fastvideo"):
+        return "/root/reference"
+    return _STAGED
+
+
+REF_ROOT = _default_root()
 _STUBS = {"imageio", "torchvision", "diffusers", "remote_pdb"}
 _state = {"installed": False, "dist": False}
 
