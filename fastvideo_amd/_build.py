@@ -1,5 +1,5 @@
-"""Build libfvk_amd.so (hipcc, gfx950) in-tree.  Called by ``__graft_entry__.build()`` and, lazily, by
-``fastvideo_amd._lib`` when the library is missing but hipcc is present (developer convenience).
+"""Build libfvk_amd.so (hipcc, gfx950) in-tree.  Called by ``__graft_entry__.build()`` (and by ``bench.py`` through it).
+``fastvideo_amd._lib.load()`` never builds: a missing library is an error there (no silent slow path).
 The built .so lives next to the sources so that it travels with the repo snapshot to the GPU box."""
 from __future__ import annotations
 

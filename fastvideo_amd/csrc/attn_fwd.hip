@@ -364,6 +364,16 @@ int check_common(const fvk_attn_args* a, const char* fn) {
     FVK_CHECK(a->q_ss % 8 == 0 && a->k_ss % 8 == 0 && a->o_ss % 4 == 0 && a->q_hs % 8 == 0 && a->k_hs % 8 == 0 &&
                   a->o_hs % 4 == 0 && a->q_bs % 8 == 0 && a->k_bs % 8 == 0 && a->o_bs % 4 == 0,
               FVK_ERR_ARG, "%s: strides must keep 16-byte alignment of head rows", fn);
+    // The K / V^T streams are addressed through 32-bit buffer descriptors and byte offsets relative to the (batch, head) slice
+    // (attn_pp2.hip / attn_pp.hip / this file: make_buffer_rsrc range, per-piece voffsets, tile strides).  A slice whose extent —
+    // including the up-to-two 128-key tiles a prefetch may address past the end — reaches 4 GiB would wrap silently: refuse it.
+    const long k_rows = ((long)a->Skv + 127) / 128 * 128 + 128;
+    const long k_extent = (k_rows * a->k_ss + (a->qk_dim == 384 ? 384 : 128)) * 2;
+    FVK_CHECK(a->k_ss >= 0 && k_extent < (1L << 32), FVK_ERR_ARG,
+              "%s: one (batch, head) K slice spans %ld bytes >= 4 GiB (Skv=%d keys x row stride %ld elements): 32-bit buffer offsets "
+              "would wrap; pass K with a narrower row stride (e.g. a contiguous [S, H, D] copy) or split the key range",
+              fn, k_extent, a->Skv, (long)a->k_ss);
+    FVK_CHECK(256L * a->Skv_pad < (1L << 32), FVK_ERR_ARG, "%s: V^T rows of %d keys exceed the 4 GiB descriptor range", fn, a->Skv_pad);
     return FVK_OK;
 }
 
@@ -371,14 +381,13 @@ template <int NW, int MODE, int DK = 128, int NL = 0, int PAIRS = 1>
 int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
     constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES;
     constexpr int LDS = PAIRS * 2 * STAGE_BYTES;
-    static bool configured = false;
-    if (!configured) {
+    static bool configured[FVK_MAX_DEVICES] = {};
+    if (fvk_needs_lds_config(configured)) {
         if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE, DK, NL, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
             hipSuccess) {
             fvk_set_error("fvk_attn: cannot set dynamic LDS size");
             return FVK_ERR_LAUNCH;
         }
-        configured = true;
     }
     const int bmq = NW * 32;
     const long nlists = (a->Sq + bmq - 1) / bmq;

@@ -274,13 +274,12 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
 
 template <bool PROBE, bool PRIO>
 static int launch_pp2(const fvk_attn_args* a, hipStream_t s) {
-    static bool configured = false;
-    if (!configured) {
+    static bool configured[FVK_MAX_DEVICES] = {};
+    if (fvk_needs_lds_config(configured)) {
         if (hipFuncSetAttribute((const void*)attn_pp2_kernel<PROBE, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
             fvk_set_error("fvk_attn_dense_bf16 (pp2): cannot set dynamic LDS size");
             return FVK_ERR_LAUNCH;
         }
-        configured = true;
     }
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
     hipLaunchKernelGGL((attn_pp2_kernel<PROBE, PRIO>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a);

@@ -33,6 +33,18 @@ void fvk_set_error(const char* fmt, ...);
         }                                                                      \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device): a process that drives several GPUs must set it
+// on each.  `flags` = one function-local static array per kernel instantiation; returns true when the caller still has to set the
+// attribute on the CURRENT device.
+#define FVK_MAX_DEVICES 64
+inline bool fvk_needs_lds_config(bool* flags) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FVK_MAX_DEVICES) return true;  // unknown device: always (re)configure
+    if (flags[dev]) return false;
+    flags[dev] = true;
+    return true;
+}
+
 // device helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ bf16x8 ld_bf16x8(const void* p) {
     uint4 u = *reinterpret_cast<const uint4*>(p);

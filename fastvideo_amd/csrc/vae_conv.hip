@@ -288,14 +288,13 @@ int launch(ConvArgs a, hipStream_t s) {
     constexpr int TM = WNW == 1 ? 512 : 256;
     constexpr int TN = WNW == 1 ? 96 : 192;
     constexpr int LDS = NSLOT * (TM + TN) * 64 + 1024;
-    static bool configured = false;
-    if (!configured) {
+    static bool configured[FVK_MAX_DEVICES] = {};
+    if (fvk_needs_lds_config(configured)) {
         if (hipFuncSetAttribute((const void*)vae_conv_kernel<WNW, EPI, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
             hipSuccess) {
             fvk_set_error("fvk_vae_conv_bf16: cannot set dynamic LDS size %d", LDS);
             return FVK_ERR_LAUNCH;
         }
-        configured = true;
     }
     a.ntm = (a.M + TM - 1) / TM;
     a.ntn = (a.Cout + TN - 1) / TN;

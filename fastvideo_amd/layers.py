@@ -174,14 +174,15 @@ def _full_tables(cos: torch.Tensor, sin: torch.Tensor, head_size: int):
 
 
 def apply_rotary_emb(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, is_neox_style: bool = False) -> torch.Tensor:
-    """Drop-in for ``_apply_rotary_emb`` (rotary_embedding.py:105-150) as the Wan path calls it (attention/layer.py:130-132):
-    x [..., S, H, D] bf16, cos/sin [S, D/2] fp32, GPT-J (interleaved pair) style; fp32 rotation, one rounding to bf16."""
-    if is_neox_style:
-        raise NotImplementedError("apply_rotary_emb: the gfx950 kernel implements the interleaved (GPT-J) style the Wan DiT uses")
+    """Drop-in for ``_apply_rotary_emb`` (rotary_embedding.py:105-150) as the Wan path calls it (attention/layer.py:130-132,
+    wanvideo.py:679-687): x [..., S, H, D] bf16 and FULL-WIDTH fp32 tables cos/sin [S, D] (each pair's value repeated) — the
+    reference's ``rope_dim == head_size`` branch, ``x.float()*cos + rotate(x).float()*sin`` rounded once; ``is_neox_style`` is
+    ignored there, as in the reference.  Half-width tables [S, D/2] are served for the interleaved (GPT-J) style, which is the
+    same rotation; the Neox half-split style is refused."""
     _require_rocm_bf16(x, "x")
     S, H, D = x.shape[-3], x.shape[-2], x.shape[-1]
-    if cos.shape[-1] == D:
-        raise NotImplementedError("apply_rotary_emb: full-width (rotate_half) tables are the HunyuanVideo form, not on the Wan path")
+    if cos.shape[-1] != D and is_neox_style:
+        raise NotImplementedError("apply_rotary_emb: the gfx950 kernel rotates interleaved pairs (the Wan DiT's form), not Neox halves")
     if cos.shape[0] != S:
         raise ValueError(f"rotary tables hold {cos.shape[0]} positions, x has {S} tokens")
     c, s = _full_tables(cos.to(x.device), sin.to(x.device), D)

@@ -29,6 +29,10 @@ def _chk(t: torch.Tensor, dtype, name: str):
         raise RuntimeError(f"fastvideo_amd: {name} must be a ROCm device tensor (the HIP path has no CPU fallback)")
     if t.dtype != dtype:
         raise RuntimeError(f"fastvideo_amd: {name} must be {dtype}, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        # launches go to torch.cuda.current_stream() of the CURRENT device: a tensor of another GPU would be dereferenced there
+        raise RuntimeError(f"fastvideo_amd: {name} lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "wrap the call in torch.cuda.device(tensor.device)")
     return t
 
 
@@ -548,7 +552,8 @@ def unpatchify(x, latent_shape, patch=(1, 2, 2)):
 
 
 def timestep_embedding(t, dim, max_period=10000.0):
-    t = t.to(device="cuda", dtype=torch.float32).contiguous()
+    t = t.to(device=t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device()), dtype=torch.float32).contiguous()
+    _chk(t, torch.float32, "t")
     out = torch.empty((t.shape[0], dim), dtype=BF16, device=t.device)
     _lib.call("fvk_timestep_embedding_bf16", _p(t), _p(out), t.shape[0], dim, float(max_period), _stream())
     return out

@@ -119,8 +119,14 @@ class DenoisingLoopHip:
 
     def __init__(self, transformer, num_inference_steps: int, flow_shift: float = 3.0, guidance_scale: float = 1.0,
                  transformer_2=None, boundary_ratio: float | None = None, guidance_scale_2: float | None = None,
-                 num_train_timesteps: int = 1000):
-        """``transformer_2`` / ``boundary_ratio`` / ``guidance_scale_2``: Wan2.2-A14B's two experts — steps with
+                 num_train_timesteps: int = 1000, scalar_rounding: str = "fp32"):
+        """``scalar_rounding``: "fp32" (default) keeps the 0-d ``sigma_t`` / Python ``guidance_scale`` operands in fp32 inside the step
+        kernel — what the reference's eager elementwise kernels do ON THE GPU with a CPU-scalar operand, i.e. what a user of the
+        reference on an accelerator gets; "bf16" reproduces the reference's CPU eager path (the scalar is cast to the tensor dtype
+        first), which is what ``oracle/sched_oracle.py`` and ``tests/golden/unipc.pt`` pin bit-exactly (``FlowUniPCStepper``'s own
+        default, used by the golden tests).  The two differ by at most one bf16 ulp of the product per step.
+
+        ``transformer_2`` / ``boundary_ratio`` / ``guidance_scale_2``: Wan2.2-A14B's two experts — steps with
         t >= boundary_ratio * num_train_timesteps run the high-noise expert with ``guidance_scale``, the rest run ``transformer_2``
         with ``guidance_scale_2`` (denoising.py:251-256, 377-403).  Both experts stay resident (2 x 28 GB of bf16 weights in 288 GB
         of HBM), so the reference's per-boundary CPU offload shuffle has no counterpart here."""
@@ -130,7 +136,8 @@ class DenoisingLoopHip:
         self.boundary_timestep = None if boundary_ratio is None else boundary_ratio * num_train_timesteps
         if self.boundary_timestep is not None and transformer_2 is None:
             raise ValueError("DenoisingLoopHip: boundary_ratio given without transformer_2 (the low-noise expert)")
-        self.stepper = FlowUniPCStepper(num_inference_steps, shift=flow_shift, num_train_timesteps=num_train_timesteps)
+        self.stepper = FlowUniPCStepper(num_inference_steps, shift=flow_shift, num_train_timesteps=num_train_timesteps,
+                                        scalar_rounding=scalar_rounding)
 
     def expert_for(self, t: float):
         """(model, guidance scale) of the step at timestep t (denoising.py:377-403)."""

@@ -174,9 +174,11 @@ def block_sparse_attn(q, k, v, block_map: np.ndarray, vbs: np.ndarray, block: in
     return torch.matmul(torch.softmax(s, dim=-1), v.float())
 
 
-def video_sparse_attn(q, k, v, vbs, q_vbs, topk: int, block_elements: int = 64, gate=None):
+def video_sparse_attn(q, k, v, vbs, q_vbs, topk: int, block_elements: int = 64, gate=None, mask_override=None):
     """``video_sparse_attn`` — fastvideo-kernel/python/fastvideo_kernel/ops.py:65-133.
-    q,k,v(,gate) [B,H,S_pad,D] bf16.  Returns (out bf16, dict of intermediates)."""
+    q,k,v(,gate) [B,H,S_pad,D] bf16.  Returns (out bf16, dict of intermediates).
+    ``mask_override`` (bool [B,H,Nq,Nkv]) replaces the top-k selection: tests feed the mask the device computed from ITS coarse
+    scores (a bf16 ulp in one score can flip a near-tie), so that the composite is compared block for block."""
     B, H, S, D = q.shape
     q_c = block_mean(q, q_vbs, block_elements)
     k_c = block_mean(k, vbs, block_elements)
@@ -185,7 +187,7 @@ def video_sparse_attn(q, k, v, vbs, q_vbs, topk: int, block_elements: int = 64, 
     attn = torch.softmax(scores, dim=-1)
     out_c = torch.matmul(attn, v_c)
     out_c = out_c.view(B, H, S // block_elements, 1, D).repeat(1, 1, 1, block_elements, 1).view(B, H, S, D)
-    mask = topk_mask_bisect(scores.float().numpy(), topk)
+    mask = topk_mask_bisect(scores.float().numpy(), topk) if mask_override is None else mask_override
     out_s = block_sparse_attn(q, k, v, mask, vbs, block_elements).to(q.dtype)
     out = out_c * gate + out_s if gate is not None else out_c + out_s
     return out, dict(q_c=q_c, k_c=k_c, v_c=v_c, scores=scores, mask=mask, out_c=out_c, out_s=out_s)

@@ -57,6 +57,39 @@ def test_argument_checks_of_the_newer_entries(lib):
     lib.call("fvk_set_tunable", b"vsa_impl", 0)
 
 
+def test_attention_refuses_slices_beyond_the_32bit_descriptor_range(lib):
+    """The K / V^T streams are addressed with 32-bit buffer descriptors and byte offsets per (batch, head) slice (attn_pp2.hip,
+    attn_fwd.hip).  Wan2.2-A14B at 129f x 720p with K read in place from a fused [S, 4*5120] QKV+gate buffer is 138 240 keys x
+    40 960 B = 5.7 GB: offsets would wrap silently.  The host check refuses it before any launch (so it is testable here)."""
+    import ctypes as C
+    buf = (C.c_char * 4096)()
+    p = C.cast(buf, C.c_void_p).value
+
+    def args(skv, k_ss, h=40):
+        a = lib.AttnArgs()
+        a.q = a.k = a.vt = a.o = p
+        a.lse = None
+        a.B, a.H, a.Sq, a.Skv, a.Skv_pad = 1, h, skv, skv, (skv + 127) // 128 * 128
+        a.q_bs = a.k_bs = a.o_bs = 0
+        a.q_ss, a.q_hs, a.k_ss, a.k_hs, a.o_ss, a.o_hs = h * 128, 128, k_ss, 128, h * 128, 128
+        a.scale, a.qk_dim = 128**-0.5, 0
+        return a
+
+    bad = args(138240, 4 * 5120)
+    for entry, extra in (("fvk_attn_dense_bf16", ()), ("fvk_attn_block_sparse_bf16", (p, p, p, 8, 64)),
+                         ("fvk_attn_sta_bf16", (6, 6, 10, 384, (C.c_int32 * 120)(*([3] * 120))))):
+        with pytest.raises(RuntimeError, match="4 GiB"):
+            lib.call(entry, C.byref(bad), *extra, None)
+    # the same keys in a contiguous [S, H, D] copy (what wan_dit.py hands over: 10 240 B per token) are inside the range:
+    # the check passes and the call proceeds to the launch, which is what fails on a GPU-less host
+    if not torch.cuda.is_available():  # (with a device present the call would really launch on the dummy pointers)
+        ok = args(138240, 5120)
+        try:
+            lib.call("fvk_attn_dense_bf16", C.byref(ok), None)
+        except RuntimeError as e:
+            assert "4 GiB" not in str(e)
+
+
 @pytest.mark.parametrize("shape", [(8, 16, 16), (9, 10, 7), (5, 7, 3), (2, 2, 2), (21, 30, 52)])
 def test_vsa_metadata_host_bit_exact(lib, shape):
     from fastvideo_amd import ops
