@@ -27,7 +27,55 @@ import torch.distributed as dist  # noqa: E402
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md); never the 2:1-sparse figure
 
 
-def cpu_baseline(cfg, S, L_text, budget_s=25.0):
+def cpu_baseline_reference(cfg, latent_shape, S, L_text, sample_layers=2):
+    """The REFERENCE ITSELF: hao-ai-lab/FastVideo's own ``WanTransformer3DModel`` through its
+    ``SDPABackend`` (fastvideo/models/dits/wanvideo.py, fastvideo/attention/backends/sdpa.py), imported with the App. A harness from
+    /root/reference or from the copy staged by oracle/stage_ref.py, fp32 on the host cores.  BOUNDED sample of the same workload:
+    the full cfg latent, ``sample_layers`` of the model's transformer blocks; each block is timed by forward hooks, and the forward
+    is extrapolated as (mean block time) x num_layers + (measured time outside the blocks).  Returns None when no reference tree
+    is present (the caller then falls back to the port)."""
+    from oracle import ref_loader as R
+    if not R.available():
+        return None
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)  # torch CPU GEMM/SDPA stop scaling (and oversubscribe) far below 256 threads
+    torch.set_num_threads(threads)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    model = R.build_wan(num_heads=cfg.num_heads, head_dim=cfg.head_dim, ffn_dim=cfg.ffn_dim, num_layers=sample_layers,
+                        text_dim=cfg.text_dim, seed=0)
+    from fastvideo.forward_context import set_forward_context
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(latent_shape, generator=g)
+    ctx = torch.randn((1, L_text, cfg.text_dim), generator=g)
+    marks = []
+    for blk in model.blocks:
+        blk.register_forward_pre_hook(lambda m, a: marks.append(("in", time.perf_counter())))
+        blk.register_forward_hook(lambda m, a, o: marks.append(("out", time.perf_counter())))
+
+    def run(lat):
+        marks.clear()
+        t0 = time.perf_counter()
+        with torch.no_grad(), set_forward_context(current_timestep=0, attn_metadata=None):
+            model(hidden_states=lat, encoder_hidden_states=ctx, timestep=torch.tensor([500]))
+        return time.perf_counter() - t0
+
+    run(torch.randn((1, latent_shape[1], 2, 8, 8), generator=g))  # warm-up: thread pool, oneDNN primitives
+    total = run(x)
+    ins = [t for k, t in marks if k == "in"]
+    outs = [t for k, t in marks if k == "out"]
+    blocks = [b - a for a, b in zip(ins, outs)]
+    per_block = sum(blocks) / len(blocks)
+    per_forward = per_block * cfg.num_layers + (total - sum(blocks))
+    return dict(value=round(S / per_forward, 2), unit="latent-tokens/s", cores=threads, kind="reference",
+                sample=f"the reference's WanTransformer3DModel (fastvideo/models/dits/wanvideo.py, SDPABackend, torch CPU fp32, {threads} threads of "
+                       f"{cores} cores) with {sample_layers} of {cfg.num_layers} blocks, one forward on the full latent {list(latent_shape)}: "
+                       f"{total:.2f} s, blocks {', '.join(f'{b:.2f}' for b in blocks)} s; forward = mean block x {cfg.num_layers} + "
+                       f"{total - sum(blocks):.2f} s outside the blocks", ms_per_step=round(per_forward * 1e3, 1),
+                reference_root=("live checkout" if R.REF_ROOT.startswith("/root/reference") else "oracle/_ref (staged by oracle/stage_ref.py)"))
+
+
+def cpu_baseline_port(cfg, S, L_text, budget_s=25.0):
     """Reference-algorithm CPU baseline ("port" = oracle/wan_oracle.py, the restatement of the reference eager path that is
     pinned bit-exact against the real reference) on a BOUNDED sample: ONE of the 30 transformer blocks, fp32 weights and
     activations (the reference's CPU harness dtype), at the largest sequence length whose block fits the time
@@ -70,6 +118,158 @@ def cpu_baseline(cfg, S, L_text, budget_s=25.0):
                 ms_per_step=round(per_forward * 1e3, 1))
 
 
+
+def cpu_baseline(cfg, latent_shape, S, L_text, kind="auto"):
+    if kind in ("auto", "reference"):
+        try:
+            out = cpu_baseline_reference(cfg, latent_shape, S, L_text)
+            if out is not None:
+                return out
+            if kind == "reference":
+                return {"error": "no reference tree (neither /root/reference nor oracle/_ref/reference)"}
+        except Exception as ex:  # noqa: BLE001 - fall back to the port, but say why
+            port = cpu_baseline_port(cfg, S, L_text)
+            port["reference_error"] = repr(ex)[:300]
+            return port
+    return cpu_baseline_port(cfg, S, L_text)
+
+
+def attention_traffic_from_profiles():
+    """HBM-side bytes per launch of the dominant kernel from the newest committed PMC pass (profiles/*pmc_attn_pp2*.json, written by
+    scripts/pmc_traffic.sh from `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes with the gfx950 x2 FETCH correction; counters cannot be
+    collected inside the timed run).  A pass only counts if it recorded the sha256 of the kernel source it measured and that still matches
+    the source in the tree: a stale number is reported as null, never silently."""
+    import glob
+    import hashlib
+    src = os.path.join(ROOT, "fastvideo_amd", "csrc", "attn_pp2.hip")
+    cur = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attn_pp2*.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        if j.get("kernel_source_sha256") == cur and j.get("traffic_bytes_per_launch"):
+            best = (j["traffic_bytes_per_launch"], os.path.basename(f))
+    return best if best else (None, "no PMC pass for the current attn_pp2.hip (run scripts/pmc_traffic.sh)")
+
+
+def vae_cpu_baseline(latent_shape, budget_frames=3):
+    """CPU baseline of the VAE stage on a bounded sample: the reference's own ``AutoencoderKLWan.decode`` (fp32, its
+    default precision) on the first ``budget_frames`` latent frames at the full spatial size, when a reference tree is present (live or
+    staged); else the oracle port (oracle/vae_oracle.py).  Scaled to the full latent by algorithmic FLOPs."""
+    from fastvideo_amd.wan_config import vae_decode_flops
+    _, _, T, H, W = latent_shape
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn((1, 16, budget_frames, H, W), generator=g)
+    kind, where = "port", "oracle/vae_oracle.py"
+    t = None
+    try:
+        from oracle import ref_loader as R
+        if R.available():
+            from oracle.make_golden_vae import build_ref_vae
+            vae = build_ref_vae(base_dim=96, seed=0)
+            with torch.no_grad():
+                vae.decode(torch.randn((1, 16, 1, 8, 8), generator=g))  # warm-up
+                t0 = time.perf_counter()
+                vae.decode(z)
+                t = time.perf_counter() - t0
+            kind, where = "reference", "the reference's AutoencoderKLWan.decode (fastvideo/models/vaes/wanvae.py:1189-1215)"
+    except Exception as ex:  # noqa: BLE001
+        where += f" (reference unavailable: {repr(ex)[:120]})"
+    if t is None:
+        from oracle import vae_oracle as VO
+        from fastvideo_amd.wan_config import wan_vae_param_spec
+        sd = VO.seeded_state_dict(wan_vae_param_spec(base_dim=96), 0)
+        dec = VO.WanVaeDecoderOracle(sd)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            dec.decode(z)
+            t = time.perf_counter() - t0
+    scale = vae_decode_flops(T, H, W) / vae_decode_flops(budget_frames, H, W)
+    per_decode = t * scale
+    frames = 1 + 4 * (T - 1)
+    return dict(value=round(frames / per_decode, 3), unit="pixel-frames/s", cores=threads, kind=kind,
+                sample=f"{where}, torch CPU fp32, {threads} threads of {cores} cores, latent [1,16,{budget_frames},{H},{W}] in {t:.2f} s, "
+                       f"scaled by algorithmic FLOPs x{scale:.2f} to {T} latent frames", ms_per_step=round(per_decode * 1e3, 1))
+
+
+def run_vae(args):
+    """--stage vae: one step = one causal-3D-conv VAE decode (``AutoencoderKLWan.decode``, fastvideo/models/vaes/wanvae.py:1189-1215) of the
+    config's latent on ONE GPU: cfg2 [1,16,21,60,104] -> [1,3,81,480,832], cfg5 [1,16,33,90,160] -> [1,3,129,720,1280]; random-init
+    Wan2.1-VAE decoder (base_dim 96, 73 M parameters).  Activations bf16 with fp32 accumulation — NARROWER than the reference's default
+    fp32 VAE (stated in `dtype`); the parity tests bound the difference against the fp32 reference decode."""
+    import __graft_entry__ as G
+    G.build()
+    from fastvideo_amd import ops
+    from fastvideo_amd.wan_config import vae_decode_flops, wan_vae_param_spec
+    from fastvideo_amd.wan_vae import WanVaeDecoderHip
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or args.gpus != 1:
+        raise SystemExit("--stage vae is a single-GPU line (tile-parallel decode is covered by tests, not benchmarked here)")
+    latent_shape = {"cfg2": (1, 16, 21, 60, 104), "cfg5": (1, 16, 33, 90, 160), "cfg1": (1, 16, 9, 64, 64), "cfg4": (1, 16, 21, 90, 160)}[args.config]
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for n, shp in wan_vae_param_spec(base_dim=96):
+        fan_in = 1
+        for d in shp[1:]:
+            fan_in *= d
+        sd[n] = (torch.ones(shp) if "gamma" in n else ((torch.rand(shp, generator=g) * 2 - 1) * (3.0 / fan_in)**0.5 if len(shp) >= 4 else torch.zeros(shp)))
+    dec = WanVaeDecoderHip(sd, device="cuda")
+    z = torch.randn(latent_shape, generator=g).cuda()
+    for _ in range(max(args.warmup, 1)):
+        y = dec.decode(z)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = dec.decode(z)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if not torch.isfinite(y).all():
+        raise SystemExit("non-finite output")
+    # roofline leg: per-launch HIP events around every conv launch of ONE extra decode (events inside the timed region would perturb it)
+    ops.VAE_CONV_EVENTS = []
+    dec.decode(z)
+    torch.cuda.synchronize()
+    ev, ops.VAE_CONV_EVENTS = ops.VAE_CONV_EVENTS, None
+    groups = {}
+    for taps, cin, cout, fl, e0, e1 in ev:
+        k = "vae_conv3_kernel (3x3 spatial taps, halo slabs in LDS)" if taps.endswith("3x3") else "vae_conv_kernel (1x1 / temporal taps)"
+        gsum = groups.setdefault(k, [0.0, 0.0, 0])
+        gsum[0] += fl
+        gsum[1] += e0.elapsed_time(e1)
+        gsum[2] += 1
+    dom = max(groups, key=lambda k: groups[k][1])
+    fl_d, ms_d, n_d = groups[dom]
+    achieved = fl_d / (ms_d * 1e-3) / 1e12
+    ms = elapsed / args.steps * 1e3
+    fl = vae_decode_flops(*latent_shape[2:])
+    frames = y.shape[2]
+    out = {"metric": f"Wan2.1 VAE decode, latent {list(latent_shape)} -> pixels {list(y.shape)} (one decode per step)",
+           "value": round(frames / (elapsed / args.steps), 2), "unit": "pixel-frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16 activations, fp32 accumulation and fp32 output (the reference's default VAE precision is fp32)",
+           "data": "synthetic (randn latent, random-init decoder)",
+           "config": {"workload": f"Wan2.1 VAE decoder (base_dim 96), frame-chunked cached decode of latent {list(latent_shape)}", "parallelism": "1 GPU"},
+           "step_tflops": round(fl / (ms * 1e-3) / 1e12, 1), "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+           "roofline": dict(bound="mfma", kernel=dom, achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                            frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None, flops_per_launch=fl_d / n_d,
+                            mean_launch_ms=round(ms_d / n_d, 4), launches=n_d, share_of_step=round(ms_d / ms, 3),
+                            other_kernels={k: dict(ms=round(v[1], 2), tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), launches=v[2])
+                                           for k, v in groups.items() if k != dom}),
+           "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+    if not args.no_cpu_baseline:
+        try:
+            import contextlib
+            with contextlib.redirect_stdout(sys.stderr):
+                out["cpu_baseline"] = vae_cpu_baseline(latent_shape)
+        except Exception as ex:  # noqa: BLE001
+            out["cpu_baseline"] = {"error": repr(ex)[:300]}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,8 +282,14 @@ def main():
     ap.add_argument("--quant", default=None, choices=["fp8", "fp8_channel"],
                     help="fp8 linear path (BASELINE config 5's GEMM dtype); the contract line is the default bf16 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-kind", default="auto", choices=["auto", "reference", "port"],
+                    help="auto: the reference itself when a reference tree is present (live or staged), else the oracle port")
+    ap.add_argument("--stage", default="dit", choices=["dit", "vae"],
+                    help="dit (default, the contract line): one DiT forward per step; vae: one causal-3D-conv VAE decode of the same latent per step")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
     args = ap.parse_args()
+    if args.stage == "vae":
+        return run_vae(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -169,16 +375,11 @@ def main():
         flops_launch = 4.0 * Sq * Skv * h * cfg.head_dim * dens
         kname = f"{args.attention} self-attention (gather + attn_fwd_kernel block-sparse + untile), density {dens:.3f} of dense"
     achieved = flops_launch / (mean_ms * 1e-3) / 1e12
-    traffic = None
+    traffic, traffic_src = None, None
     if args.attention == "dense" and args.config == "cfg2" and world == 1:
-        # HBM-side bytes per launch of this kernel at this shape from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
-        # gfx950 correction applied; counters cannot be collected inside the timed run)
-        try:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r01_final_pmc_attn_pp2.json")))["traffic_bytes_per_launch"]
-        except Exception:  # noqa: BLE001
-            traffic = None
+        traffic, traffic_src = attention_traffic_from_profiles()
     roof = dict(bound="mfma", kernel=kname, achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS,
-                unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic,
+                unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                 flops_per_launch=flops_launch, mean_launch_ms=round(mean_ms, 4), launches=len(attn_ms),
                 share_of_step=round(sum(attn_ms) / args.steps / (elapsed / args.steps * 1e3), 3))
     fl = WC.algorithmic_flops(cfg, S, L_text)
@@ -205,7 +406,9 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg, S, L_text)
+                import contextlib
+                with contextlib.redirect_stdout(sys.stderr):  # the reference's logger writes to stdout: keep the ONE JSON line alone there
+                    out["cpu_baseline"] = cpu_baseline(cfg, latent_shape, S, L_text, args.cpu_baseline_kind)
             except Exception as ex:  # the baseline must never hide the GPU number
                 out["cpu_baseline"] = {"error": repr(ex)[:300]}
         print(json.dumps(out), flush=True)

@@ -457,7 +457,10 @@ extern "C" int fvk_attn_sta_bf16(const fvk_attn_args* a, int ct, int ch, int cw,
     ModeArgs ma{};
     ma.ct = ct; ma.ch = ch; ma.cw = cw; ma.tile_tokens = tile_tokens;
     for (int i = 0; i < 3 * a->H; ++i) {
-        FVK_CHECK(win_host[i] >= 1 && (win_host[i] & 1), FVK_ERR_ARG, "fvk_attn_sta_bf16: window sizes must be odd and >= 1");
+        // Even sizes are legal in the reference (its own test uses (3,1,10), fastvideo-kernel/tests/test_sta.py:40): the mask rule is
+        // |clamp(q, k/2, n-1-k/2) - kv| <= k/2 with INTEGER k/2 (support_flex_sta.py:44-51), i.e. an even k acts like k+1; when
+        // k/2 > n-1-k/2 both clamp orders (torch.clamp / st_attn_triton.py:52-56) select the whole axis.
+        FVK_CHECK(win_host[i] >= 1, FVK_ERR_ARG, "fvk_attn_sta_bf16: window sizes must be >= 1");
         ma.win[i] = win_host[i];
     }
     return launch<4, MODE_STA>(a, ma, (hipStream_t)stream);

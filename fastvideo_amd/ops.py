@@ -305,6 +305,19 @@ def attn_dense_wide(q, k, v, scale=None):
 
 # ------------------------------------------------------------------ Wan VAE decode
 VAE_EPI_BIAS, VAE_EPI_RESIDUAL, VAE_EPI_FINAL = 0, 1, 2
+# bench.py's roofline leg: set to a list to collect (taps "ktxksxks", Cin, Cout, algorithmic FLOPs, start event, end event) per conv
+# launch, recorded on the launch stream around the kernel alone.  None (default) = no events, nothing extra on the stream.
+VAE_CONV_EVENTS = None
+
+
+def _conv_timed(kt, ks, Cin, Cout, T, H, W, launch):
+    if VAE_CONV_EVENTS is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    VAE_CONV_EVENTS.append((f"{kt}x{ks}x{ks}", Cin, Cout, 2.0 * T * H * W * Cout * kt * ks * ks * Cin, e0, e1))
 
 
 def vae_conv(inp, w, bias, *, T, H, W, kt, ks, ring_start=0, out=None, out_frame_stride=None, residual=None,
@@ -334,9 +347,10 @@ def vae_conv(inp, w, bias, *, T, H, W, kt, ks, ring_start=0, out=None, out_frame
                 res_frame_stride = H * W * Cout
     if bias is not None:
         _chk(bias, BF16, "bias")
-    _lib.call("fvk_vae_conv_bf16", _p(inp), _p(w), _p(bias), _p(out), _p(residual), _p(out_f32), T, H, W, Cin, Cout, kt, ks, ks,
-              ring, int(ring_start), int(out_frame_stride or 0), int(res_frame_stride or 0), int(plane_stride), int(upsample2x), epi,
-              _stream())
+    _conv_timed(kt, ks, Cin, Cout, T, H, W, lambda: _lib.call(
+        "fvk_vae_conv_bf16", _p(inp), _p(w), _p(bias), _p(out), _p(residual), _p(out_f32), T, H, W, Cin, Cout, kt, ks, ks,
+        ring, int(ring_start), int(out_frame_stride or 0), int(res_frame_stride or 0), int(plane_stride), int(upsample2x), epi,
+        _stream()))
     return out if out_f32 is None else out_f32
 
 
@@ -367,9 +381,10 @@ def vae_conv_norm(inp, w, bias, gamma, norm_ring_buf, *, T, H, W, kt, norm_slot0
             res_frame_stride = H * W * Cout
     if bias is not None:
         _chk(bias, BF16, "bias")
-    _lib.call("fvk_vae_conv_norm_bf16", _p(inp), _p(w), _p(bias), _p(out), _p(residual), T, H, W, Cin, Cout, kt, ring, int(ring_start),
-              int(out_frame_stride or 0), int(res_frame_stride or 0), int(upsample2x), _p(gamma), _p(norm_ring_buf), norm_ring_buf.shape[0],
-              int(norm_slot0), int(silu), _stream())
+    _conv_timed(kt, 3, Cin, Cout, T, H, W, lambda: _lib.call(
+        "fvk_vae_conv_norm_bf16", _p(inp), _p(w), _p(bias), _p(out), _p(residual), T, H, W, Cin, Cout, kt, ring, int(ring_start),
+        int(out_frame_stride or 0), int(res_frame_stride or 0), int(upsample2x), _p(gamma), _p(norm_ring_buf), norm_ring_buf.shape[0],
+        int(norm_slot0), int(silu), _stream()))
     return out
 
 

@@ -91,6 +91,10 @@ def install() -> None:
     from fastvideo.platforms.cpu import CpuPlatform
     CpuPlatform.get_attn_backend_cls = classmethod(
         lambda c, sel, hs, dt: "fastvideo.attention.backends.sdpa.SDPABackend")
+    # The harness runs the reference on the HOST cores everywhere — also on the GPU box, where the reference's platform probe
+    # (fastvideo/platforms/__init__.py:117-157, amdsmi) could otherwise resolve to RocmPlatform: pin the CPU platform.
+    import fastvideo.platforms as _P
+    _P._current_platform = CpuPlatform()
     import torch
     import fastvideo.distributed.parallel_state as ps
     ps.get_local_torch_device = lambda: torch.device("cpu")

@@ -180,3 +180,27 @@ def test_sta_mask_matches_tile_lists():
         got = sorted(set((torch.nonzero(row).flatten() // tv).tolist()))
         assert got == kvs
         assert len(kvs) == min(kern[0], ct[0]) * min(kern[1], ct[1]) * min(kern[2], ct[2])
+
+
+def test_sta_window_even_kernel_sizes_follow_the_reference_mask_rule():
+    """The reference's own STA test uses the EVEN window (3,1,10) (fastvideo-kernel/tests/test_sta.py:40).  The rule is
+    |clamp(q, k//2, n-1-k//2) - kv| <= k//2 with integer k//2 (support_flex_sta.py:44-51): an even k selects like k+1, and when
+    k//2 > n-1-k//2 the two clamp orders in the reference (torch.clamp in the flex mask, cap-then-raise in
+    st_attn_triton.py:52-56) pick different centres but the SAME key set (the whole axis)."""
+
+    def triton_order(q, n, k):  # st_attn_triton.py:52-56, 176-190
+        c = min(q, (n - 1) - k // 2)
+        c = max(c, k // 2)
+        return max(c - k // 2, 0), min(c + k // 2 + 1, n)
+
+    for n in range(1, 13):
+        for k in range(1, 14):
+            for q in range(n):
+                s, e = V.sta_window(q, n, k)
+                mask_rule = [kv for kv in range(n) if abs(int(torch.tensor(q).clamp(k // 2, (n - 1) - k // 2)) - kv) <= k // 2]
+                assert list(range(s, e)) == mask_rule, (n, k, q)
+                ts, te = triton_order(q, n, k)
+                assert list(range(max(ts, 0), te)) == mask_rule, (n, k, q)
+    # the reference test's window on its canvas: 10 tiles wide, k = 10 -> every query tile sees all 10
+    assert all(V.sta_window(q, 10, 10) == (0, 10) for q in range(10))
+    assert V.sta_window(0, 10, 4) == (0, 5) and V.sta_window(9, 10, 4) == (5, 10)  # even 4 behaves like 5
