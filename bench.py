@@ -154,7 +154,7 @@ def attention_traffic_from_profiles():
     return best if best else (None, "no PMC pass for the current attn_pp2.hip (run scripts/pmc_traffic.sh)")
 
 
-def vae_cpu_baseline(latent_shape, budget_frames=3):
+def vae_cpu_baseline(latent_shape, budget_frames=2):
     """CPU baseline of the VAE stage on a bounded sample: the reference's own ``AutoencoderKLWan.decode`` (fp32, its
     default precision) on the first ``budget_frames`` latent frames at the full spatial size, when a reference tree is present (live or
     staged); else the oracle port (oracle/vae_oracle.py).  Scaled to the full latent by algorithmic FLOPs."""

@@ -145,6 +145,12 @@ struct RmsArgs {
     int M, width, head_dim, seq_len, pos_offset;
     long in_stride, out_stride;
     float eps;
+    int rope_mask;       // bit t: tensor t is rotated (when cos/sin are given)
+    // sequence-parallel exchange packing (fvk_qkv_norm_rope_pack_bf16): when pack_dst is set, column block g (pack_W wide) of row m of
+    // tensor t is written to every destination rank rp = g + pack_G*u', u' < pack_U, at pack_dst[((rp*M + m)*3 + pack_slot[t])*pack_W + cc]
+    bf16_t* pack_dst;
+    int pack_G, pack_U, pack_W;
+    int pack_slot[3];
 };
 
 template <int VPL>
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs a) {
         const int c = lane + 64 * i;
         if (c < nchunks) {
             bf16x8 o;
-            if (a.cos) {
+            if (a.cos && ((a.rope_mask >> t) & 1)) {
                 const int dd = (c * 8) % a.head_dim;
                 const float4 c0 = *reinterpret_cast<const float4*>(a.cos + pos + dd);
                 const float4 c1 = *reinterpret_cast<const float4*>(a.cos + pos + dd + 4);
@@ -207,7 +213,15 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs a) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[i][j];
             }
-            st_bf16x8(out + c * 8, o);
+            if (a.pack_dst) {
+                const int col = c * 8, g = col / a.pack_W, cc = col - g * a.pack_W;
+                for (int uu = 0; uu < a.pack_U; ++uu) {
+                    const long rp = g + (long)a.pack_G * uu;
+                    st_bf16x8(a.pack_dst + ((rp * a.M + row) * 3 + a.pack_slot[t]) * a.pack_W + cc, o);
+                }
+            } else {
+                st_bf16x8(out + c * 8, o);
+            }
         }
     }
 }
@@ -338,13 +352,42 @@ extern "C" int fvk_rmsnorm_rope_bf16(const void* const* in, void* const* out, co
         a.w[i] = weight ? (const bf16_t*)weight[i] : nullptr;
     }
     a.cos = cos; a.sin = sin; a.M = M; a.width = width; a.head_dim = head_dim; a.seq_len = seq_len; a.pos_offset = pos_offset;
-    a.in_stride = in_stride; a.out_stride = out_stride; a.eps = eps;
+    a.in_stride = in_stride; a.out_stride = out_stride; a.eps = eps; a.rope_mask = 7;
     int rc = dispatch_vpl(width, [&](auto vpl) {
         hipLaunchKernelGGL((rmsnorm_rope_kernel<decltype(vpl)::value>), dim3((M + 3) / 4, n_tensors), dim3(256), 0,
                            (hipStream_t)stream, a);
         return FVK_OK;
     });
     FVK_CHECK(rc == FVK_OK, rc, "fvk_rmsnorm_rope_bf16: unsupported width=%d", width);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+extern "C" int fvk_qkv_norm_rope_pack_bf16(const void* q, const void* k, const void* v, const void* wq, const void* wk, const float* cos,
+                                           const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset,
+                                           long in_stride, int G, int U, float eps, void* stream) {
+    FVK_CHECK(q && k && v && send, FVK_ERR_ARG, "fvk_qkv_norm_rope_pack_bf16: null pointer");
+    FVK_CHECK(width > 0 && head_dim > 0 && head_dim % 8 == 0 && width % head_dim == 0, FVK_ERR_ARG,
+              "fvk_qkv_norm_rope_pack_bf16: width=%d head_dim=%d", width, head_dim);
+    FVK_CHECK(G >= 1 && U >= 1 && (width / head_dim) % G == 0, FVK_ERR_ARG,
+              "fvk_qkv_norm_rope_pack_bf16: %d heads do not split into G=%d head groups", width / head_dim, G);
+    FVK_CHECK((cos == nullptr) == (sin == nullptr), FVK_ERR_ARG, "fvk_qkv_norm_rope_pack_bf16: cos/sin must both be set");
+    FVK_CHECK(pos_offset >= 0 && seq_len > 0 && in_stride % 8 == 0, FVK_ERR_ARG, "fvk_qkv_norm_rope_pack_bf16: strides must be multiples of 8");
+    if (Sl <= 0) return FVK_OK;
+    RmsArgs a{};
+    a.in[0] = (const bf16_t*)q; a.in[1] = (const bf16_t*)k; a.in[2] = (const bf16_t*)v;
+    a.out[0] = a.out[1] = a.out[2] = (bf16_t*)send;  // unused: every store goes through pack_dst
+    a.w[0] = (const bf16_t*)wq; a.w[1] = (const bf16_t*)wk; a.w[2] = nullptr;  // V: no norm
+    a.cos = cos; a.sin = sin; a.M = Sl; a.width = width; a.head_dim = head_dim; a.seq_len = seq_len; a.pos_offset = pos_offset;
+    a.in_stride = in_stride; a.out_stride = 0; a.eps = eps;
+    a.rope_mask = 3;  // q and k are rotated, v is copied
+    a.pack_dst = (bf16_t*)send; a.pack_G = G; a.pack_U = U; a.pack_W = width / G;
+    a.pack_slot[0] = 2; a.pack_slot[1] = 0; a.pack_slot[2] = 1;  // message row = [K | V | Q] of one token
+    int rc = dispatch_vpl(width, [&](auto vpl) {
+        hipLaunchKernelGGL((rmsnorm_rope_kernel<decltype(vpl)::value>), dim3((Sl + 3) / 4, 3), dim3(256), 0, (hipStream_t)stream, a);
+        return FVK_OK;
+    });
+    FVK_CHECK(rc == FVK_OK, rc, "fvk_qkv_norm_rope_pack_bf16: unsupported width=%d", width);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }

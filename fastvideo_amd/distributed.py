@@ -18,6 +18,15 @@ queries per GPU) at 1.5x the K/V traffic, instead of the reference's hard failur
 RoPE and QK-norm are token-local, so they are applied *before* exchange #1 with global positions (the reference
 applies RoPE after its all-to-all, layer.py:130-132 — same values, one fewer pass over the gathered tensor).
 
+Exchange #1 is ONE ``all_to_all_single`` with equal per-peer blocks in a ROW-INTERLEAVED layout: the message for rank r' is
+``[Sl, 3, W]`` = per token ``[K | V | Q]`` of r'`s head group (W = heads/G * head_dim).  The received buffer is then
+``[P*Sl, 3, heads/G, head_dim]`` — the shape of a fused QKV projection — and attention reads K, V^T and this rank's query rows out of
+it IN PLACE through strides: no unpack copy.  On the device the send buffer is written directly by the norm/RoPE kernel
+(``ops.qkv_norm_rope_pack``): no pack copy either (the reference: ``torch.cat`` + two ``transpose().contiguous()`` per exchange,
+layer.py:117-124, base_device_communicator.py:147-183).  Q travels to all U ranks of a column although only one needs it: xGMI
+links are point-to-point, the exchange lasts as long as its fullest link, and the links to this rank's own query-block row carry
+K+V+Q anyway — uniform blocks cost no wall time and keep the exchange a single equal-split collective.
+
 All functions work on CPU tensors too (layout code is plain torch), which is how the gloo tests exercise them;
 the attention itself is injected (``attn_fn``): the product passes the HIP kernel, tests pass the oracle.
 """
@@ -73,6 +82,27 @@ class SequenceParallel:
         # independent); any rank seeing a difference switches every rank back to the plain exchange.
         self.overlap = P > 1 and os.environ.get("FVK_SP_OVERLAP") == "1"
         self._overlap_checked = False
+        # bench.py's exchange accounting: set ``stats`` to a dict to collect, per exchange kind, the bytes this rank sends to OTHER
+        # ranks and HIP-event pairs around the collective on the caller's stream (None = nothing recorded, nothing extra on the stream)
+        self.stats = None
+
+    def _tick(self):
+        if self.stats is None or self._stage_host:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def _tock(self, e0, kind: str, remote_bytes: int) -> None:
+        if self.stats is None:
+            return
+        rec = self.stats.setdefault(kind, {"calls": 0, "remote_bytes": 0, "events": []})
+        rec["calls"] += 1
+        rec["remote_bytes"] += int(remote_bytes)
+        if e0 is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            rec["events"].append((e0, e1))
 
     # -- sharding with zero padding (ref: distributed/utils.py:63-123, communication_op.py:61-91) ---------------
     def padded_len(self, S: int) -> int:
@@ -128,12 +158,40 @@ class SequenceParallel:
         work = dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group, async_op=True)
         return lambda: (work.wait(), recv, send)[1]  # `send` stays referenced until the exchange has been waited for
 
-    def scatter_heads_gather_seq(self, q, k, v):
-        """q,k,v: this rank's shard [Sl, H, D] (batch 1).  Returns (q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all).
-        ONE all-to-all: the message for rank r' = (g', u') is [K | V (| Q)] of head group g' — Q only if u' is this shard's query block —
-        so a layer costs two collectives (this one and the output exchange) instead of four."""
-        return self._unpack_qkv(*self._pack_qkv(q, k, v), sync=True)
+    # ---- exchange #1, row-interleaved uniform layout ------------------------------------------------------------------------
+    def pack_rows(self, q, k, v):
+        """Layout restatement (plain torch, any device) of what ``ops.qkv_norm_rope_pack`` writes on the GPU: q, k, v [Sl, H, D]
+        (already normed / rotated) -> send [P, Sl, 3, W], message row = [K | V | Q] of the destination's head group.  Used by the
+        CPU (gloo) tests and as the checker of the kernel's layout; the device path never calls it."""
+        L = self.lay
+        Sl, H, D = q.shape
+        W = (H // L.G) * D
+        rows = torch.stack([t.reshape(Sl, L.G, W) for t in (k, v, q)], dim=2)       # [Sl, G, 3, W]
+        return rows.permute(1, 0, 2, 3).repeat(L.U, 1, 1, 1).contiguous()           # rank rp = g + G*u' gets group g
 
+    def exchange_rows(self, send: torch.Tensor) -> torch.Tensor:
+        """send [P, Sl, 3, W] -> recv [P*Sl, 3, hg, D]: row n = s*Sl + m is token m of source rank s = global token n."""
+        L = self.lay
+        P, Sl, _, W = send.shape
+        t0 = self._tick()
+        recv = self._a2a(send.reshape(P * Sl, 3 * W), None, None, P * Sl)
+        self._tock(t0, "exchange1", send.numel() * send.element_size() * (P - 1) // P)
+        return recv.view(P * Sl, 3, W)
+
+    def views_of(self, recv: torch.Tensor, D: int):
+        """(q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all [P*Sl, hg, D]) as strided VIEWS of the received buffer (row stride 3W)."""
+        L = self.lay
+        n, _, W = recv.shape
+        Sl = n // L.P
+        r4 = recv.view(n, 3, W // D, D)
+        return r4[L.u * L.G * Sl:(L.u + 1) * L.G * Sl, 2], r4[:, 0], r4[:, 1]
+
+    def scatter_heads_gather_seq(self, q, k, v):
+        """q,k,v: this rank's shard [Sl, H, D] (batch 1).  Returns (q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all) — views of ONE
+        received buffer.  A layer costs two collectives (this one and the output exchange)."""
+        return self.views_of(self.exchange_rows(self.pack_rows(q, k, v)), q.shape[-1])
+
+    # ---- exchange #1, per-tensor blocks with uneven splits (the pipelined mode's packing) ----------------------------------
     def _pack_qkv(self, q, k, v):
         """q, k, v [Sl, G*hg, D] (heads group-major) -> (send buffer, splits, Sl) of exchange #1."""
         L = self.lay
@@ -164,7 +222,9 @@ class SequenceParallel:
         L = self.lay
         hg, D = o_blk.shape[1], o_blk.shape[2]
         o_in, o_out = self._o_splits(Sl)
+        t0 = self._tick()
         recv = self._a2a(o_blk.contiguous(), o_in, o_out, L.G * Sl)      # [G(g), Sl, hg, D]
+        self._tock(t0, "exchange2", (L.G - 1) * Sl * hg * D * o_blk.element_size())
         return recv.reshape(L.G, Sl, hg, D).permute(1, 0, 2, 3).reshape(Sl, L.G * hg, D).contiguous()
 
     def _o_splits(self, Sl: int):
@@ -195,6 +255,13 @@ class SequenceParallel:
         for (a, b), (hc, done) in zip(cuts, outs):
             out[:, :, a:b] = done().reshape(L.G, Sl, hc, D).permute(1, 0, 2, 3)
         return out.reshape(Sl, H, D)
+
+    def attention_packed(self, send: torch.Tensor, S: int, attn_fn, head_dim: int = 128):
+        """The device path of ``attention``: ``send`` [P, Sl, 3, W] was written by ``ops.qkv_norm_rope_pack`` (norm + RoPE + packing in one
+        kernel).  exchange #1 -> attention on strided views of the received buffer -> exchange #2.  Returns this rank's [Sl, H, D]."""
+        Sl = send.shape[1]
+        q_blk, k_all, v_all = self.views_of(self.exchange_rows(send), head_dim)
+        return self.scatter_seq_gather_heads(attn_fn(q_blk, k_all, v_all, S), Sl)
 
     def attention(self, q, k, v, S: int, attn_fn, extra=None):
         """Distributed self-attention for one batch element.

@@ -317,12 +317,19 @@ class WanTransformer3DModelHip:
             attn = torch.empty((B * Sl, d), dtype=BF16, device=dev) if B > 1 else None
             for bi in range(B):
                 rows = qkv[bi * Sl:(bi + 1) * Sl]
-                q, k = ops.rmsnorm_rope([rows[:, :d], rows[:, d:2 * d]], [b["nq_w"], b["nk_w"]], cos, sin, head_dim=D, seq_len=S,
-                                        eps=self.eps, pos_offset=pos0)
-                v = rows[:, 2 * d:3 * d]
                 gate = rows[:, 3 * d:4 * d].view(Sl, H, D) if nq == 4 else None
                 fn = lambda q_, k_, v_, kv_len, g_=None: self._attn_local(q_, k_, v_, kv_len, grid, g_)
-                o = sp.attention(q.view(Sl, H, D), k.view(Sl, H, D), v.view(Sl, H, D), S, fn, extra=gate).reshape(Sl, d)
+                if P > 1 and gate is None and not sp.overlap:
+                    # sequence parallel: QK-norm + RoPE + the per-peer packing of exchange #1 in ONE kernel (no torch.cat, no unpack —
+                    # attention reads K, V and its query rows out of the received buffer through strides)
+                    send = ops.qkv_norm_rope_pack(rows[:, :d], rows[:, d:2 * d], rows[:, 2 * d:3 * d], b["nq_w"], b["nk_w"], cos, sin,
+                                                  sp.lay.G, sp.lay.U, head_dim=D, seq_len=S, eps=self.eps, pos_offset=pos0)
+                    o = sp.attention_packed(send, S, fn, head_dim=D).reshape(Sl, d)
+                else:
+                    q, k = ops.rmsnorm_rope([rows[:, :d], rows[:, d:2 * d]], [b["nq_w"], b["nk_w"]], cos, sin, head_dim=D, seq_len=S,
+                                            eps=self.eps, pos_offset=pos0)
+                    v = rows[:, 2 * d:3 * d]
+                    o = sp.attention(q.view(Sl, H, D), k.view(Sl, H, D), v.view(Sl, H, D), S, fn, extra=gate).reshape(Sl, d)
                 if B == 1:
                     attn = o
                 else:

@@ -70,6 +70,19 @@ int fvk_rmsnorm_rope_bf16(const void* const* in, void* const* out, const void* c
                           const float* cos, const float* sin, int M, int width, int head_dim, int seq_len,
                           int pos_offset, long in_stride, long out_stride, float eps, void* stream);
 
+/* Sequence-parallel exchange #1 packing fused into the QK-norm / RoPE pass (one read of the fused QKV buffer, no torch.cat):
+ * q,k: RMS-norm across heads (weights wq/wk, NULL = skip) + RoPE (cos/sin NULL = skip); v: copied.  Row m of the rank's shard
+ * (Sl rows, `in_stride` elements apart, `width` = heads*head_dim columns) is split into G head groups of W = width/G columns; group
+ * g goes to every rank rp = g + G*u' (u' < U) of the 2-D Ulysses grid (fastvideo_amd/distributed.py) as the message row
+ *     send[((rp*Sl + m)*3 + slot)*W .. +W],  slot 0 = K, 1 = V, 2 = Q
+ * i.e. send is [G*U ranks, Sl, 3, W] bf16: equal-size per-peer blocks for ONE all_to_all_single, and the received buffer
+ * [ranks*Sl, 3, heads/G, head_dim] is a fused-QKV-shaped tensor the attention kernels read in place through strides.
+ * replaces: torch.cat([q,k,v]) + all_to_all_4D's transpose().contiguous() pack
+ *   (ref: fastvideo/attention/layer.py:117-124, fastvideo/distributed/device_communicators/base_device_communicator.py:147-165). */
+int fvk_qkv_norm_rope_pack_bf16(const void* q, const void* k, const void* v, const void* wq, const void* wk, const float* cos,
+                                const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset,
+                                long in_stride, int G, int U, float eps, void* stream);
+
 /* V[b, s, h, :] at v + b*in_batch_stride + s*in_stride + h*in_head_stride (elements) -> Vt [B, H, D, S_pad] bf16,
  * S_pad = a multiple of 64 >= S (the host wrapper uses round_up(S, 128): whole tiles of the 128-key-tile kernel), pad columns zero.  Within every aligned group of 16 keys the key order is
  * permuted by swapping bits 2 and 3 of the in-group index (the MFMA-B-operand order of fvk_attn_*; see

@@ -280,3 +280,29 @@ def test_hip_linear_methods_match_eager_linear():
             assert out.shape == (2, 130, 768) and (err <= 1e-2 + 1e-2 * ref.abs()).all(), err.max().item()
     cfg = L.Mi355xFp8Config("channel")
     assert cfg.get_name() == "MI355X_FP8" and L.Mi355xBf16Config().get_name() == "MI355X_BF16"
+
+
+# ------------------------------------------------------------------ sequence-parallel exchange packing (fvk_qkv_norm_rope_pack_bf16)
+@pytest.mark.parametrize("H,G,U", [(12, 4, 2), (12, 4, 1), (12, 2, 1), (40, 8, 1), (2, 2, 2)])
+def test_qkv_norm_rope_pack_equals_norm_rope_then_torch_pack(H, G, U):
+    """The fused kernel = ``rmsnorm_rope`` on q, k (+ v untouched) followed by the layout ``SequenceParallel.pack_rows`` builds with
+    plain torch — bit for bit (same arithmetic, only the store addresses differ), from strided column blocks of a fused QKV buffer,
+    with a shard position offset (RoPE uses GLOBAL token positions)."""
+    from fastvideo_amd import ops
+    from fastvideo_amd.distributed import SequenceParallel, SPLayout
+    D, Sl, S, pos0 = 128, 37, 150, 74
+    d = H * D
+    qkv = rnd((Sl, 3 * d), 1, 1.5).to(DEV)
+    wq, wk = (1 + 0.1 * torch.randn(d, generator=g(2))).bfloat16().to(DEV), (1 + 0.1 * torch.randn(d, generator=g(3))).bfloat16().to(DEV)
+    cos, sin = W.rope_tables((5, 5, 6), D)
+    cos, sin = cos.to(DEV), sin.to(DEV)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    send = ops.qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, G, U, head_dim=D, seq_len=S, eps=1e-6, pos_offset=pos0)
+    qn, kn = ops.rmsnorm_rope([q, k], [wq, wk], cos, sin, head_dim=D, seq_len=S, eps=1e-6, pos_offset=pos0)
+    sp = SequenceParallel(H)
+    sp.lay = SPLayout(P=G * U, rank=0, H=H, G=G, U=U)
+    want = sp.pack_rows(qn.view(Sl, H, D), kn.view(Sl, H, D), v.reshape(Sl, H, D))
+    assert send.shape == want.shape == (G * U, Sl, 3, d // G)
+    assert torch.equal(send, want)
+    with pytest.raises(RuntimeError):
+        ops.qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, 5, 1, head_dim=D, seq_len=S)  # 12 / 40 / 2 heads do not split 5 ways

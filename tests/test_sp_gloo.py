@@ -76,6 +76,54 @@ def test_sp_attention_equals_single_process(world, H, S, overlap):
     torch.testing.assert_close(full, ref, atol=1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("H,S", [(12, 50), (40, 67)])
+def test_sp_attention_world8(H, S):
+    """The node-sized grids: Wan2.1-1.3B's 12 heads on 8 ranks (G = 4 head groups x U = 2 query blocks — the case the reference refuses,
+    wanvideo.py:606-607) and Wan2.2-A14B's 40 heads (G = 8, U = 1, plain Ulysses), ragged S (zero padded to a multiple of 8)."""
+    world, D = 8, 8
+    g = torch.Generator().manual_seed(800 + H)
+    q, k, v = (torch.randn((S, H, D), generator=g) for _ in range(3))
+    ref = _attn_fn(q, k, v, S)
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, S, D, q, k, v, out_q, False)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, roundtrip_ok, (G, U) = out_q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert (G, U) == ((4, 2) if H == 12 else (8, 1))
+    assert roundtrip_ok
+    torch.testing.assert_close(full, ref, atol=1e-5, rtol=1e-5)
+
+
+def test_pack_rows_layout_is_the_documented_one():
+    """``pack_rows`` (the torch restatement of what fvk_qkv_norm_rope_pack_bf16 writes) against the layout formula of include/fvk_amd.h:
+    send[rp, m, slot, :] = head group (rp % G) of token m, slot 0 = K, 1 = V, 2 = Q — for a fake 8-rank layout, no process group."""
+    from fastvideo_amd.distributed import SequenceParallel, SPLayout
+    sp = SequenceParallel(12)
+    sp.lay = SPLayout(P=8, rank=5, H=12, G=4, U=2)
+    Sl, H, D = 7, 12, 8
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn((Sl, H, D), generator=g) for _ in range(3))
+    send = sp.pack_rows(q, k, v)
+    W = (H // 4) * D
+    assert send.shape == (8, Sl, 3, W)
+    for rp in range(8):
+        grp = rp % 4
+        for slot, t in enumerate((k, v, q)):
+            assert torch.equal(send[rp, :, slot], t.reshape(Sl, H * D)[:, grp * W:(grp + 1) * W])
+    # receive side: a buffer [P*Sl, 3, W] whose source blocks are in rank order -> this rank (g = 1, u = 1) reads queries of sources 4..7
+    recv = torch.arange(8 * Sl * 3 * W, dtype=torch.float32).view(8 * Sl, 3, W)
+    q_blk, k_all, v_all = sp.views_of(recv, D)
+    assert q_blk.shape == (4 * Sl, H // 4, D) and k_all.shape == (8 * Sl, H // 4, D)
+    assert torch.equal(q_blk.reshape(4 * Sl, W), recv[4 * Sl:8 * Sl, 2]) and torch.equal(k_all.reshape(-1, W), recv[:, 0])
+    assert torch.equal(v_all.reshape(-1, W), recv[:, 1])
+    assert q_blk.data_ptr() == recv[4 * Sl, 2].data_ptr() and k_all.stride(0) == 3 * W  # views: nothing is copied
+
+
 def test_layout_choice():
     import math
     for H, P, G, U in [(12, 1, 1, 1), (12, 2, 2, 1), (12, 4, 4, 1), (12, 8, 4, 2), (40, 8, 8, 1), (12, 6, 6, 1), (12, 16, 4, 4)]:
