@@ -342,6 +342,8 @@ def main():
         y = model(latent, ctx, ts)
     sync()
     model.attn_events = []
+    if world > 1:
+        model.sp.stats = {}  # per-exchange bytes + HIP-event pairs on the compute stream (fastvideo_amd/distributed.py)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         y = model(latent, ctx, ts)
@@ -399,6 +401,21 @@ def main():
         "step_frac_of_bf16_peak": round(fl["total"] / (ms_per_step * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "roofline": roof,
     }
+    if world > 1:
+        # sequence-parallel exchange accounting of THIS rank (rank 0): bytes sent to other ranks and the time the compute stream spent
+        # in each collective (HIP events bracketing it on that stream), i.e. the achieved per-GPU egress rate over xGMI
+        st, model.sp.stats = model.sp.stats or {}, None
+        ex = {}
+        for kind, rec in st.items():
+            ms = [a.elapsed_time(b) for a, b in rec["events"]]
+            tot_ms = sum(ms)
+            ex[kind] = dict(calls_per_step=rec["calls"] / args.steps, remote_mb_per_call=round(rec["remote_bytes"] / max(rec["calls"], 1) / 1e6, 3),
+                            mean_ms=round(tot_ms / max(len(ms), 1), 4) if ms else None,
+                            egress_gb_s=round(rec["remote_bytes"] / (tot_ms * 1e-3) / 1e9, 1) if tot_ms > 0 else None,
+                            ms_per_step=round(tot_ms / args.steps, 3) if ms else None)
+        out["exchange"] = dict(backend=dist.get_backend(), rccl_ranks=(world if dist.get_backend() == "nccl" else 0), per_kind=ex,
+                               note="rank 0's view; egress = bytes to the other ranks / time the compute stream waited in the collective; "
+                                    "xGMI: 7 links x ~153 GB/s per GPU (point-to-point mesh)")
     if args.layers:
         out["INVALID"] = "debug run with fewer layers"
     if shared:

@@ -305,4 +305,4 @@ def test_qkv_norm_rope_pack_equals_norm_rope_then_torch_pack(H, G, U):
     assert send.shape == want.shape == (G * U, Sl, 3, d // G)
     assert torch.equal(send, want)
     with pytest.raises(RuntimeError):
-        ops.qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, 5, 1, head_dim=D, seq_len=S)  # 12 / 40 / 2 heads do not split 5 ways
+        ops.qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, 7, 1, head_dim=D, seq_len=S)  # 12 / 40 / 2 heads do not split 7 ways
