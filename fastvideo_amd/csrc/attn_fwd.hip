@@ -86,6 +86,8 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
     const int h = (blockIdx.x / nwg) % a.H;
     const int b = blockIdx.x / (nwg * a.H);
     unsigned char* const smem_p = smem + pr * (2 * STAGE_BYTES);     // this pair's double-buffered stage
+    constexpr int LIST_CAP = MODE == MODE_BLOCKS ? 2048 : 0;         // KV-list entries kept in LDS per query block (8 KiB)
+    int32_t* const lds_lists = reinterpret_cast<int32_t*>(smem + PAIRS * 2 * STAGE_BYTES);
 
     const bf16_t* qp = (const bf16_t*)a.q + (long)b * a.q_bs + (long)h * a.q_hs;
     const bf16_t* kp = (const bf16_t*)a.k + (long)b * a.k_bs + (long)h * a.k_hs;
@@ -102,6 +104,24 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
         const long meta = ((long)b * a.H + h) * nqb + (pair_ok ? qb : 0);
         n_tiles = pair_ok ? ma.q2k_num[meta] : 0;
         blk_list = ma.q2k_idx + meta * ma.max_kv;
+        // The KV lists live in LDS for the whole kernel: entry = block id | (valid keys << 24).  Read from global memory inside the
+        // tile loop, `id = blk_list[j+1]` is a vector load every wave must WAIT for (vmcnt(0): a full L2 round trip, 500+ cycles under
+        // load) before the tile's DMA can even be issued — every iteration, on compute and loader waves alike; `kv_block_sizes[id]` is
+        // a second, dependent round trip.  One cooperative fill here, then a ~100-cycle uniform ds_read per tile.
+        for (int p = 0; p < PAIRS; ++p) {
+            const int qb_p = (blockIdx.x % nwg) * PAIRS + p;
+            if (qb_p < nqb) {
+                const long meta_p = ((long)b * a.H + h) * nqb + qb_p;
+                int n_p = ma.q2k_num[meta_p];
+                n_p = n_p < LIST_CAP ? n_p : LIST_CAP;
+                const int32_t* src = ma.q2k_idx + meta_p * ma.max_kv;
+                for (int i = tid; i < n_p; i += PAIRS * (NW + NL) * 64) {
+                    const int id = src[i];
+                    lds_lists[p * LIST_CAP + i] = id | (ma.kv_block_sizes[id] << 24);
+                }
+            }
+        }
+        __syncthreads();  // the first get_tile() below reads entries other threads wrote
     } else {
         const int qt = (qb * BMQ) / ma.tile_tokens;
         const int qt_t = qt / (ma.ch * ma.cw), qt_h = (qt / ma.cw) % ma.ch, qt_w = qt % ma.cw;
@@ -131,9 +151,15 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
             const int rem = a.Skv - kv0;
             valid = rem < 64 ? rem : 64;
         } else if (MODE == MODE_BLOCKS) {
-            const int id = blk_list[j];
-            kv0 = id << 6;
-            valid = ma.kv_block_sizes[id];
+            if (j < LIST_CAP) {
+                const int e = lds_lists[pr * LIST_CAP + j];
+                kv0 = (e & 0xffffff) << 6;
+                valid = e >> 24;
+            } else {  // lists longer than the LDS copy (not reached by any Wan geometry: 2 160 blocks at 129f x 720p)
+                const int id = blk_list[j];
+                kv0 = id << 6;
+                valid = ma.kv_block_sizes[id];
+            }
         } else {
             const int sub = j % sta_sub;
             int wi = j / sta_sub;
@@ -380,7 +406,8 @@ int check_common(const fvk_attn_args* a, const char* fn) {
 template <int NW, int MODE, int DK = 128, int NL = 0, int PAIRS = 1>
 int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
     constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES;
-    constexpr int LDS = PAIRS * 2 * STAGE_BYTES;
+    constexpr int LDS = PAIRS * 2 * STAGE_BYTES + (MODE == MODE_BLOCKS ? PAIRS * 2048 * 4 : 0);  // + the KV lists (LIST_CAP entries each)
+    static_assert(LDS <= 163840, "LDS budget");
     static bool configured[FVK_MAX_DEVICES] = {};
     if (fvk_needs_lds_config(configured)) {
         if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE, DK, NL, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
