@@ -38,12 +38,19 @@ q, k, v = (torch.randn((1, S_pad, H, D), generator=g, device=dev).bfloat16() for
 scores = torch.randn((1, H, n, n), generator=g, device=dev)
 mask = ops.topk_mask(scores, 125)
 idx, num = ops.map_to_index(mask)
-vt = None
-ms = timeit(lambda: ops.attn_block_sparse(q, k, v, idx, num, vbs, layout="bshd"))
+IMPLS = [int(x) for x in os.environ.get("IMPLS", "0").split(",")]
 ms_vt = timeit(lambda: ops.v_transpose(v))
 pairs = float((vbs.float()[None, None, :, None] * (mask.float() * vbs.float()[None, None, None, :])).sum())
-out["vsa"] = dict(ms=round(ms, 4), ms_kernel_only=round(ms - ms_vt, 4), tflops_kernel=round(4 * pairs * D / ((ms - ms_vt) * 1e-3) / 1e12, 1),
-                  v_transpose_ms=round(ms_vt, 4))
+ref_o = None
+for impl in IMPLS:
+    ops.set_tunable("attn_impl", impl)
+    o = ops.attn_block_sparse(q, k, v, idx, num, vbs, layout="bshd")
+    ref_o = o if ref_o is None else ref_o
+    ms = timeit(lambda: ops.attn_block_sparse(q, k, v, idx, num, vbs, layout="bshd"))
+    out[f"vsa_impl{impl}"] = dict(ms=round(ms, 4), ms_kernel_only=round(ms - ms_vt, 4), tflops_real_pairs=round(4 * pairs * D / ((ms - ms_vt) * 1e-3) / 1e12, 1),
+                                  tflops_padded_blocks=round(4.0 * S_pad * 125 * 64 * H * D / ((ms - ms_vt) * 1e-3) / 1e12, 1),
+                                  equal_to_first=bool(torch.equal(o, ref_o)))
+ops.set_tunable("attn_impl", 0)
 # ---- STA lists
 h = kernel_api.sliding_tile_block_lists((21, 30, 52), (6, 8, 8), (3, 3, 3))
 S2 = h["S_pad"]
@@ -51,8 +58,15 @@ q2, k2, v2 = (torch.randn((1, S2, H, D), generator=g, device=dev).bfloat16() for
 idx2 = h["q2k_idx"].to(dev)[None, None].expand(1, H, -1, -1).contiguous()
 num2 = h["q2k_num"].to(dev)[None, None].expand(1, H, -1).contiguous()
 bs2 = h["block_sizes"].to(dev)
-ms2 = timeit(lambda: ops.attn_block_sparse(q2, k2, v2, idx2, num2, bs2, layout="bshd", q_block=h["q_block"]))
 ms2_vt = timeit(lambda: ops.v_transpose(v2))
 fl2 = 4.0 * (21 * 30 * 52)**2 * h["density"] * H * D
-out["sta_lists"] = dict(ms=round(ms2, 4), ms_kernel_only=round(ms2 - ms2_vt, 4), tflops_algorithmic=round(fl2 / ((ms2 - ms2_vt) * 1e-3) / 1e12, 1))
+ref_o = None
+for impl in IMPLS:
+    ops.set_tunable("attn_impl", impl)
+    o = ops.attn_block_sparse(q2, k2, v2, idx2, num2, bs2, layout="bshd", q_block=h["q_block"])
+    ref_o = o if ref_o is None else ref_o
+    ms2 = timeit(lambda: ops.attn_block_sparse(q2, k2, v2, idx2, num2, bs2, layout="bshd", q_block=h["q_block"]))
+    out[f"sta_lists_impl{impl}"] = dict(ms=round(ms2, 4), ms_kernel_only=round(ms2 - ms2_vt, 4),
+                                        tflops_algorithmic=round(fl2 / ((ms2 - ms2_vt) * 1e-3) / 1e12, 1), equal_to_first=bool(torch.equal(o, ref_o)))
+ops.set_tunable("attn_impl", 0)
 print(json.dumps(out))
