@@ -150,8 +150,8 @@ def attention_traffic_from_profiles():
         except Exception:  # noqa: BLE001
             continue
         if j.get("kernel_source_sha256") == cur and j.get("traffic_bytes_per_launch"):
-            best = (j["traffic_bytes_per_launch"], os.path.basename(f))
-    return best if best else (None, "no PMC pass for the current attn_pp2.hip (run scripts/pmc_traffic.sh)")
+            best = (j["traffic_bytes_per_launch"], os.path.basename(f), j.get("GRBM_GUI_ACTIVE_sum"))
+    return best if best else (None, "no PMC pass for the current attn_pp2.hip (run scripts/pmc_traffic.sh)", None)
 
 
 def vae_cpu_baseline(latent_shape, budget_frames=2):
@@ -377,13 +377,19 @@ def main():
         flops_launch = 4.0 * Sq * Skv * h * cfg.head_dim * dens
         kname = f"{args.attention} self-attention (gather + attn_fwd_kernel block-sparse + untile), density {dens:.3f} of dense"
     achieved = flops_launch / (mean_ms * 1e-3) / 1e12
-    traffic, traffic_src = None, None
+    traffic, traffic_src, gui_cycles = None, None, None
     if args.attention == "dense" and args.config == "cfg2" and world == 1:
-        traffic, traffic_src = attention_traffic_from_profiles()
+        traffic, traffic_src, gui_cycles = attention_traffic_from_profiles()
     roof = dict(bound="mfma", kernel=kname, achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS,
                 unit="TFLOP/s", frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                 flops_per_launch=flops_launch, mean_launch_ms=round(mean_ms, 4), launches=len(attn_ms),
                 share_of_step=round(sum(attn_ms) / args.steps / (elapsed / args.steps * 1e3), 3))
+    if gui_cycles:
+        # DVFS separated from stalls: GRBM_GUI_ACTIVE (busy shader cycles, summed over the 8 XCDs by rocprofv3; same binary, same shape, so
+        # the cycle count per launch carries over) / the LIVE launch duration = the clock this run sustained; the MFMA peak scales with it
+        clk = gui_cycles / 8 / (mean_ms * 1e-3) / 1e9
+        roof.update(effective_clock_ghz=round(clk, 3), peak_at_effective_clock=round(PEAK_BF16_TFLOPS * clk / 2.4, 1),
+                    frac_of_clock_limited_peak=round(achieved / (PEAK_BF16_TFLOPS * clk / 2.4), 4))
     fl = WC.algorithmic_flops(cfg, S, L_text)
     ms_per_step = elapsed / args.steps * 1e3
     lay = model.sp.lay
