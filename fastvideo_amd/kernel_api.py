@@ -95,8 +95,8 @@ def video_sparse_attn(q, k, v, variable_block_sizes, q_variable_block_sizes, top
     if v.shape[2] != kv_seq_len:
         raise ValueError(f"Expected k and v to have the same sequence length, got k.shape[2]={kv_seq_len}, "
                          f"v.shape[2]={v.shape[2]}")
-    if block_elements != 64:
-        raise ValueError(f"fastvideo_amd implements the 64-token VSA block only (got block_elements={block_elements})")
+    if block_elements not in (64, 128, 256):
+        raise ValueError(f"video_sparse_attn: block_elements must be 64, 128 or 256 (got {block_elements})")
     if q_seq_len % block_elements != 0 or kv_seq_len % block_elements != 0:
         raise ValueError(f"q_seq_len and kv_seq_len must be divisible by block_elements={block_elements}, "
                          f"got q_seq_len={q_seq_len}, kv_seq_len={kv_seq_len}")
@@ -109,13 +109,28 @@ def video_sparse_attn(q, k, v, variable_block_sizes, q_variable_block_sizes, top
     vbs = variable_block_sizes.to(device=q.device, dtype=torch.int32)
     qvbs = q_variable_block_sizes.to(device=q.device, dtype=torch.int32)
 
-    return _vsa_forward(q, k, v, vbs, qvbs, topk, compress_attn_weight, "bhsd", return_intermediates)
+    return _vsa_forward(q, k, v, vbs, qvbs, topk, compress_attn_weight, "bhsd", return_intermediates, block_elements)
 
 
-def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=False):
+def _expand_block_lists(idx, num, vbs, block_elements):
+    """KV lists over blocks of 128 / 256 tokens -> lists over the kernel's 64-key blocks: block b is sub-blocks b*sub + t with sizes
+    clamp(vbs[b] - 64 t, 0, 64) (a block's real tokens come first, video_sparse_attn.py:170-189); a query block of 256 rows is two
+    128-row lists sharing one KV list.  Pure integer index arithmetic on [B, H, Nq, max_kv]-sized tensors."""
+    sub = block_elements // 64
+    t = torch.arange(sub, device=idx.device, dtype=idx.dtype)
+    idx_s = (idx.unsqueeze(-1) * sub + t).flatten(-2)
+    num_s = num * sub
+    sizes = (vbs.to(torch.int32)[:, None] - 64 * t.to(torch.int32)[None, :]).clamp_(0, 64).flatten()
+    rep = block_elements // 128
+    if rep > 1:
+        idx_s, num_s = idx_s.repeat_interleave(rep, dim=2), num_s.repeat_interleave(rep, dim=2)
+    return idx_s.contiguous(), num_s.contiguous(), sizes.contiguous()
+
+
+def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=False, block_elements=64):
     """The VSA composition (fastvideo_kernel/ops.py:108-128) on tensors of either layout: "bhsd" (the package API) or "bshd" (what the model
-    host holds — strides go to the kernels, nothing is transposed or copied)."""
-    block_elements = 64
+    host holds — strides go to the kernels, nothing is transposed or copied).  ``block_elements`` 64 (Wan: tile (4,4,4)) runs the 64-row
+    list kernel; 128 / 256 (the reference's Blackwell CuTe paths, ops.py:125-128) run the 128-row list kernel over expanded lists."""
     if layout == "bhsd":
         batch, heads, q_seq_len, dim = q.shape
         kv_seq_len = k.shape[2]
@@ -133,7 +148,11 @@ def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=Fa
     # sparse branch (ops.py:120-128): exact top-k mask -> ascending index lists -> block-sparse attention
     mask = ops.topk_mask(scores, min(int(topk), kv_num_blocks))
     idx, num = ops.map_to_index(mask)
-    out_s = ops.attn_block_sparse(q, k, v, idx, num, vbs, layout=layout)
+    if block_elements == 64:
+        out_s = ops.attn_block_sparse(q, k, v, idx, num, vbs, layout=layout)
+    else:
+        idx_s, num_s, sizes = _expand_block_lists(idx, num, vbs, block_elements)
+        out_s = ops.attn_block_sparse(q, k, v, idx_s, num_s, sizes, layout=layout, q_block=128)
     out = ops.vsa_combine(out_c, out_s, gate, block_elements, layout=layout)
     if return_intermediates:
         return out, dict(q_c=q_c, k_c=k_c, v_c=v_c, scores=scores, mask=mask, q2k_idx=idx, q2k_num=num, out_c=out_c,
@@ -142,20 +161,28 @@ def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=Fa
 
 
 def video_sparse_attn_bshd(q, k, v, variable_block_sizes, q_variable_block_sizes, topk, block_size=64, compress_attn_weight=None):
-    """ref: fastvideo_kernel ``video_sparse_attn_bshd`` (fastvideo-kernel/python/fastvideo_kernel/__init__.py:40-62): q,k,v(,gate)
-    [B,S_pad,H,D] bf16, tile-major, zero padded.  64-token blocks (the reference's bshd entry serves 128 / 256 only on its hardware)."""
+    """ref: fastvideo_kernel ``video_sparse_attn_bshd`` (fastvideo-kernel/python/fastvideo_kernel/ops.py:136-200): q,k,v(,gate)
+    [B,S_pad,H,D] bf16, tile-major, zero padded; 128- / 256-token blocks as in the reference, and — an extension the model host uses —
+    the 64-token block too (the reference's bshd entry refuses 64 only because its 64-block kernels want [B,H,S,D])."""
     if isinstance(block_size, (tuple, list)):
         block_size = block_size[0] * block_size[1] * block_size[2]
-    if block_size != 64:
-        raise ValueError(f"fastvideo_amd implements the 64-token VSA block only (got block_elements={block_size})")
-    if q.shape[1] % 64 or k.shape[1] % 64 or v.shape[1] != k.shape[1]:
-        raise ValueError("q_seq_len and kv_seq_len must be divisible by block_elements=64 and k, v must agree")
+    if block_size not in (64, 128, 256):
+        raise ValueError(f"video_sparse_attn_bshd: block_elements must be 64, 128 or 256 (got {block_size})")
+    if k.shape[0] != q.shape[0] or v.shape[0] != q.shape[0] or k.shape[2] != q.shape[2] or v.shape[2] != q.shape[2]:
+        raise ValueError("Expected q/k/v to have the same batch and head dimensions.")
+    if v.shape[1] != k.shape[1]:
+        raise ValueError(f"Expected k and v to have the same sequence length, got k.shape[1]={k.shape[1]}, v.shape[1]={v.shape[1]}")
+    if q.shape[1] % block_size or k.shape[1] % block_size:
+        raise ValueError(f"q_seq_len and kv_seq_len must be divisible by block_elements={block_size}, "
+                         f"got q_seq_len={q.shape[1]}, kv_seq_len={k.shape[1]}")
     _check_bf16(q, k, v)
     vbs = variable_block_sizes.to(device=q.device, dtype=torch.int32)
     qvbs = q_variable_block_sizes.to(device=q.device, dtype=torch.int32)
-    if vbs.numel() != k.shape[1] // 64 or qvbs.numel() != q.shape[1] // 64:
-        raise ValueError("variable block size lists do not match the block counts")
-    return _vsa_forward(q, k, v, vbs, qvbs, topk, compress_attn_weight, "bshd")
+    if vbs.numel() != k.shape[1] // block_size:
+        raise ValueError(f"variable_block_sizes must have length kv_num_blocks={k.shape[1] // block_size}, got {vbs.numel()}")
+    if qvbs.numel() != q.shape[1] // block_size:
+        raise ValueError(f"q_variable_block_sizes must have length q_num_blocks={q.shape[1] // block_size}, got {qvbs.numel()}")
+    return _vsa_forward(q, k, v, vbs, qvbs, topk, compress_attn_weight, "bshd", False, block_size)
 
 
 _STA_CANVAS = {"30x48x80": (30, 48, 80), "36x48x48": (36, 48, 48), "18x48x80": (18, 48, 80)}

@@ -306,3 +306,32 @@ def test_qkv_norm_rope_pack_equals_norm_rope_then_torch_pack(H, G, U):
     assert torch.equal(send, want)
     with pytest.raises(RuntimeError):
         ops.qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, 7, 1, head_dim=D, seq_len=S)  # 12 / 40 / 2 heads do not split 7 ways
+
+
+@pytest.mark.parametrize("block", [(4, 4, 8), (4, 8, 8)])
+def test_video_sparse_attn_128_and_256_token_blocks(block):
+    """``video_sparse_attn`` / ``video_sparse_attn_bshd`` with 128- and 256-token blocks (fastvideo_kernel/ops.py:78-81, 125-128, 136-200:
+    the reference's Blackwell CuTe paths) — the 128-row list kernel over lists expanded to 64-key sub-blocks — vs the oracle composite
+    with the device's block selection (unconditional, as for the 64-token block)."""
+    from fastvideo_amd import kernel_api as KA
+    be = math.prod(block)
+    B, H, D, nb = 1, 2, 128, 9
+    vbs = np.array([be, be, be - 37, be, 1, be // 2 + 3, be, 70, be], dtype=np.int32)
+    S = nb * be
+    q, k, v, gate = (rnd((B, H, S, D), s_) for s_ in (11, 12, 13, 14))
+    for t in (q, k, v, gate):
+        for b in range(nb):
+            t[:, :, b * be + int(vbs[b]):(b + 1) * be] = 0  # a block's real tokens first, zero padding after
+    topk = 4
+    tv = torch.from_numpy(vbs).to(DEV)
+    out, inter = KA.video_sparse_attn(q.to(DEV), k.to(DEV), v.to(DEV), tv, tv, topk, block, gate.to(DEV), return_intermediates=True)
+    mask = inter["mask"].cpu().numpy()
+    assert np.array_equal(mask, V.topk_mask_bisect(inter["scores"].float().cpu().numpy(), topk)) and (mask.sum(-1) == topk).all()
+    ref, _ = V.video_sparse_attn(q, k, v, vbs, vbs, topk, be, gate, mask_override=mask)
+    rows = torch.cat([torch.arange(b * be, b * be + int(vbs[b])) for b in range(nb)])  # pad query rows are dropped by untile
+    _attn_check(out[:, :, rows], ref.float()[:, :, rows], f"vsa composite, {be}-token blocks", mean_tol=3e-3)
+    o2 = KA.video_sparse_attn_bshd(q.transpose(1, 2).contiguous().to(DEV), k.transpose(1, 2).contiguous().to(DEV),
+                                   v.transpose(1, 2).contiguous().to(DEV), tv, tv, topk, block, gate.transpose(1, 2).contiguous().to(DEV))
+    assert torch.equal(o2.transpose(1, 2), out)
+    with pytest.raises(ValueError):
+        KA.video_sparse_attn(q.to(DEV), k.to(DEV), v.to(DEV), tv, tv, topk, (4, 4, 2), gate.to(DEV))  # 32-token blocks do not exist
