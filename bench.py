@@ -391,6 +391,11 @@ def main():
         roof.update(effective_clock_ghz=round(clk, 3), peak_at_effective_clock=round(PEAK_BF16_TFLOPS * clk / 2.4, 1),
                     frac_of_clock_limited_peak=round(achieved / (PEAK_BF16_TFLOPS * clk / 2.4), 4))
     fl = WC.algorithmic_flops(cfg, S, L_text)
+    if args.attention != "dense":
+        # sparse modes: the algorithmic work of self-attention is the SELECTED share of the score matrix, not the dense count
+        fl = dict(fl)
+        fl["total"] = fl["total"] - fl["self_attn"] * (1.0 - dens)
+        fl["self_attn"] = fl["self_attn"] * dens
     ms_per_step = elapsed / args.steps * 1e3
     lay = model.sp.lay
     par = "sp1" if world == 1 else (f"sp{world} 2-D Ulysses (head groups {lay.G} x query blocks {lay.U}), "
