@@ -27,10 +27,13 @@ def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):
     return (torch.randn(shape, generator=g(seed)) * scale).to(dtype)
 
 
-def _attn_check(out, ref, what, mean_tol=2e-3):
+def _attn_check(out, ref, what, mean_tol=None):
+    """max |err| < 4e-2 (test_sta.py:88-91); mean |err| < 3e-3 x mean |ref| + 2e-5 — 1.4x the bf16 rounding of the output, which is what
+    the kernels measure (2.1e-3 x mean |ref|); ``mean_tol`` widens the relative factor for composites with two bf16 outputs summed."""
     err = (out.float().cpu() - ref.float()).abs()
     assert torch.isfinite(out.float()).all(), f"{what}: non-finite output"
-    assert err.max().item() < 4e-2 and err.mean().item() < mean_tol, f"{what}: max {err.max().item():.4g} mean {err.mean().item():.4g}"
+    bound = (mean_tol or 3e-3) * ref.float().abs().mean().item() + 2e-5
+    assert err.max().item() < 4e-2 and err.mean().item() < bound, f"{what}: max {err.max().item():.4g} mean {err.mean().item():.4g} (bound {bound:.4g})"
 
 
 def _same_rounding(got, ref, what):
@@ -108,7 +111,7 @@ def test_vsa_impl_tile_forward_untile_matches_oracle():
     t = lambda z: V.tile(z, om).transpose(1, 2).contiguous()
     ref_t, _ = V.video_sparse_attn(t(q), t(k), t(v), vbs, vbs, topk, 64, t(gate), mask_override=mask)
     ref = V.untile(ref_t.transpose(1, 2), om)
-    _attn_check(out, ref, "vsa impl composite (GPU mask)", mean_tol=3e-3)
+    _attn_check(out, ref, "vsa impl composite (GPU mask)", mean_tol=5e-3)
     # the reference-layout entry of the kernel package gives the same numbers as the strided one
     o_bhsd = KA.video_sparse_attn(tq.transpose(1, 2).contiguous(), tk.transpose(1, 2).contiguous(), tv.transpose(1, 2).contiguous(),
                                   md.variable_block_sizes, md.variable_block_sizes, topk, (4, 4, 4), tg.transpose(1, 2).contiguous())
@@ -329,7 +332,7 @@ def test_video_sparse_attn_128_and_256_token_blocks(block):
     assert np.array_equal(mask, V.topk_mask_bisect(inter["scores"].float().cpu().numpy(), topk)) and (mask.sum(-1) == topk).all()
     ref, _ = V.video_sparse_attn(q, k, v, vbs, vbs, topk, be, gate, mask_override=mask)
     rows = torch.cat([torch.arange(b * be, b * be + int(vbs[b])) for b in range(nb)])  # pad query rows are dropped by untile
-    _attn_check(out[:, :, rows], ref.float()[:, :, rows], f"vsa composite, {be}-token blocks", mean_tol=3e-3)
+    _attn_check(out[:, :, rows], ref.float()[:, :, rows], f"vsa composite, {be}-token blocks", mean_tol=5e-3)
     o2 = KA.video_sparse_attn_bshd(q.transpose(1, 2).contiguous().to(DEV), k.transpose(1, 2).contiguous().to(DEV),
                                    v.transpose(1, 2).contiguous().to(DEV), tv, tv, topk, block, gate.transpose(1, 2).contiguous().to(DEV))
     assert torch.equal(o2.transpose(1, 2), out)

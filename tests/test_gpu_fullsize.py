@@ -20,6 +20,15 @@ def ops():
     return o
 
 
+def _bounded(err, ref, what):
+    """max |err| < 4e-2 (fastvideo-kernel/tests/test_sta.py:88-91) and a RELATIVE mean bound: with tens of thousands of keys per row the
+    outputs are O(1e-2), so an absolute 3e-3 would pass garbage.  Two bf16 roundings (P, then the output) at 2^-9 mean relative error each
+    give ~3e-3 x mean |ref|; the bound is twice that plus a floor."""
+    mean_ref = ref.abs().mean().item()
+    print(f"{what}: max|err|={err.max().item():.4g} mean|err|={err.mean().item():.4g} mean|ref|={mean_ref:.4g}")
+    assert err.max().item() < 4e-2 and err.mean().item() < 6e-3 * mean_ref + 2e-5, (err.mean().item(), err.max().item(), mean_ref)
+
+
 def _rows(n, seed=0):
     return torch.randperm(S, generator=torch.Generator().manual_seed(seed))[:n].sort().values.cuda()
 
@@ -38,8 +47,9 @@ def test_dense_attention_full_size(ops):
     q, k, v = (torch.randn((1, S, H, D), generator=g, device="cuda").bfloat16() for _ in range(3))
     o = ops.attn_dense(q, k, v)
     rows = _rows(256)
-    err = (o[0, rows].float() - _attn_ref_rows(q, k, v, rows)).abs()
-    assert err.mean().item() < 3e-3 and err.max().item() < 4e-2, (err.mean().item(), err.max().item())
+    ref = _attn_ref_rows(q, k, v, rows)
+    err = (o[0, rows].float() - ref).abs()
+    _bounded(err, ref, "dense attention, S = 32 760")
     # rows of P sum to one
     ones = torch.ones_like(v)
     o1 = ops.attn_dense(q, k, ones)
@@ -72,7 +82,7 @@ def test_sliding_tile_attention_full_grid(ops):
         mask &= (tcoord[None, :, ax] >= lo[:, None]) & (tcoord[None, :, ax] < hi[:, None])
     ref = _attn_ref_rows(q[None], k[None], v[None], rows, mask.cuda())
     err = (o[rows].float() - ref).abs()
-    assert err.mean().item() < 3e-3 and err.max().item() < 4e-2, (err.mean().item(), err.max().item())
+    _bounded(err, ref, "sliding-tile attention, grid 21x30x52")
     assert 0.15 < mask.float().mean().item() < 0.45   # the window really is sparse
 
 

@@ -172,9 +172,15 @@ def test_gemm_epilogues(ops):
 
 # ------------------------------------------------------------------ attention
 def _attn_check(out, ref, what):
+    """max |err| < 4e-2: the reference's own kernel-test bound (fastvideo-kernel/tests/test_sta.py:88-91).  Mean: the kernel's only bf16
+    roundings are P and the output, and the measured mean |err| is 2.1e-3 x mean |ref| on every case (= the rounding of a bf16 output:
+    half an ulp of 2^-8 relative, on average); the bound is 1.4x that plus an absolute floor for near-zero outputs — not the former
+    absolute 2e-3, which was ~15x what the kernel achieves."""
     err = (out.float().cpu() - ref).abs()
     assert torch.isfinite(out.float()).all(), f"{what}: non-finite output"
-    assert err.max().item() < 4e-2 and err.mean().item() < 2e-3, f"{what}: max {err.max().item():.4g} mean {err.mean().item():.4g}"
+    mean_bound = 3e-3 * ref.float().abs().mean().item() + 2e-5
+    assert err.max().item() < 4e-2 and err.mean().item() < mean_bound, \
+        f"{what}: max {err.max().item():.4g} mean {err.mean().item():.4g} (bound {mean_bound:.4g})"
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 48, 48), (1, 2, 105, 105), (2, 3, 300, 77), (1, 1, 1000, 1000), (1, 12, 130, 512)])
