@@ -9,9 +9,9 @@ them runnable on the MI355X as a checker).  The four files are staged byte-for-b
 
 Triton is used ONLY here, as the checker (the product has no Triton anywhere).  Tests skip — with the reason — when the staged
 files are absent or Triton-HIP cannot import / compile on the box; they never fall back to anything.
-Thresholds: the reference's own (fastvideo-kernel/tests/test_sta.py:88-91 avg < 3e-6 is quoted for TK-vs-flex on its own pair
-of kernels; between two independent bf16-P flash kernels we assert max < 4e-2 and report avg, bounded at 2e-5;
-test_fused_compress_topk.py:138 atol = rtol = 1e-2 for the block means; masks and index lists exact)."""
+Thresholds: the reference's own — sliding-tile attention avg < 3e-6 and max < 4e-2 (fastvideo-kernel/tests/test_sta.py:88-91; measured
+1.9e-8 / 3.1e-2 against the reference's Triton kernel), block means atol = rtol = 1e-2 (test_fused_compress_topk.py:138), masks and
+index lists exact; block-sparse attention max < 4e-2 and mean < 1e-3 (measured 9.8e-4 / 1.2e-8)."""
 import importlib.util
 import os
 
@@ -175,5 +175,5 @@ def test_sliding_tile_attention_vs_reference_triton_on_18x48x80():
     err = (o.float() - ref.float()).abs()
     avg, mx = err.mean().item(), err.max().item()
     print(f"STA 18x48x80 vs reference Triton STA: avg_diff={avg:.4g} max_diff={mx:.4g} (reference thresholds: 3e-6 / 4e-2)")
-    assert mx < 4e-2, mx
-    assert avg < 2e-5, avg
+    assert mx < 4e-2, mx    # the reference's own thresholds (test_sta.py:88-91), against the reference's own kernel
+    assert avg < 3e-6, avg  # measured 1.9e-8: the two kernels walk the keys in the same order, their bf16 P roundings coincide
