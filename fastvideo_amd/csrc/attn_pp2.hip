@@ -35,8 +35,26 @@ __device__ __forceinline__ float xhalf_sum(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <bool PROBE, bool PRIO>
+// VSTREAM: the trailing group issues its 8 V^T pieces per tile inside the second half of its matrix segment and only the 8 K pieces at the
+// top of its softmax segment.  s_memtime stamps (profiles/r02_attn_pp2_probe.md): the tile step IS the trailing group's serial chain
+// (matrix 2300 + DMA issue 998 + softmax 1902 + ~990 of barrier / loop cycles; the leading group idles 1187 cycles at its second barrier),
+// and a DMA piece costs its issuing wave ~62 cycles at the top of the softmax segment but only the MFMA-gap overflow inside the stream.
+// ONEBAR: ONE workgroup barrier per 128-key tile step instead of two.  The barrier between a group's matrix segment and its partner's
+// softmax segment (leading after-M / trailing after-S) guards no data: the ring slots a matrix segment reads were waited for one barrier
+// earlier, and they are refilled only after the OTHER barrier (leading after-S / trailing after-M), which every wave still passes.  It only
+// forced the two matrix segments of a SIMD to alternate strictly — each hand-off idling the matrix pipe (s_memtime: the tile step was
+// exactly 2 x (matrix segment + hand-off)).  Without it the trailing wave starts its matrix segment when its own softmax is done.
+// (VSTREAM needs that barrier — the leading group's P·V must have left the V^T slot — so ONEBAR implies all 16 pieces after the barrier.)
+// LDMA (implies ONEBAR): the LEADING group issues every DMA piece and waits for them.  With one barrier per step the tile step is the
+// trailing wave's own serial chain (matrix 2300 + vmcnt/barrier 420 + DMA issue 1020 + softmax 1940 + loop 560 = 6360 cycles by s_memtime)
+// while the leading wave idles ~1480 cycles at the barrier: the DMA work moves to the wave that has the slack.  Set j+1's ring slots are
+// free as soon as the barrier closing step j is passed (both groups' M(j) are behind it), which is exactly where the leading group's next
+// matrix segment starts; the pieces ride in that segment's MFMA gaps (LSTREAM) or precede it, and are waited for before the leading
+// group's next barrier, ~4 000 cycles later, by which time they have long landed (the trailing group used to wait 200-400 cycles there).
+template <bool PROBE, bool PRIO, bool VSTREAM = true, bool ONEBAR = false, bool LDMA = false, bool LSTREAM = false>
 __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
+    static_assert(!(VSTREAM && ONEBAR), "in-stream V^T pieces rely on the second barrier");
+    static_assert(!LDMA || ONEBAR, "leading-group DMA is a one-barrier schedule");
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
@@ -97,6 +115,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
         }                                                                                                            \
     }
 #define ISSUE_SET(T) { _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) ISSUE_PIECE(T, i_) }
+#define ISSUE_K(T) { _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) ISSUE_PIECE(T, i_) }
 
     // ---- fragment read offsets (same swizzle for both tiles): row l31 (+32*block), k-chunk 2*step + hi ------------------------
     int foff[8];
@@ -133,7 +152,11 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
             if (n_ < (LAST)) fr_[(n_ - (FIRST)) % FD] = FRAG(J, n_);                                                 \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
             if (n_ < (LAST)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
-            /* (an in-stream DMA variant for the leading group measured ~160 cycles slower per segment: see DMA == 0 everywhere) */           \
+            /* DMA (trailing group only): the wave's 8 V^T pieces of set J+1 ride in the gaps of the Q·K^T half (one per 4 MFMAs); their   \
+               ring slot held V^T(J-1), which this wave finished reading with MFMA 31 and the leading group a whole barrier interval ago */ \
+            if ((DMA) && VSTREAM && grp == 1 && i >= 32 && ((i - 32) & 3) == 0) ISSUE_PIECE((J) + 1, 8 + ((i - 32) >> 2))          \
+            /* LSTREAM (leading group): all 16 pieces of set J (its slots were freed by the barrier just passed), one per 4 MFMAs */      \
+            if ((DMA) == 2 && LSTREAM && grp == 0 && (i & 3) == 0) ISSUE_PIECE((J), (i >> 2))                                         \
         }                                                                                                            \
     }
     // online softmax of tile J (row q = lane&31; this lane holds 64 of its 128 scores, lane^32 the other 64)
@@ -177,6 +200,8 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
         _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) asm volatile("" : "+v"(pf[kk]));                           \
     }
 #define WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // VSTREAM: everything but the 8 youngest loads (the V^T pieces issued inside the segment that just ended) has landed
+#define WAIT_SET() { if (VSTREAM) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #define BAR()                                   \
     {                                           \
         __builtin_amdgcn_sched_barrier(0);      \
@@ -184,6 +209,61 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
         __builtin_amdgcn_sched_barrier(0);      \
     }
 
+    // PROBE (timing only): every wave of workgroup 0 sums the s_memtime deltas between its segment boundaries over tiles 50..177 in
+    // registers and writes the sums to a.lse (as uint64) after the loop.
+    unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0}, abs_[6] = {0, 0, 0, 0, 0, 0}, last_ = 0;
+#define STAMP(K)                                                                                                     \
+    if (PROBE && blockIdx.x == 0 && j >= 50 && j < 178) {                                                            \
+        const unsigned long long now_ = __builtin_readcyclecounter();                                                \
+        if ((K) != 0 || j > 50) acc_[K] += now_ - last_;                                                             \
+        last_ = now_;                                                                                                \
+        if (j == 100) abs_[K] = now_;                                                                                \
+    }
+    if (LDMA) {
+        // ---- leading-group DMA, one barrier per tile step --------------------------------------------------------------------------
+        // leading : [set j in flight] M(j) . softmax(j) . wait(set j) . BARRIER(j) . issue set j+1 ...
+        // trailing:                   ... softmax(j-1) . M(j) . BARRIER(j) . softmax(j) . M(j+1) ...
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + pdst + i * 4096), 16, kv0 + i * k_pstride, 0, 0, 0);
+            ISSUE_SET(0)
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // K(0) landed; set 0 = {K(1), V(0)} flies
+        }
+        BAR()
+        if (grp == 1) BAR()  // stagger: pairs with the leading group's barrier after M(0)
+        {
+            const int j = 0;
+            (void)j;
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            MSEG(0, 32, 64, 0)
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            BAR()  // leading: releases the trailing group's M(0); trailing: barrier(0)
+            SOFTMAX(0)
+            if (grp == 0) {
+                WAIT_ALL()  // set 0 landed
+                BAR()       // barrier(0)
+            }
+        }
+        for (int j = 1; j < n; ++j) {
+            STAMP(0)
+            if (grp == 0 && !LSTREAM) ISSUE_SET(j)  // slots free: both groups' M(j-1) are behind barrier(j-1)
+            STAMP(1)
+            if (PRIO) __builtin_amdgcn_s_setprio(1);
+            MSEG(j, 0, 64, 2)
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            STAMP(2)
+            if (grp == 1) BAR()  // barrier(j) for the trailing group
+            STAMP(3)
+            SOFTMAX(j)
+            STAMP(4)
+            if (grp == 0) {
+                WAIT_ALL()  // set j (issued ~4 000 cycles ago) landed
+                BAR()       // barrier(j) for the leading group
+            }
+            STAMP(5)
+        }
+    } else {
     // ---- prologue: K(0) landed; set 0 = {K(1), V(0)} in flight (issued by the trailing group) -------------------------------------
     if (grp == 1) {
 #pragma unroll
@@ -197,40 +277,35 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
 
     // ---- j = 0: Q·K^T only ---------------------------------------------------------------------------------------------------
     if (PRIO) __builtin_amdgcn_s_setprio(1);
-    MSEG(0, 32, 64, 0)
+    MSEG(0, 32, 64, 1)
     if (PRIO) __builtin_amdgcn_s_setprio(0);
-    if (grp == 1) WAIT_ALL()  // trailing group: set 0 landed before the barrier that precedes the leading group's M(1)
-    BAR()
-    if (grp == 1) ISSUE_SET(1)  // ring slots of set 1 are free: every wave has finished M(0)
-    SOFTMAX(0)
-    BAR()
-    // ---- steady state ----------------------------------------------------------------------------------------------------------
-    // PROBE (timing only): every wave of workgroup 0 sums the s_memtime deltas between its segment boundaries over tiles 50..177 in
-    // registers and writes the sums to a.lse (as uint64) after the loop.
-    unsigned long long acc_[6] = {0, 0, 0, 0, 0, 0}, abs_[6] = {0, 0, 0, 0, 0, 0}, last_ = 0;
-#define STAMP(K)                                                                                                     \
-    if (PROBE && blockIdx.x == 0 && j >= 50 && j < 178) {                                                            \
-        const unsigned long long now_ = __builtin_readcyclecounter();                                                \
-        if ((K) != 0 || j > 50) acc_[K] += now_ - last_;                                                             \
-        last_ = now_;                                                                                                \
-        if (j == 100) abs_[K] = now_;                                                                                \
+    if (grp == 1) WAIT_SET()  // trailing group: set 0 landed before the barrier that precedes the leading group's M(1)
+    BAR()                     // (ONEBAR: for the leading group this one still pairs with the trailing group's stagger barrier)
+    if (grp == 1) {  // ring slots of set 1 are free: every wave has finished M(0)
+        if (VSTREAM) ISSUE_K(1) else ISSUE_SET(1)
     }
+    SOFTMAX(0)
+    if (!ONEBAR || grp == 0) BAR()
+    // ---- steady state ----------------------------------------------------------------------------------------------------------
     for (int j = 1; j < n; ++j) {
         STAMP(0)
         if (PRIO) __builtin_amdgcn_s_setprio(1);
-        MSEG(j, 0, 64, 0)
+        MSEG(j, 0, 64, 1)
         if (PRIO) __builtin_amdgcn_s_setprio(0);
         STAMP(1)
-        if (grp == 1) WAIT_ALL()         // set j (issued at the top of V(j-1)) landed
-        BAR()
+        if (grp == 1) WAIT_SET()         // set j landed (K(j+1) issued at the top of V(j-1); V^T(j) there or inside M(j-1))
+        if (!ONEBAR || grp == 1) BAR()
         STAMP(2)
-        if (grp == 1) ISSUE_SET(j + 1)
+        if (grp == 1) {
+            if (VSTREAM) ISSUE_K(j + 1) else ISSUE_SET(j + 1)
+        }
         STAMP(3)
         SOFTMAX(j)
         STAMP(4)
-        BAR()
+        if (!ONEBAR || grp == 0) BAR()
         STAMP(5)
     }
+    }  // !LDMA
     if (PROBE && blockIdx.x == 0 && lane == 0)
         for (int i = 0; i < 6; ++i) {
             reinterpret_cast<unsigned long long*>(a.lse)[wave * 8 + i] = acc_[i];
@@ -241,9 +316,11 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
     MSEG(n, 0, 32, 0)
     if (PRIO) __builtin_amdgcn_s_setprio(0);
     WAIT_ALL()           // drain the tail re-reads before this workgroup's LDS can be re-assigned
-    if (grp == 0) BAR()  // matches the extra leading barrier of waves 4-7
+    if (!ONEBAR && grp == 0) BAR()  // matches the extra leading barrier of waves 4-7 (ONEBAR: every barrier is already paired)
 #undef ISSUE_PIECE
 #undef ISSUE_SET
+#undef ISSUE_K
+#undef WAIT_SET
 #undef FRAG
 #undef MSEG
 #undef STAMP
@@ -272,27 +349,40 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
 
 }  // namespace
 
-template <bool PROBE, bool PRIO>
+template <bool PROBE, bool PRIO, bool VSTREAM = true, bool ONEBAR = false, bool LDMA = false, bool LSTREAM = false>
 static int launch_pp2(const fvk_attn_args* a, hipStream_t s) {
     static bool configured[FVK_MAX_DEVICES] = {};
     if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)attn_pp2_kernel<PROBE, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
             fvk_set_error("fvk_attn_dense_bf16 (pp2): cannot set dynamic LDS size");
             return FVK_ERR_LAUNCH;
         }
     }
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
-    hipLaunchKernelGGL((attn_pp2_kernel<PROBE, PRIO>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a);
+    hipLaunchKernelGGL((attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
 
 // probe != 0: timing probe build (a->lse receives s_memtime sums, see PROBE)
 int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s) {
-    switch (probe) {  // 0 shipped; 1 probe; 2 = no s_setprio (A/B); 3 = probe without s_setprio
-        case 1: return launch_pp2<true, true>(a, s);
-        case 2: return launch_pp2<false, false>(a, s);
-        case 3: return launch_pp2<true, false>(a, s);
-        default: return launch_pp2<false, true>(a, s);
+    switch (probe) {
+        // 0 (shipped): one barrier per tile step, the LEADING group issues the DMA inside its matrix segment (round 2: -3 % time, -9 % cycles
+        // against the round-1 schedule, bit-identical output); 1 = its s_memtime probe; 2 = shipped without s_setprio (A/B).
+        // Earlier schedules, kept for A/B (scripts/attn_variants_check.py, attn_impl = 99 + k):
+        //   4 / 5  round 1: two barriers, the trailing group issues all 16 pieces at the top of its softmax segment (5 = probe)
+        //   12 / 3 two barriers, trailing group's V^T pieces inside its matrix segment (3 = probe)
+        //   6 / 7  one barrier, trailing group issues (7 = probe);  8 / 9 one barrier, leading group issues AHEAD of its matrix segment
+        case 1: return launch_pp2<true, true, false, true, true, true>(a, s);
+        case 2: return launch_pp2<false, false, false, true, true, true>(a, s);
+        case 3: return launch_pp2<true, true, true>(a, s);
+        case 4: return launch_pp2<false, true, false>(a, s);
+        case 5: return launch_pp2<true, true, false>(a, s);
+        case 6: return launch_pp2<false, true, false, true>(a, s);
+        case 7: return launch_pp2<true, true, false, true>(a, s);
+        case 8: return launch_pp2<false, true, false, true, true, false>(a, s);
+        case 9: return launch_pp2<true, true, false, true, true, false>(a, s);
+        case 12: return launch_pp2<false, true, true>(a, s);
+        default: return launch_pp2<false, true, false, true, true, true>(a, s);
     }
 }

@@ -15,7 +15,7 @@ for _ in range(2):
 torch.cuda.synchronize()
 t = buf.cpu()[:64].view(8, 8).double() / 256
 names = ["loopback", "M(mfma)", "wait_dma", "barrier1", "dma_issue", "V(softmax)", "barrier2"]
-if impl in (100, 102):
+if impl >= 100:
     names = ["loopback", "M(mfma)", "wait+barrier1", "dma_issue", "V(softmax)", "wait+barrier2"]
     t = buf.cpu()[:64].view(8, 8).double() / 128
     ab = buf.cpu()[64:].view(8, 8)[:, :6]

@@ -431,6 +431,27 @@ def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
     _attn_check(out, ref, f"dense impl {impl} {B},{H},{Sq},{Skv}")
 
 
+def test_attn_pp2_schedules_are_bit_identical(ops, tunables):
+    """The schedule variants of the 128-key-tile kernel (attn_pp2.hip: attn_impl 0 = shipped one-barrier / leading-group in-stream DMA;
+    103 = round 1's two-barrier schedule; 111 = V^T pieces inside the trailing matrix segment; 105 / 107 = one barrier with the trailing /
+    leading group issuing ahead of the segment) move DMA issue and barriers only: same arithmetic in the same order, so the outputs must
+    be bit-identical — also with a late rescale spike and ragged tails, and across repeated launches (a slot reused too early or a
+    barrier miscount shows up as a difference or a hang)."""
+    B, H, Sq, Skv = 2, 3, 1030, 2999
+    q, k, v = rnd((B, Sq, H, 128), 1, 0.7), rnd((B, Skv, H, 128), 2, 0.7), rnd((B, Skv, H, 128), 3)
+    k[0, 2500, 1] = q[0, 700, 1] * 6
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    outs = {}
+    for impl in (0, 103, 105, 107, 111, 0):
+        tunables("attn_impl", impl)
+        outs.setdefault(impl, []).append(ops.attn_dense(qd, kd, vd, layout="bshd").cpu())
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    _attn_check(outs[0][0], ref, "attn_pp2 shipped schedule")
+    for impl, lst in outs.items():
+        for o in lst:
+            assert torch.equal(o, outs[0][0]), f"attn_impl {impl} differs from the shipped schedule"
+
+
 @pytest.mark.parametrize("impl", [0, 2, 3])
 def test_attn_pp_rescale_branch_and_repeatability(ops, tunables, impl):
     """Spiked keys force the running-max rescale in late tiles of the ping-pong kernel; 3 launches must agree bit-for-bit
