@@ -236,7 +236,11 @@ def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3)):
                 tiles = [(x * nt[1] + y) * nt[2] + z for x in win(a, nt[0], window[0]) for y in win(b, nt[1], window[1])
                          for z in win(c, nt[2], window[2])]
                 blocks = [t * sub + s_ for t in tiles for s_ in range(sub) if bsz[t * sub + s_] > 0]
-                lists += [blocks] * (tok // qb)
+                # a tile's real tokens come first: query lists that hold only padding rows (edge tiles of a ragged grid: 13 % of the
+                # lists at 21x30x52) get an EMPTY KV list — the kernel then does nothing for them and their rows are dropped by untile
+                q_tile = (a * nt[1] + b) * nt[2] + c
+                real = int(vbs[q_tile])
+                lists += [blocks if real > i * qb else [] for i in range(tok // qb)]
     mx = max(len(l) for l in lists)
     idx = np.zeros((len(lists), mx), dtype=np.int32)
     num = np.zeros((len(lists),), dtype=np.int32)
