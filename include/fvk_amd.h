@@ -151,14 +151,20 @@ int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream);
 /* block-sparse (VSA sparse branch; sliding-tile windows on arbitrary canvases): query block i (q_block = 64 or 128 rows) attends KV
  * blocks q2k_idx[b,h,i,0..q2k_num[b,h,i]) (64 keys each, of which the first kv_block_sizes[j] are valid).
  * ref: fastvideo-kernel/csrc/attention/block_sparse_h100.cu:66-272, triton_kernels/block_sparse_attn_triton.py:32-160.
- * q2k_idx int32 [B,H,Nq,max_kv], q2k_num int32 [B,H,Nq] with Nq = Sq / q_block, kv_block_sizes int32 [Nkv]. Skv multiple of 64. */
+ * q2k_idx int32 [B,H,Nq,max_kv], q2k_num int32 [B,H,Nq] with Nq = Sq / q_block, kv_block_sizes int32 [Nkv]. Skv multiple of 64.
+ * A list may be empty (q2k_num = 0: the block's output rows are written as zeros) and a listed block may have size 0.  Block ids
+ * must be < 2^24; the first 2048 entries of a list are kept in LDS (longer lists fall back to global reads past that point).
+ * Every entry point taking fvk_attn_args refuses (FVK_ERR_ARG) a (batch, head) K slice whose extent reaches 4 GiB: the K / V^T
+ * streams are addressed through 32-bit buffer descriptors. */
 int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
                                const int32_t* kv_block_sizes, int max_kv, int q_block, void* stream);
 
 /* sliding-tile attention: tokens in tile-major order, tile = tile_t*tile_h*tile_w tokens (multiple of 64),
  * canvas of (ct,ch,cw) tiles; head h uses window (win[3h], win[3h+1], win[3h+2]) tiles with the clamped
- * centre rule of ref: fastvideo-kernel/tests/support_flex_sta.py:29-59 ≡ st_attn_triton.py:158-176.
- * win_host: HOST int32 [3*H].  No text tokens (Wan T2V self-attention has none). */
+ * centre rule of ref: fastvideo-kernel/tests/support_flex_sta.py:29-59 ≡ st_attn_triton.py:158-176:
+ *   kv tile in window  <=>  |clamp(q_tile, k/2, n-1-k/2) - kv_tile| <= k/2   per axis, INTEGER k/2
+ * so window sizes may be odd or even (>= 1; an even k selects like k+1 — the reference's own test uses (3,1,10),
+ * fastvideo-kernel/tests/test_sta.py:40).  win_host: HOST int32 [3*H].  No text tokens (Wan T2V self-attention has none). */
 int fvk_attn_sta_bf16(const fvk_attn_args* a, int ct, int ch, int cw, int tile_tokens, const int32_t* win_host,
                       void* stream);
 
