@@ -62,6 +62,7 @@ class WanTransformer3DModelHip:
         self._load(state_dict)
         self._vsa_cache = {}
         self.attn_events = None  # set to a list to collect (start, end, Sq, Skv, heads) HIP-event pairs
+        self.vsa_trace = None    # set to a list to collect every layer's VSA block mask (tests)
 
     # ------------------------------------------------------------------ weights
     def _load(self, sd):
@@ -204,7 +205,11 @@ class WanTransformer3DModelHip:
             tq, tk, tv = tile(q4, 0), tile(k4, 1), tile(v4, 2)
             tg = tile(gate.unsqueeze(0), 3) if gate is not None else None
             vbs = m["variable_block_sizes"]
-            o = kernel_api.video_sparse_attn_bshd(tq, tk, tv, vbs, vbs, m["topk"], 64, tg)
+            if self.vsa_trace is None:
+                o = kernel_api.video_sparse_attn_bshd(tq, tk, tv, vbs, vbs, m["topk"], 64, tg)
+            else:  # tests: keep every layer's block selection so that an oracle can be evaluated with the SAME selection
+                o, inter = kernel_api._vsa_forward(tq, tk, tv, vbs, vbs, m["topk"], tg, "bshd", True)
+                self.vsa_trace.append(inter["mask"])
             o = ops.gather_rows(o, S, m["untile_combined_index"], None)
             if q.shape[0] != S:
                 o = torch.cat([o, o.new_zeros((1, q.shape[0] - S, *o.shape[2:]))], 1)
