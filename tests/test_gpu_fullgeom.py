@@ -60,3 +60,28 @@ def test_one_block_at_full_geometry_matches_oracle(block_1_3b, name, latent_shap
         _cmp(tr[key], tr_ref[key], f"{name} {key}")
     _cmp(y, y_ref, f"{name} model output")
     assert y.shape == latent.shape and y.dtype == torch.bfloat16
+
+
+def test_one_block_at_a14b_geometry_matches_oracle():
+    """Wan2.2-T2V-A14B block geometry (BASELINE cfg4: 40 heads x 128 = 5120, ffn 13 824, text 512 x 4096: QKV row stride 15 360, RMS norm
+    across 5120 columns, 54 / 20 column tiles per GEMM) in a 1-layer model on a reduced latent [1,16,5,32,32] (S = 1 280) vs the oracle."""
+    from fastvideo_amd import wan_config as WC
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    from oracle import wan_oracle as W
+    cfg = WC.WanConfig("Wan2.2-A14B geometry, 1 layer", 40, 128, 13824, 1)
+    sd = WC.random_state_dict(cfg, seed=3, device="cpu")
+    gen = torch.Generator().manual_seed(7)
+    for k in ("blocks.0.scale_shift_table", "scale_shift_table"):
+        sd[k] = (torch.randn(sd[k].shape, generator=gen) * 0.3).to(sd[k].dtype)
+    latent = torch.randn((1, 16, 5, 32, 32), generator=gen).bfloat16()
+    ctx = torch.randn((1, 512, cfg.text_dim), generator=gen).bfloat16()
+    t = torch.tensor([321.0])
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    tr_ref, tr = {}, {}
+    with torch.no_grad():
+        y_ref = W.WanOracle(sd, num_heads=cfg.num_heads).forward(latent, ctx, t, trace=tr_ref)
+    model = WanTransformer3DModelHip(sd, cfg.num_heads, cfg.head_dim, cfg.patch_size, cfg.eps, cfg.freq_dim)
+    y = model(latent.cuda(), ctx.cuda(), t.cuda(), trace=tr)
+    for key in ("blocks.0.after_self_attn", "blocks.0.out", "norm_out"):
+        _cmp(tr[key], tr_ref[key], f"A14B geometry {key}")
+    _cmp(y, y_ref, "A14B geometry model output")
