@@ -217,7 +217,7 @@ def run_vae(args):
         for d in shp[1:]:
             fan_in *= d
         sd[n] = (torch.ones(shp) if "gamma" in n else ((torch.rand(shp, generator=g) * 2 - 1) * (3.0 / fan_in)**0.5 if len(shp) >= 4 else torch.zeros(shp)))
-    dec = WanVaeDecoderHip(sd, device="cuda")
+    dec = WanVaeDecoderHip(sd, device="cuda", frames_per_pass=args.vae_frames_per_pass)
     z = torch.randn(latent_shape, generator=g).cuda()
     for _ in range(max(args.warmup, 1)):
         y = dec.decode(z)
@@ -252,7 +252,8 @@ def run_vae(args):
            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16 activations, fp32 accumulation and fp32 output (the reference's default VAE precision is fp32)",
            "data": "synthetic (randn latent, random-init decoder)",
-           "config": {"workload": f"Wan2.1 VAE decoder (base_dim 96), frame-chunked cached decode of latent {list(latent_shape)}", "parallelism": "1 GPU"},
+           "config": {"workload": f"Wan2.1 VAE decoder (base_dim 96), frame-chunked cached decode of latent {list(latent_shape)}", "parallelism": "1 GPU",
+                      "frames_per_pass": args.vae_frames_per_pass},
            "step_tflops": round(fl / (ms * 1e-3) / 1e12, 1), "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
            "roofline": dict(bound="mfma", kernel=dom, achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                             frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None, flops_per_launch=fl_d / n_d,
@@ -286,6 +287,9 @@ def main():
                     help="auto: the reference itself when a reference tree is present (live or staged), else the oracle port")
     ap.add_argument("--stage", default="dit", choices=["dit", "vae"],
                     help="dit (default, the contract line): one DiT forward per step; vae: one causal-3D-conv VAE decode of the same latent per step")
+    ap.add_argument("--vae-frames-per-pass", type=int, default=4,
+                    help="--stage vae: latent frames per decoder pass after the first (1 = the reference's frame-by-frame walk; results are "
+                         "bit-identical for every value, tests/test_gpu_vae.py)")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (result marked invalid)")
     args = ap.parse_args()
     if args.stage == "vae":

@@ -38,11 +38,14 @@ __device__ __forceinline__ void wait_vm() {  // counted wait: at most N of this 
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WNW, int EPI, bool UPS>
+// NB = 32-channel output blocks per wave: 3 everywhere except conv_out (Cout = 3 <= 32, EPI_FINAL), whose NB = 1 instantiation does a third
+// of the padded MFMA work and stages a third of the weight rows.
+template <int WNW, int EPI, bool UPS, int NB = 3>
 __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(NB == 3 || (NB == 1 && WNW == 1 && EPI == EPI_FINAL && !UPS), "NB = 1 serves the final conv only");
     constexpr int TH = WNW == 1 ? 16 : 8, TW = 32;
-    constexpr int TN = WNW == 1 ? 96 : 192;
+    constexpr int TN = WNW * NB * 32;
     constexpr int HH = UPS ? TH / 2 + 2 : TH + 2, WW = UPS ? TW / 2 + 2 : TW + 2;  // halo slab in INPUT pixels
     constexpr int XPIECES = (HH * WW + 15) / 16;       // 16-pixel DMA pieces per slab
     constexpr int XS = (XPIECES + 7) / 8;              // per wave (surplus = zero pieces inside the slab's padded tail)
@@ -144,12 +147,12 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
         }
 #pragma unroll
     for (int dw = 0; dw < 3; ++dw) colt_[dw] = UPS ? ((w0 + l31 + dw - 1) >> 1) - wb : l31 + dw;
-    const int wfo = (wn * 96 + l31) * 64;  // weight fragment row within a (dw) block
+    const int wfo = (wn * (NB * 32) + l31) * 64;  // weight fragment row within a (dw) block
     const int wsw = (l31 >> 2) & 3;
 
-    f32x16 acc[3][2];
+    f32x16 acc[NB][2];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NB; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -186,32 +189,37 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
         for (int dh = 0; dh < 3; ++dh, ++u) {
             C3_STAMP(0)
             const unsigned char* wsb = smem + W_BASE + rd_slot * WSTEP;
-            bf16x8 wf[2][3], xf[2][2];
+            bf16x8 wf[2][NB], xf[2][2];
             // fragment group g = (dw, ks): w rows nb at wsb + dw*TN*64 + row*64 + chunk; x pixels mb at xs + p*64 + chunk (both swizzled)
 #define C3_READ(G, BUF, R)                                                                                          \
     {                                                                                                               \
         const int dw_ = (G) >> 1, c_ = 2 * ((G) & 1) + hi;                                                          \
-        if ((R) < 3) wf[BUF][R] = *reinterpret_cast<const bf16x8*>(wsb + dw_ * (TN * 64) + wfo + (R) * 2048 + ((c_ ^ wsw) << 4)); \
+        if ((R) < NB) wf[BUF][(R) < NB ? (R) : 0] = *reinterpret_cast<const bf16x8*>(wsb + dw_ * (TN * 64) + wfo + (R) * 2048 + ((c_ ^ wsw) << 4)); \
         else {                                                                                                      \
-            const int p_ = rowt_[(R) - 3][dh] + colt_[dw_];                                                         \
-            xf[BUF][(R) - 3] = *reinterpret_cast<const bf16x8*>(xs + p_ * 64 + ((c_ ^ ((p_ >> 2) & 3)) << 4));     \
+            const int p_ = rowt_[(R) - NB][dh] + colt_[dw_];                                                        \
+            xf[BUF][(R) - NB] = *reinterpret_cast<const bf16x8*>(xs + p_ * 64 + ((c_ ^ ((p_ >> 2) & 3)) << 4));    \
         }                                                                                                           \
     }
 #pragma unroll
-            for (int r = 0; r < 5; ++r) C3_READ(0, 0, r)
+            for (int r = 0; r < NB + 2; ++r) C3_READ(0, 0, r)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int g = 0; g < 6; ++g) {
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
+                for (int i = 0; i < 2 * NB; ++i) {
                     const int nb = i >> 1, mb = i & 1;
                     acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g & 1][nb], xf[g & 1][mb], acc[nb][mb], 0, 0, 0);
-                    if (g < 5 && i < 5) C3_READ(g + 1, (g + 1) & 1, i)
+                    if (NB == 3) {
+                        if (g < 5 && i < 5) C3_READ(g + 1, (g + 1) & 1, i)
+                    } else if (g < 5) {  // NB = 1: three fragment reads behind two MFMAs
+                        if (i == 0) { C3_READ(g + 1, (g + 1) & 1, 0) C3_READ(g + 1, (g + 1) & 1, 1) }
+                        else C3_READ(g + 1, (g + 1) & 1, 2)
+                    }
                     // this wave's DMA pieces ride in the gaps: weights of step u+2 (its ring slot was read in step u-1), and the
                     // next slab (its buffer was read in the previous slab) during dh = 0 and 1 so that it has landed by this slab's end
-                    if (i == 2 || i == 4) {
-                        const int k = 2 * g + (i == 4);  // two issue slots per group, 12 per step
+                    if (NB == 3 ? (i == 2 || i == 4) : true) {
+                        const int k = NB == 3 ? 2 * g + (i == 4) : 2 * g + i;  // two issue slots per group, 12 per step
                         if (k < WS) C3_ISSUE_W(k)
                         else if (dh == 0 && k - WS < XS0) C3_ISSUE_X(k - WS)
                         else if (dh == 1 && k - WS < XS1) C3_ISSUE_X(XS0 + (k - WS))
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
     const int HW = a.H * a.W;
     if (EPI == EPI_FINAL) {
 #pragma unroll
-        for (int nb = 0; nb < 3; ++nb)
+        for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
             for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -273,6 +281,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
                 }
         return;
     }
+    if constexpr (NB == 3) {
     unsigned char* st = smem + wave * EPI_WAVE;
 #pragma unroll
     for (int nb = 0; nb < 3; ++nb)
@@ -369,19 +378,20 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
             st_bf16x8(a.out + (long)t_out * a.out_fs + hw * a.Cout + n, y);
         }
     }
+    }  // NB == 3
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int WNW, int EPI, bool UPS>
+template <int WNW, int EPI, bool UPS, int NB = 3>
 int launch3(Conv3Args a, hipStream_t s) {
     constexpr int TH = WNW == 1 ? 16 : 8;
-    constexpr int TN = WNW == 1 ? 96 : 192;
+    constexpr int TN = WNW * NB * 32;
     constexpr int HH = UPS ? TH / 2 + 2 : TH + 2, WW = UPS ? 18 : 34;
     constexpr int RING = 2 * ((HH * WW + 15) / 16) * 1024 + 3 * (3 * TN / 16) * 1024 + 1024;
     constexpr int LDS = RING > 8 * 64 * 208 ? RING : 8 * 64 * 208;  // epilogue staging reuses the ring
     static bool configured[FVK_MAX_DEVICES] = {};
     if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)vae_conv3_kernel<WNW, EPI, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)vae_conv3_kernel<WNW, EPI, UPS, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             fvk_set_error("fvk_vae_conv_bf16 (3x3): cannot set dynamic LDS size %d", LDS);
             return FVK_ERR_LAUNCH;
         }
@@ -390,7 +400,7 @@ int launch3(Conv3Args a, hipStream_t s) {
     a.tiles_w = (a.W + 31) / 32;
     a.ntn = (a.Cout + TN - 1) / TN;
     const long nwg = (long)a.T * a.tiles_h * a.tiles_w * a.ntn;
-    hipLaunchKernelGGL((vae_conv3_kernel<WNW, EPI, UPS>), dim3((unsigned)nwg), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((vae_conv3_kernel<WNW, EPI, UPS, NB>), dim3((unsigned)nwg), dim3(512), LDS, s, a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -425,6 +435,7 @@ int fvk_vae_conv3_launch(const void* in, const void* w, const void* bias, void* 
     a.residual = (const bf16_t*)residual; a.out_f32 = out_f32;
     a.out_fs = out_fs; a.res_fs = res_fs; a.plane_stride = plane_stride;
     a.T = T; a.H = H; a.W = W; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KT = KT; a.ring = ring; a.ring_start = ring_start;
+    if (epilogue == EPI_FINAL && !ups && Cout <= 32) return launch3<1, EPI_FINAL, false, 1>(a, s);  // conv_out: one 32-channel block per wave
     const int w96 = (Cout + 95) / 96 * 96, w192 = (Cout + 191) / 192 * 192;
     if (w192 <= w96) return launch3_e<2>(a, epilogue, ups != 0, s);
     return launch3_e<1>(a, epilogue, ups != 0, s);

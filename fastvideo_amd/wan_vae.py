@@ -74,7 +74,8 @@ class WanVaeDecoderHip:
                  device="cuda", *, use_feature_cache: bool = True, tile_sample_min_height: int = 256, tile_sample_min_width: int = 256,
                  tile_sample_min_num_frames: int = 16, tile_sample_stride_height: int = 192, tile_sample_stride_width: int = 192,
                  tile_sample_stride_num_frames: int = 12, blend_num_frames: int | None = None, use_tiling: bool = False,
-                 use_temporal_tiling: bool = False, use_parallel_tiling: bool = False, sp_group=None, fuse_norm: bool = True):
+                 use_temporal_tiling: bool = False, use_parallel_tiling: bool = False, sp_group=None, fuse_norm: bool = True,
+                 frames_per_pass: int = 4):
         self.device = torch.device(device)
         # VAEConfig / WanVAEConfig fields (configs/models/vaes/base.py:29-46, wanvae.py:72-82)
         self.use_feature_cache = use_feature_cache
@@ -134,33 +135,56 @@ class WanVaeDecoderHip:
                 u["tc_b"] = [tc.b[:half].contiguous(), tc.b[half:].contiguous()]
             self.ups[i] = u
         self.g_out = self.f32("decoder.norm_out.gamma")
+        # cached decode: latent frames per decoder pass after the first.  The reference walks ONE latent frame per pass (wanvae.py:1222-1233,
+        # a memory-saving device); the causal convs read their history from rings, so F frames per pass are the same arithmetic per
+        # output element (bit-identical, tests/test_gpu_vae.py) with F x the workgroups at the 60x104 stages and 1/F the launches.
+        if frames_per_pass < 1:
+            raise ValueError("frames_per_pass must be >= 1")
+        self.frames_per_pass = int(frames_per_pass)
         self._sites = None
         self._tile_sites = (None, None)  # (geometry key, ring set) of the cache-less tile decode, reused while the geometry repeats
         self.t_ratio = 2**sum(1 for i in range(len(self.dim_mult) - 1) if self.t_up[i])
         self.s_ratio = 2**(len(self.dim_mult) - 1)
 
     # ------------------------------------------------------------------ per-decode state
+    def _site_shapes(self, H, W, t0):
+        """(name, frames per pass, H, W, C, is_time_conv_buffer) of every causal-history buffer of one decoder pass over t0 latent frames."""
+        t, h, w = t0, H, W
+        yield "conv_in", t, h, w, self.conv_in.cin, False
+        for p in ("decoder.mid_block.resnets.0.", "decoder.mid_block.resnets.1."):
+            yield p + "1", t, h, w, self.res[p]["conv1"].cin, False
+            yield p + "2", t, h, w, self.res[p]["conv2"].cin, False
+        for i in range(len(self.dim_mult)):
+            for j in range(self.nres + 1):
+                p = f"decoder.up_blocks.{i}.resnets.{j}."
+                yield p + "1", t, h, w, self.res[p]["conv1"].cin, False
+                yield p + "2", t, h, w, self.res[p]["conv2"].cin, False
+            if i in self.ups:
+                if "tc" in self.ups[i]:
+                    yield f"tc{i}", t, h, w, self.ups[i]["tc"].cin, True
+                    t *= 2
+                h, w = 2 * h, 2 * w
+        yield "conv_out", t, h, w, self.conv_out.cin, False
+
+    RING_BYTES_MAX = 0xFFFFFF00  # the conv kernels address one ring through a 32-bit buffer descriptor (fvk_vae_conv_bf16 refuses more)
+
+    def _fit_frames_per_pass(self, H, W):
+        """Largest F <= frames_per_pass whose widest ring ((t_ratio F + 2) full-resolution frames) stays inside one buffer descriptor."""
+        F = self.frames_per_pass
+        while F > 1 and max((t + 2) * h * w * c * 2 for _, t, h, w, c, _ in self._site_shapes(H, W, F)) >= self.RING_BYTES_MAX:
+            F -= 1
+        return F
+
     def _make_sites(self, H, W, t0=1):
         """One ring per cached conv, zero-initialised (= the reference's empty feature cache); t0 = latent frames per decoder pass."""
         dev = self.device
         sites = {}
-        t, h, w = t0, H, W
-        sites["conv_in"] = _Site(t, h, w, self.conv_in.cin, dev)
-        for p in ("decoder.mid_block.resnets.0.", "decoder.mid_block.resnets.1."):
-            sites[p + "1"] = _Site(t, h, w, self.res[p]["conv1"].cin, dev)
-            sites[p + "2"] = _Site(t, h, w, self.res[p]["conv2"].cin, dev)
-        for i in range(len(self.dim_mult)):
-            for j in range(self.nres + 1):
-                p = f"decoder.up_blocks.{i}.resnets.{j}."
-                sites[p + "1"] = _Site(t, h, w, self.res[p]["conv1"].cin, dev)
-                sites[p + "2"] = _Site(t, h, w, self.res[p]["conv2"].cin, dev)
-            if i in self.ups:
-                if "tc" in self.ups[i]:
-                    # linear buffer [2 history frames + chunk frames]; the last resnet writes its output straight into it
-                    sites[f"tc{i}"] = torch.zeros((t + 2, h, w, self.ups[i]["tc"].cin), dtype=BF16, device=dev)
-                    t *= 2
-                h, w = 2 * h, 2 * w
-        sites["conv_out"] = _Site(t, h, w, self.conv_out.cin, dev)
+        for name, t, h, w, c, is_tc in self._site_shapes(H, W, t0):
+            if is_tc:  # linear buffer [2 history frames + chunk frames]; the last resnet writes its output straight into it
+                sites[name] = torch.zeros((t + 2, h, w, c), dtype=BF16, device=dev)
+            else:
+                sites[name] = _Site(t, h, w, c, dev)
+        sites["frames_per_pass"] = t0
         return sites
 
     # ------------------------------------------------------------------ building blocks
@@ -302,14 +326,18 @@ class WanVaeDecoderHip:
         site = sites["conv_in"]
         plane = out.stride(0)
         t_out = 0
-        for i in range(Tl):
-            slot = (site.start + 2) % site.ring
-            ops.gemm(zc[i].view(H * W, 64), self.pq_w, self.pq_b, out=site.buf[slot].view(H * W, -1))
+        i = 0
+        while i < Tl:
+            first = fresh and i == 0  # the very first latent frame of a stream always goes alone (it skips time_conv)
+            n = 1 if first else min(sites["frames_per_pass"], Tl - i)
+            for j in range(n):
+                slot = (site.start + 2 + j) % site.ring
+                ops.gemm(zc[i + j].view(H * W, 64), self.pq_w, self.pq_b, out=site.buf[slot].view(H * W, -1))
             tr = [] if trace is not None else None
-            first = fresh and i == 0
-            t_out += self._decoder_pass(1, first, not first, out[:, t_out:], plane, tr)
+            t_out += self._decoder_pass(n, first, not first, out[:, t_out:], plane, tr)
             if trace is not None:
                 trace.append(tr)
+            i += n
         self._sites = None
         return t_out
 
@@ -325,7 +353,7 @@ class WanVaeDecoderHip:
         Ho, Wo = self._out_geometry(H, W)
         Tout = 1 + self.t_ratio * (Tl - 1)
         out = torch.empty((self.conv_out.cout, Tout, Ho, Wo), dtype=torch.float32, device=self.device)
-        n = self._chunked(zc, self._make_sites(H, W), True, out, trace)
+        n = self._chunked(zc, self._make_sites(H, W, self._fit_frames_per_pass(H, W)), True, out, trace)
         assert n == Tout
         return out.unsqueeze(0)
 
@@ -343,7 +371,7 @@ class WanVaeDecoderHip:
         zc = self._latents_cl(z)
         Tl, H, W, _ = zc.shape
         if cache["sites"] is None:
-            cache["sites"], cache["geom"] = self._make_sites(H, W), (H, W)
+            cache["sites"], cache["geom"] = self._make_sites(H, W, self._fit_frames_per_pass(H, W)), (H, W)
         elif cache["geom"] != (H, W):
             raise ValueError(f"streaming_decode: latent size {(H, W)} differs from the cache's {cache['geom']}")
         Ho, Wo = self._out_geometry(H, W)

@@ -186,3 +186,40 @@ def test_fused_norm_equals_separate_norm_kernels():
     err = (outs[0] - outs[1]).abs()
     print(f"fused vs separate norm: max {err.max().item():.3g} mean {err.mean().item():.3g}")
     assert err.max().item() < 3e-2 and err.mean().item() < 1.5e-3  # bf16 one-ulp flips propagate through the six 96-channel convs
+
+
+def test_frames_per_pass_is_bit_identical_to_the_reference_frame_by_frame_walk():
+    """The cached decode walks F latent frames per decoder pass after the first (default 4) where the reference walks one
+    (wanvae.py:1222-1233).  Every conv reads its causal history from a ring, so each output element sees the same operands in the same
+    order whatever F is: F = 1 (the reference's literal walk), 2, 3 (ragged last group), 4 and 7 must agree bit for bit — on the real
+    decoder widths (base_dim 96: the fused-norm epilogue, the 384-wide mid attention and both time-upsampling convs are on the path)."""
+    from fastvideo_amd.wan_vae import WanVaeDecoderHip
+    from fastvideo_amd.wan_config import wan_vae_param_spec
+    g = torch.Generator().manual_seed(3)
+    sd = {}
+    for n, shp in wan_vae_param_spec(base_dim=96):
+        fan_in = 1
+        for d in shp[1:]:
+            fan_in *= d
+        if "gamma" in n:
+            sd[n] = torch.ones(shp) + 0.05 * torch.randn(shp, generator=g)
+        elif len(shp) >= 4:
+            sd[n] = (torch.rand(shp, generator=g) * 2 - 1) * (3.0 / fan_in)**0.5
+        else:
+            sd[n] = 0.02 * torch.randn(shp, generator=g)
+    z = torch.randn(1, 16, 6, 8, 12, generator=g).cuda()
+    ref = WanVaeDecoderHip(sd, frames_per_pass=1).decode(z)
+    assert ref.shape == (1, 3, 21, 64, 96)
+    for F in (2, 3, 4, 7):
+        y = WanVaeDecoderHip(sd, frames_per_pass=F).decode(z)
+        assert torch.equal(y, ref), f"frames_per_pass={F}: {(y != ref).sum().item()} elements differ"
+    with pytest.raises(ValueError):
+        WanVaeDecoderHip(sd, frames_per_pass=0)
+    # a ring that would outgrow one 32-bit buffer descriptor lowers F instead of reaching the kernel's refusal
+    dec = WanVaeDecoderHip(sd, frames_per_pass=4)
+    assert dec._fit_frames_per_pass(8, 12) == 4
+    widest = lambda F: max((t + 2) * h * w * c * 2 for _, t, h, w, c, _ in dec._site_shapes(8, 12, F))
+    dec.RING_BYTES_MAX = widest(3)  # F = 3's widest ring is exactly one byte too many
+    assert dec._fit_frames_per_pass(8, 12) == 2
+    assert torch.equal(dec.decode(z), ref)
+    assert WanVaeDecoderHip(sd, frames_per_pass=4)._fit_frames_per_pass(135, 240) == 2  # 1080p: 4 F + 2 frames of 1080 x 1920 x 96 bf16
