@@ -22,6 +22,11 @@
 
 int fvk_attn_pp_launch(const fvk_attn_args* a, int variant, hipStream_t s);  // attn_pp.hip
 int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s);   // attn_pp2.hip
+struct fvk_pp2_lists {  // attn_pp2.hip: 256-row workgroups over shared KV block lists
+    const int32_t* q2k_idx; const int32_t* q2k_num; const int32_t* kv_block_sizes; const int32_t* q_rows_valid;
+    int max_kv, n_lists, q_stride, q_sub;
+};
+int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);
 
 namespace {
 
@@ -33,6 +38,10 @@ struct ModeArgs {
     const int32_t* q2k_num;
     const int32_t* kv_block_sizes;
     int max_kv;
+    // block-sparse, shared lists (fvk_attn_tile_lists_bf16): list i serves query rows i*q_stride + q_offset .. + BMQ; n_lists lists per head;
+    // q_rows_valid[i] (optional) = real query rows of list i's q_stride rows.  q_stride = 0: one list per BMQ rows (the plain form).
+    const int32_t* q_rows_valid;
+    int q_stride, q_offset, n_lists;
     // STA
     int ct, ch, cw, tile_tokens;
     int win[3 * 64];
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
     const bool compute = wave < NCW;                                 // this wave owns 32 query rows
     const int pr = PAIRS == 1 ? 0 : (compute ? wave / NW : (wave - NCW) / (NL ? NL : 1));  // which query block of the workgroup
     const int lw = compute ? wave % NW : 0;                          // index among the pair's compute waves
-    const int nqb = (a.Sq + BMQ - 1) / BMQ;                          // query blocks (= KV lists) per head
+    const int nqb = (MODE == MODE_BLOCKS && ma.q_stride) ? ma.n_lists : (a.Sq + BMQ - 1) / BMQ;  // query blocks (= KV lists) per head
     const int nwg = (nqb + PAIRS - 1) / PAIRS;                       // workgroups per head
     const int qb = (blockIdx.x % nwg) * PAIRS + pr;
     const bool pair_ok = PAIRS == 1 || qb < nqb;
@@ -103,6 +112,7 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
     } else if (MODE == MODE_BLOCKS) {
         const long meta = ((long)b * a.H + h) * nqb + (pair_ok ? qb : 0);
         n_tiles = pair_ok ? ma.q2k_num[meta] : 0;
+        if (ma.q_rows_valid && pair_ok && ma.q_offset >= ma.q_rows_valid[qb]) n_tiles = 0;  // only padding rows
         blk_list = ma.q2k_idx + meta * ma.max_kv;
         // The KV lists live in LDS for the whole kernel: entry = block id | (valid keys << 24).  Read from global memory inside the
         // tile loop, `id = blk_list[j+1]` is a vector load every wave must WAIT for (vmcnt(0): a full L2 round trip, 500+ cycles under
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
     };
 
     // ---- Q fragments (B operand): row q0 + l31, d = 16*ks + 8*hi .. +8 -----------------------------------
-    const int q0 = qb * BMQ + lw * 32;  // (loader waves own no rows)
+    const int q0 = ((MODE == MODE_BLOCKS && ma.q_stride) ? qb * ma.q_stride + ma.q_offset : qb * BMQ) + lw * 32;  // (loader waves own no rows)
     int qrow = q0 + l31;
     const bool q_ok = pair_ok && qrow < a.Sq;
     qrow = q_ok ? qrow : a.Sq - 1;
@@ -417,7 +427,7 @@ int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
         }
     }
     const int bmq = NW * 32;
-    const long nlists = (a->Sq + bmq - 1) / bmq;
+    const long nlists = (MODE == MODE_BLOCKS && ma.q_stride) ? ma.n_lists : (a->Sq + bmq - 1) / bmq;
     const long nblk = ((nlists + PAIRS - 1) / PAIRS) * a->H * a->B;
     hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE, DK, NL, PAIRS>), dim3((unsigned)nblk), dim3(PAIRS * (NW + NL) * 64), LDS, s, *a, ma);
     FVK_LAUNCH_CHECK();
@@ -470,6 +480,34 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     // one-list 4-wave workgroups, two per CU, for A/B)
     if (fvk::tunable(fvk::TUNE_ATTN_IMPL) == 50) return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);
     return launch<2, MODE_BLOCKS, 128, 2, 2>(a, ma, (hipStream_t)stream);
+}
+
+extern "C" int fvk_attn_tile_lists_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
+                                        const int32_t* kv_block_sizes, int max_kv, int rows_per_list, const int32_t* q_rows_valid,
+                                        void* stream) {
+    int rc = check_common(a, "fvk_attn_tile_lists_bf16");
+    if (rc) return rc;
+    FVK_CHECK(q2k_idx && q2k_num && kv_block_sizes && max_kv > 0, FVK_ERR_ARG, "fvk_attn_tile_lists_bf16: null index arrays");
+    FVK_CHECK(rows_per_list >= 256 && rows_per_list % 128 == 0, FVK_ERR_ARG,
+              "fvk_attn_tile_lists_bf16: rows_per_list=%d must be a multiple of 128, >= 256 (128-row lists: fvk_attn_block_sparse_bf16)", rows_per_list);
+    FVK_CHECK(a->Sq % rows_per_list == 0 && a->Skv % 64 == 0, FVK_ERR_ARG,
+              "fvk_attn_tile_lists_bf16: Sq=%d must be a multiple of rows_per_list=%d and Skv=%d of the 64-token KV block", a->Sq, rows_per_list, a->Skv);
+    FVK_CHECK(a->qk_dim == 0 || a->qk_dim == 128, FVK_ERR_ARG, "fvk_attn_tile_lists_bf16: qk_dim=%d unsupported", a->qk_dim);
+    const int n_lists = a->Sq / rows_per_list;
+    // 256-row workgroups on the ping-pong schedule; a 128-row remainder per list (384-token sliding tiles) on the 4-wave kernel
+    fvk_pp2_lists la{q2k_idx, q2k_num, kv_block_sizes, q_rows_valid, max_kv, n_lists, rows_per_list, rows_per_list / 256};
+    rc = fvk_attn_pp2_lists_launch(a, &la, (hipStream_t)stream);
+    if (rc || rows_per_list % 256 == 0) return rc;
+    ModeArgs ma{};
+    ma.q2k_idx = q2k_idx;
+    ma.q2k_num = q2k_num;
+    ma.kv_block_sizes = kv_block_sizes;
+    ma.max_kv = max_kv;
+    ma.q_rows_valid = q_rows_valid;
+    ma.q_stride = rows_per_list;
+    ma.q_offset = rows_per_list - 128;
+    ma.n_lists = n_lists;
+    return launch<4, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
 }
 
 extern "C" int fvk_attn_sta_bf16(const fvk_attn_args* a, int ct, int ch, int cw, int tile_tokens, const int32_t* win_host,

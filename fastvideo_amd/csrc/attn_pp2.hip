@@ -26,6 +26,15 @@ constexpr int RING = 2;
 constexpr int V_BASE = RING * K_TILE;
 constexpr int LDS_BYTES = RING * (K_TILE + V_TILE);  // 131 072
 
+}  // namespace
+// LIST mode (fvk_attn_tile_lists_bf16, attn_fwd.hip): every `q_stride` consecutive query rows share ONE list of 64-key KV blocks (the
+// sliding-tile window of their tile); a workgroup owns 256 of those rows and walks the list two blocks (= one 128-key tile) per step.
+struct fvk_pp2_lists {
+    const int32_t* q2k_idx; const int32_t* q2k_num; const int32_t* kv_block_sizes; const int32_t* q_rows_valid;
+    int max_kv, n_lists, q_stride, q_sub;  // q_sub = 256-row workgroups per list
+};
+namespace {
+
 __device__ __forceinline__ float xhalf_max(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -51,10 +60,15 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 // free as soon as the barrier closing step j is passed (both groups' M(j) are behind it), which is exactly where the leading group's next
 // matrix segment starts; the pieces ride in that segment's MFMA gaps (LSTREAM) or precede it, and are waited for before the leading
 // group's next barrier, ~4 000 cycles later, by which time they have long landed (the trailing group used to wait 200-400 cycles there).
-template <bool PROBE, bool PRIO, bool VSTREAM = true, bool ONEBAR = false, bool LDMA = false, bool LSTREAM = false>
-__global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
+// LIST: the KV tiles come from a per-workgroup list of 64-key blocks (two per 128-key tile step, each with its own valid-key count) instead of
+// 0 .. Skv/128: K pieces add their block's row offset, V^T pieces select the block per lane (a piece row spans both halves), the softmax
+// masks each half by its block size.  The list lives in LDS (packed per tile: id | size << 24 for both halves) and is read one step
+// ahead.  Workgroup ids are dealt so that each XCD (private L2) owns a contiguous run of lists: neighbouring tiles' windows overlap.
+template <bool PROBE, bool PRIO, bool VSTREAM = true, bool ONEBAR = false, bool LDMA = false, bool LSTREAM = false, bool LIST = false>
+__global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a, fvk_pp2_lists la) {
     static_assert(!(VSTREAM && ONEBAR), "in-stream V^T pieces rely on the second barrier");
     static_assert(!LDMA || ONEBAR, "leading-group DMA is a one-barrier schedule");
+    static_assert(!LIST || (LDMA && LSTREAM && !PROBE), "block lists ride on the shipped schedule only");
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
@@ -64,19 +78,47 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int nqb = (a.Sq + BMQ - 1) / BMQ;
-    const int qb = blockIdx.x % nqb;
-    const int h = (blockIdx.x / nqb) % a.H;
-    const int b = blockIdx.x / (nqb * a.H);
+    int n;            // KV tiles of this workgroup
+    int q_first, h, b;
+    int lst_num = 0;  // LIST: 64-key blocks in this workgroup's list
+    int32_t* const lst = reinterpret_cast<int32_t*>(smem + LDS_BYTES);  // LIST: [tile][2] packed entries
+    if (LIST) {
+        // XCD-aware deal: hardware workgroup id x lands on XCD x % 8; XCD c gets the contiguous logical ids [c*q + min(c,r), ...)
+        const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+        const int bid = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+        const int per_head = la.n_lists * la.q_sub;
+        const int u = bid % per_head, sub = u % la.q_sub, li = u / la.q_sub;
+        h = (bid / per_head) % a.H;
+        b = bid / (per_head * a.H);
+        q_first = li * la.q_stride + sub * BMQ;
+        const long meta = ((long)b * a.H + h) * la.n_lists + li;
+        lst_num = la.q2k_num[meta];
+        if (la.q_rows_valid && sub * BMQ >= la.q_rows_valid[li]) lst_num = 0;  // only padding rows: nothing to do
+        n = (lst_num + 1) >> 1;
+        const int32_t* src = la.q2k_idx + meta * la.max_kv;
+        for (int t = tid; t < n; t += 512) {
+            const int id0 = src[2 * t];
+            const bool two = 2 * t + 1 < lst_num;
+            const int id1 = two ? src[2 * t + 1] : id0;  // an absent second half re-reads the first block, fully masked
+            lst[2 * t] = id0 | (la.kv_block_sizes[id0] << 24);
+            lst[2 * t + 1] = id1 | ((two ? la.kv_block_sizes[id1] : 0) << 24);
+        }
+        __syncthreads();
+    } else {
+        const int nqb = (a.Sq + BMQ - 1) / BMQ;
+        q_first = (blockIdx.x % nqb) * BMQ;
+        h = (blockIdx.x / nqb) % a.H;
+        b = blockIdx.x / (nqb * a.H);
+        n = (a.Skv + KT - 1) / KT;
+    }
 
     const bf16_t* qp = (const bf16_t*)a.q + (long)b * a.q_bs + (long)h * a.q_hs;
     const bf16_t* kp = (const bf16_t*)a.k + (long)b * a.k_bs + (long)h * a.k_hs;
     const bf16_t* vtp = (const bf16_t*)a.vt + ((long)b * a.H + h) * 128L * a.Skv_pad;
     bf16_t* op = (bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs;
-    const int n = (a.Skv + KT - 1) / KT;  // KV tiles
 
     // ---- Q fragments (B operand of S^T = K·Q^T): row q0 + l31, d = 16*ks + 8*hi .. +8 ------------------------------------
-    const int q0 = qb * BMQ + wave * 32;
+    const int q0 = q_first + wave * 32;
     int qrow = q0 + l31;
     const bool q_ok = qrow < a.Sq;
     qrow = q_ok ? qrow : a.Sq - 1;
@@ -100,11 +142,34 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
     const unsigned k_pstride = (unsigned)(16 * a.k_ss * 2), v_pstride = (unsigned)(16 * a.Skv_pad * 2);  // 16 rows between a wave's pieces
     const unsigned k_tile_bytes = (unsigned)(a.k_ss * 2 * KT);  // bytes between consecutive key tiles
     const int pdst = wq * 1024;                                 // + ring slot, + i*4096
+    // LIST: a 256-B V^T piece row holds 64 keys of block A (source chunks 0-7) and 64 of block B (8-15): this lane's source chunk
+    // picks the block, (chunk & 7) the 16 B inside it
+    const unsigned csrc = (unsigned)((lane & 15) ^ (r0 & 15));
+    const bool vhalf = csrc >= 8;
+    const unsigned vvl = (unsigned)(r0 * a.Skv_pad * 2) + ((csrc & 7) << 4);
+    const unsigned k_blk_bytes = (unsigned)(a.k_ss * 2 * 64);  // bytes between consecutive 64-key blocks
+    // list entries: eA = tile j (its V^T pieces, its softmax mask), eB = tile j+1 (its K pieces), pre = tile j+2 (read one step ahead)
+    int eA0 = 0, eA1 = 0, eB0 = 0, eB1 = 0, pre0 = 0, pre1 = 0;
+    unsigned kB0 = 0, kB1 = 0, vsel = 0;
+#define LIST_LOAD(T, D0, D1) { const int t_ = (T) < n ? (T) : 0; D0 = lst[2 * t_]; D1 = lst[2 * t_ + 1]; }
+#define LIST_DERIVE()                                                                                                \
+    {                                                                                                                \
+        kB0 = (unsigned)(eB0 & 0xffffff) * k_blk_bytes;                                                              \
+        kB1 = (unsigned)(eB1 & 0xffffff) * k_blk_bytes;                                                              \
+        vsel = (unsigned)((vhalf ? eA1 : eA0) & 0xffffff) * 128u;                                                    \
+    }
 
     // piece I (0..7 = K(T+1), 8..15 = V^T(T)) of the set that tile step T makes room for; tiles past the end re-read tile 0 (harmless)
 #define ISSUE_PIECE(T, I)                                                                                            \
     {                                                                                                                \
-        if ((I) < 8) {                                                                                               \
+        if (LIST) {                                                                                                  \
+            if ((I) < 8)                                                                                             \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + (((T) + 1) & 1) * K_TILE + pdst + (I) * 4096), 16, \
+                                                         kv0 + ((I) & 3) * k_pstride + ((I) < 4 ? kB0 : kB1), 0, 0, 0); \
+            else                                                                                                     \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + ((T) & 1) * V_TILE + pdst + ((I) - 8) * 4096), 16, \
+                                                         vvl + ((I) - 8) * v_pstride + vsel, 0, 0, 0);              \
+        } else if ((I) < 8) {                                                                                        \
             const int t_ = (T) + 1 < n ? (T) + 1 : 0;                                                                \
             __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + (((T) + 1) & 1) * K_TILE + pdst + (I) * 4096), 16, \
                                                      kv0 + (I) * k_pstride + (unsigned)t_ * k_tile_bytes, 0, 0, 0);  \
@@ -162,7 +227,16 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
     // online softmax of tile J (row q = lane&31; this lane holds 64 of its 128 scores, lane^32 the other 64)
 #define SOFTMAX(J)                                                                                                   \
     {                                                                                                                \
-        const int valid_ = a.Skv - (J) * KT;                                                                         \
+        if (LIST) {                                                                                                  \
+            const int v0_ = eA0 >> 24, v1_ = eA1 >> 24; /* valid keys of the two 64-key blocks of this tile */          \
+            if (v0_ < 64 || v1_ < 64) {                                                                              \
+                _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) {   \
+                    const int key = (kb & 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;                                 \
+                    if (key >= (kb < 2 ? v0_ : v1_)) s[kb][r] = -INFINITY;                                           \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+        const int valid_ = LIST ? KT : a.Skv - (J) * KT;                                                             \
         if (valid_ < KT) {                                                                                           \
             _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) {       \
                 const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;                                           \
@@ -219,14 +293,25 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
         last_ = now_;                                                                                                \
         if (j == 100) abs_[K] = now_;                                                                                \
     }
+    if (!LIST || n > 0) {  // an empty list (LIST only; workgroup-uniform): straight to the epilogue, which writes zeros
     if (LDMA) {
         // ---- leading-group DMA, one barrier per tile step --------------------------------------------------------------------------
         // leading : [set j in flight] M(j) . softmax(j) . wait(set j) . BARRIER(j) . issue set j+1 ...
         // trailing:                   ... softmax(j-1) . M(j) . BARRIER(j) . softmax(j) . M(j+1) ...
+        if (LIST) {
+            LIST_LOAD(0, eA0, eA1)
+            LIST_LOAD(1, eB0, eB1)
+            LIST_LOAD(2, pre0, pre1)
+            eA0 = __builtin_amdgcn_readfirstlane(eA0); eA1 = __builtin_amdgcn_readfirstlane(eA1);
+            eB0 = __builtin_amdgcn_readfirstlane(eB0); eB1 = __builtin_amdgcn_readfirstlane(eB1);
+            LIST_DERIVE()
+        }
         if (grp == 0) {
+            const unsigned k00 = LIST ? (unsigned)(eA0 & 0xffffff) * k_blk_bytes : 0u, k01 = LIST ? (unsigned)(eA1 & 0xffffff) * k_blk_bytes : 4u * k_pstride;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + pdst + i * 4096), 16, kv0 + i * k_pstride, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + pdst + i * 4096), 16,
+                                                         kv0 + (i & 3) * k_pstride + (i < 4 ? k00 : k01), 0, 0, 0);
             ISSUE_SET(0)
             asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // K(0) landed; set 0 = {K(1), V(0)} flies
         }
@@ -247,6 +332,12 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
         }
         for (int j = 1; j < n; ++j) {
             STAMP(0)
+            if (LIST) {  // advance the list window: tile j -> eA, tile j+1 -> eB (read from LDS a step ago), tile j+2 -> in flight
+                eA0 = eB0; eA1 = eB1;
+                eB0 = __builtin_amdgcn_readfirstlane(pre0); eB1 = __builtin_amdgcn_readfirstlane(pre1);
+                LIST_LOAD(j + 2, pre0, pre1)
+                LIST_DERIVE()
+            }
             if (grp == 0 && !LSTREAM) ISSUE_SET(j)  // slots free: both groups' M(j-1) are behind barrier(j-1)
             STAMP(1)
             if (PRIO) __builtin_amdgcn_s_setprio(1);
@@ -317,6 +408,9 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
     if (PRIO) __builtin_amdgcn_s_setprio(0);
     WAIT_ALL()           // drain the tail re-reads before this workgroup's LDS can be re-assigned
     if (!ONEBAR && grp == 0) BAR()  // matches the extra leading barrier of waves 4-7 (ONEBAR: every barrier is already paired)
+    }  // n > 0
+#undef LIST_LOAD
+#undef LIST_DERIVE
 #undef ISSUE_PIECE
 #undef ISSUE_SET
 #undef ISSUE_K
@@ -349,6 +443,23 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a) {
 
 }  // namespace
 
+// 256-row workgroups over shared KV block lists (called by fvk_attn_tile_lists_bf16, attn_fwd.hip, after its argument checks)
+int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s) {
+    constexpr int LDS_LIST = LDS_BYTES + 2048 * 8;  // + the packed list: up to 2048 tiles = 4096 blocks
+    FVK_CHECK(la->max_kv <= 4096, FVK_ERR_ARG, "fvk_attn_tile_lists_bf16: lists of more than 4096 blocks (max_kv=%d) do not fit the LDS copy", la->max_kv);
+    static bool configured[FVK_MAX_DEVICES] = {};
+    if (fvk_needs_lds_config(configured)) {
+        if (hipFuncSetAttribute((const void*)attn_pp2_kernel<false, true, false, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIST) != hipSuccess) {
+            fvk_set_error("fvk_attn_tile_lists_bf16: cannot set dynamic LDS size");
+            return FVK_ERR_LAUNCH;
+        }
+    }
+    const long nblk = (long)la->n_lists * la->q_sub * a->H * a->B;
+    hipLaunchKernelGGL((attn_pp2_kernel<false, true, false, true, true, true, true>), dim3((unsigned)nblk), dim3(512), LDS_LIST, s, *a, *la);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
 template <bool PROBE, bool PRIO, bool VSTREAM = true, bool ONEBAR = false, bool LDMA = false, bool LSTREAM = false>
 static int launch_pp2(const fvk_attn_args* a, hipStream_t s) {
     static bool configured[FVK_MAX_DEVICES] = {};
@@ -359,7 +470,7 @@ static int launch_pp2(const fvk_attn_args* a, hipStream_t s) {
         }
     }
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
-    hipLaunchKernelGGL((attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a);
+    hipLaunchKernelGGL((attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a, fvk_pp2_lists{});
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }

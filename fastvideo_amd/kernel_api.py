@@ -213,7 +213,10 @@ def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3)):
     the tiles in the window — empty blocks dropped, partially filled ones carried with their size.
     Returns a dict of CPU tensors: tile_partition_indices / non_pad_index / untile_combined_index (as build_vsa_metadata),
     block_sizes int32 [n_blocks64], q2k_idx int32 [n_qblocks, max_kv] (ascending), q2k_num int32 [n_qblocks], q_block (64 or 128 query
-    rows per list), S_pad, num_tiles."""
+    rows per list), S_pad, num_tiles; and the per-TILE form of the same lists for ``ops.attn_tile_lists`` (tiles of >= 256 tokens):
+    tile_q2k_idx int32 [n_tiles, max_kv], tile_q2k_num int32 [n_tiles], tile_rows_valid int32 [n_tiles], tile_tokens; and the
+    query-grouped form (see below): group_src / group_dst / group_untile int32 [S], group_rows, group_q2k_idx int32 [n_groups, max_kv],
+    group_q2k_num int32 [n_groups], n_window_classes."""
     import numpy as np
     tok = tile_size[0] * tile_size[1] * tile_size[2]
     if tok % 64:
@@ -229,7 +232,7 @@ def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3)):
         c = min(max(q, k // 2), (n - 1) - k // 2)
         return range(max(c - k // 2, 0), min(c + k // 2 + 1, n))
 
-    lists = []
+    lists, tile_lists, tile_class = [], [], []
     for a in range(nt[0]):
         for b in range(nt[1]):
             for c in range(nt[2]):
@@ -241,13 +244,52 @@ def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3)):
                 q_tile = (a * nt[1] + b) * nt[2] + c
                 real = int(vbs[q_tile])
                 lists += [blocks if real > i * qb else [] for i in range(tok // qb)]
+                tile_lists.append(blocks)
+                tile_class.append(tuple(tiles))
     mx = max(len(l) for l in lists)
     idx = np.zeros((len(lists), mx), dtype=np.int32)
     num = np.zeros((len(lists),), dtype=np.int32)
     for i, l in enumerate(lists):
         idx[i, :len(l)], num[i] = l, len(l)
+    # the same lists once per TILE (all of a tile's query rows share them) for fvk_attn_tile_lists_bf16, which runs 256 of a tile's rows per
+    # workgroup: tile_rows_valid = real tokens of the tile (its row groups that start past it are skipped)
+    t_idx = np.zeros((len(tile_lists), mx), dtype=np.int32)
+    t_num = np.zeros((len(tile_lists),), dtype=np.int32)
+    for i, l in enumerate(tile_lists):
+        t_idx[i, :len(l)], t_num[i] = l, len(l)
+    # QUERY rows grouped by window class: the clamped-centre rule gives many tiles the SAME window (edge tiles share their neighbour's:
+    # 20 distinct windows for the 112 tiles of 21x30x52), and a query's output depends only on its KV set — so the real query tokens of
+    # all tiles of a class are packed back to back (no per-tile padding) and cut into 256-row groups that share the class's list.  K / V
+    # keep the tile-major layout.  group_src[i] = source token of the i-th packed row, group_dst[i] = its row, group_untile[t] = row of
+    # token t, group_rows = padded row count (a multiple of 256), group_q2k_idx / _num = one list per 256-row group.
+    tile_off = np.concatenate([[0], np.cumsum(vbs)]).astype(np.int64)
+    perm = h["tile_partition_indices"].numpy()
+    classes = {}
+    for t, key in enumerate(tile_class):
+        classes.setdefault(key, []).append(t)
+    g_src, g_dst, g_lists, row0 = [], [], [], 0
+    for key, tiles_c in classes.items():
+        toks = np.concatenate([perm[tile_off[t]:tile_off[t + 1]] for t in tiles_c])
+        if len(toks) == 0:
+            continue
+        n256 = -(-len(toks) // 256)
+        g_src.append(toks)
+        g_dst.append(row0 + np.arange(len(toks)))
+        g_lists += [tile_lists[tiles_c[0]]] * n256
+        row0 += n256 * 256
+    g_src, g_dst = np.concatenate(g_src).astype(np.int32), np.concatenate(g_dst).astype(np.int32)
+    g_untile = np.empty(len(g_src), dtype=np.int32)
+    g_untile[g_src] = g_dst
+    gmx = max(len(l) for l in g_lists)
+    g_idx = np.zeros((len(g_lists), gmx), dtype=np.int32)
+    g_num = np.zeros((len(g_lists),), dtype=np.int32)
+    for i, l in enumerate(g_lists):
+        g_idx[i, :len(l)], g_num[i] = l, len(l)
     n_tok = grid[0] * grid[1] * grid[2]
-    return dict(tile_partition_indices=h["tile_partition_indices"], non_pad_index=h["non_pad_index"],
+    return dict(group_src=torch.from_numpy(g_src), group_dst=torch.from_numpy(g_dst), group_untile=torch.from_numpy(g_untile), group_rows=row0,
+                group_q2k_idx=torch.from_numpy(g_idx), group_q2k_num=torch.from_numpy(g_num), n_window_classes=len(classes),
+                tile_q2k_idx=torch.from_numpy(t_idx), tile_q2k_num=torch.from_numpy(t_num),
+                tile_rows_valid=torch.from_numpy(vbs.astype(np.int32)), tile_tokens=tok, tile_partition_indices=h["tile_partition_indices"], non_pad_index=h["non_pad_index"],
                 untile_combined_index=h["untile_combined_index"], block_sizes=torch.from_numpy(bsz), q2k_idx=torch.from_numpy(idx),
                 q2k_num=torch.from_numpy(num), q_block=qb, S_pad=len(vbs) * tok, num_tiles=nt,
                 density=float(sum(int(bsz[i * (qb // 64):(i + 1) * (qb // 64)].sum()) * sum(int(bsz[b]) for b in l)

@@ -295,6 +295,24 @@ def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, lay
     return (o, lse) if return_lse else o
 
 
+def attn_tile_lists(q, k, v, q2k_idx, q2k_num, kv_block_sizes, rows_per_list, q_rows_valid=None, scale=None, layout="bhsd"):
+    """Block-sparse attention with one KV block list per ``rows_per_list`` consecutive query rows (fvk_attn_tile_lists_bf16): sliding-tile
+    windows in tile-major order.  q2k_idx int32 [B,H,Nl,max_kv], q2k_num int32 [B,H,Nl], kv_block_sizes int32 [Nkv],
+    q_rows_valid int32 [Nl] or None."""
+    scale = q.shape[-1]**-0.5 if scale is None else scale
+    vt = _vt_of(v, layout)
+    o = torch.empty_like(q)
+    a = _attn_args(q, k, vt, o, scale, layout)
+    q2k_idx = _chk(q2k_idx, torch.int32, "q2k_idx").contiguous()
+    q2k_num = _chk(q2k_num, torch.int32, "q2k_num").contiguous()
+    kv_block_sizes = _chk(kv_block_sizes, torch.int32, "kv_block_sizes").contiguous()
+    if q_rows_valid is not None:
+        q_rows_valid = _chk(q_rows_valid, torch.int32, "q_rows_valid").contiguous()
+    _lib.call("fvk_attn_tile_lists_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), q2k_idx.shape[-1], int(rows_per_list),
+              _p(q_rows_valid) if q_rows_valid is not None else None, _stream())
+    return o
+
+
 def attn_sta(q, k, v, canvas_tiles, tile_tokens, windows, scale=None, layout="bhsd"):
     """windows: list of (t,h,w) per head, in tiles."""
     scale = q.shape[-1]**-0.5 if scale is None else scale

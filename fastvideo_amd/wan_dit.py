@@ -61,6 +61,9 @@ class WanTransformer3DModelHip:
         self.num_layers = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
         self._load(state_dict)
         self._vsa_cache = {}
+        # sliding-tile list form: "grouped" (shipped) = queries packed by window class on 256-row workgroups; "tile" = one list per 384-token
+        # tile (256-row workgroups + a 128-row remainder); "block128" = one list per 128-row query block on the 4-wave kernel (A/B, tests)
+        self.sta_lists = "grouped"
         self.attn_events = None  # set to a list to collect (start, end, Sq, Skv, heads) HIP-event pairs
         self.vsa_trace = None    # set to a list to collect every layer's VSA block mask (tests)
 
@@ -154,7 +157,13 @@ class WanTransformer3DModelHip:
                      untile=h["untile_combined_index"].to(dev), block_sizes=h["block_sizes"].to(dev),
                      q2k_idx=h["q2k_idx"].to(dev)[None, None].expand(1, n_heads, -1, -1).contiguous(),
                      q2k_num=h["q2k_num"].to(dev)[None, None].expand(1, n_heads, -1).contiguous(),
-                     q_block=h["q_block"], density=h["density"])
+                     q_block=h["q_block"], density=h["density"], tile_tokens=h["tile_tokens"],
+                     tile_q2k_idx=h["tile_q2k_idx"].to(dev)[None, None].expand(1, n_heads, -1, -1).contiguous(),
+                     tile_q2k_num=h["tile_q2k_num"].to(dev)[None, None].expand(1, n_heads, -1).contiguous(),
+                     tile_rows_valid=h["tile_rows_valid"].to(dev), group_rows=h["group_rows"],
+                     group_src=h["group_src"].to(dev), group_dst=h["group_dst"].to(dev), group_untile=h["group_untile"].to(dev),
+                     group_q2k_idx=h["group_q2k_idx"].to(dev)[None, None].expand(1, n_heads, -1, -1).contiguous(),
+                     group_q2k_num=h["group_q2k_num"].to(dev)[None, None].expand(1, n_heads, -1).contiguous())
             self._vsa_cache[("sta",) + key] = m
         return m
 
@@ -222,8 +231,24 @@ class WanTransformer3DModelHip:
         S = kv_len
         bufs = self._tile_bufs(m["S_pad"], q.shape[1], 3, grid, "sta")
         tile = lambda t, j: ops.gather_rows(t[:, :S], m["S_pad"], m["perm"], m["non_pad"], out=bufs[j])  # [1,S_pad,h,D]
-        o = ops.attn_block_sparse(tile(q4, 0), tile(k4, 1), tile(v4, 2), m["q2k_idx"], m["q2k_num"], m["block_sizes"], scale=self.D**-0.5,
-                                  layout="bshd", q_block=m["q_block"])
+        if self.sta_lists == "grouped":
+            # queries packed by WINDOW CLASS (tiles whose clamped windows coincide share one KV list): no per-tile query padding, every
+            # query row on a 256-row workgroup of the dense kernel's schedule; K / V stay tile-major
+            qg = self._tile_bufs(m["group_rows"], q.shape[1], 1, grid, "sta_q")[0]
+            ops.gather_rows(q4[:, :S], m["group_rows"], m["group_src"], m["group_dst"], out=qg)
+            o = ops.attn_tile_lists(qg, tile(k4, 1), tile(v4, 2), m["group_q2k_idx"], m["group_q2k_num"], m["block_sizes"], 256, None,
+                                    scale=self.D**-0.5, layout="bshd")
+            o = ops.gather_rows(o, S, m["group_untile"], None)
+            if q.shape[0] != S:
+                o = torch.cat([o, o.new_zeros((1, q.shape[0] - S, *o.shape[2:]))], 1)
+            return o[0]
+        if m["tile_tokens"] >= 256 and m["tile_tokens"] % 128 == 0 and self.sta_lists == "tile":
+            # one list per tile: 256 of a tile's query rows share a workgroup on the dense kernel's schedule (fvk_attn_tile_lists_bf16)
+            o = ops.attn_tile_lists(tile(q4, 0), tile(k4, 1), tile(v4, 2), m["tile_q2k_idx"], m["tile_q2k_num"], m["block_sizes"],
+                                    m["tile_tokens"], m["tile_rows_valid"], scale=self.D**-0.5, layout="bshd")
+        else:
+            o = ops.attn_block_sparse(tile(q4, 0), tile(k4, 1), tile(v4, 2), m["q2k_idx"], m["q2k_num"], m["block_sizes"], scale=self.D**-0.5,
+                                      layout="bshd", q_block=m["q_block"])
         o = ops.gather_rows(o, S, m["untile"], None)
         if q.shape[0] != S:
             o = torch.cat([o, o.new_zeros((1, q.shape[0] - S, *o.shape[2:]))], 1)

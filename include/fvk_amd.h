@@ -159,6 +159,21 @@ int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream);
 int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
                                const int32_t* kv_block_sizes, int max_kv, int q_block, void* stream);
 
+/* block-sparse with SHARED lists — sliding-tile attention on arbitrary canvases: every rows_per_list consecutive query rows (one
+ * sliding tile in tile-major order, 384 tokens for the reference's (6,8,8) tile) attend the same KV blocks, list i =
+ * q2k_idx[b,h,i,0..q2k_num[b,h,i]) of 64-key blocks with kv_block_sizes valid keys each, exactly as above.  Same result as
+ * fvk_attn_block_sparse_bf16 with the list repeated per 128-row block (tests/test_gpu_kernels.py), but 256 of a list's rows share one
+ * workgroup on the dense kernel's ping-pong schedule (128-key steps = two listed blocks, each half masked by its own size); a 128-row
+ * remainder (384 = 256 + 128) runs on the 4-wave kernel.
+ * ref: fastvideo_kernel.sliding_tile_attention (fastvideo-kernel/python/fastvideo_kernel/ops.py:21-62), mask rule
+ *      fastvideo-kernel/tests/support_flex_sta.py:29-59, kernels st_attn_triton.py:19-121 / csrc/attention/st_attn_h100.cu.
+ * q2k_idx int32 [B,H,Nl,max_kv], q2k_num int32 [B,H,Nl], Nl = Sq / rows_per_list; rows_per_list a multiple of 128, >= 256; max_kv <= 4096.
+ * q_rows_valid (optional, int32 [Nl]): real query rows at the head of each list's rows — 256- / 128-row groups that start at or past it
+ * hold only padding and are written as zeros without touching K / V. */
+int fvk_attn_tile_lists_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
+                             const int32_t* kv_block_sizes, int max_kv, int rows_per_list, const int32_t* q_rows_valid,
+                             void* stream);
+
 /* sliding-tile attention: tokens in tile-major order, tile = tile_t*tile_h*tile_w tokens (multiple of 64),
  * canvas of (ct,ch,cw) tiles; head h uses window (win[3h], win[3h+1], win[3h+2]) tiles with the clamped
  * centre rule of ref: fastvideo-kernel/tests/support_flex_sta.py:29-59 ≡ st_attn_triton.py:158-176:

@@ -61,13 +61,17 @@ def test_dense_attention_full_size(ops):
     assert d_.max().item() < 2e-2 and d_.mean().item() < 1e-3
 
 
-def test_sliding_tile_attention_full_grid(ops):
-    """BASELINE config 3 geometry: grid (21,30,52), tile (6,8,8), window (3,3,3) through the model's STA path vs the masked fp32 form."""
+@pytest.mark.parametrize("lists", ["grouped", "tile", "block128"])
+def test_sliding_tile_attention_full_grid(ops, lists):
+    """BASELINE config 3 geometry: grid (21,30,52), tile (6,8,8), window (3,3,3) through the model's STA path vs the masked fp32 form —
+    queries packed by window class on 256-row workgroups (shipped), one KV list per tile (fvk_attn_tile_lists_bf16 with a 128-row
+    remainder) and one list per 128-row block on the 4-wave kernel."""
     from fastvideo_amd.wan_dit import WanTransformer3DModelHip
     from oracle import vsa_oracle as V
     grid, tile, win = (21, 30, 52), (6, 8, 8), (3, 3, 3)
     m = WanTransformer3DModelHip.__new__(WanTransformer3DModelHip)   # only the attention plumbing is exercised
     m.attention, m.sta_tile, m.sta_window, m.D, m.device, m._vsa_cache, m.attn_events = "sta", tile, win, D, torch.device("cuda"), {}, None
+    m.sta_lists = lists
     g = torch.Generator(device="cuda").manual_seed(2)
     q, k, v = (torch.randn((S, H, D), generator=g, device="cuda").bfloat16() for _ in range(3))
     o = m._attn_local(q, k, v, S, grid)

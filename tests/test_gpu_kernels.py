@@ -237,6 +237,58 @@ def test_attn_block_sparse(ops):
     assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("rows", [256, 384, 512])
+def test_attn_tile_lists_shared_kv_lists(ops, rows):
+    """fvk_attn_tile_lists_bf16: every `rows` consecutive query rows share one list of 64-key blocks (sliding-tile windows).  Against the
+    block-sparse oracle with the tile's list repeated for each of its 64-row query blocks — lists of odd and even length, in arbitrary
+    order, with partially filled and EMPTY (size 0) blocks, an empty list, and row groups skipped through q_rows_valid — and against
+    fvk_attn_block_sparse_bf16 (one list per 128 rows) on the same lists."""
+    B, H, nl, nk = 1, 2, 4, 11
+    q, k, v = rnd((B, H, nl * rows, 128), 1), rnd((B, H, nk * 64, 128), 2), rnd((B, H, nk * 64, 128), 3)
+    rng = np.random.default_rng(rows)
+    bm = rng.random((B, H, nl, nk)) < 0.55
+    bm[..., 0] = True
+    bm[0, 1, 2, :] = False                       # an empty list: zeros
+    bm[0, 0, 1, :] = False
+    bm[0, 0, 1, [2, 5, 9]] = True                # an odd-length list (the last 128-key step has one real half)
+    vbs = np.array([64, 64, 48, 64, 1, 33, 24, 64, 0, 64, 17], dtype=np.int32)
+    idx, num = V.map_to_index(bm)
+    for b_, h_, l_ in ((0, 0, 0), (0, 1, 3)):    # list order is free: shuffle two of them
+        n_ = int(num[b_, h_, l_])
+        idx[b_, h_, l_, :n_] = rng.permutation(idx[b_, h_, l_, :n_])
+    rep = rows // 64
+    ref = torch.nan_to_num(V.block_sparse_attn(q, k, v, np.repeat(bm, rep, axis=2), vbs), nan=0.0)  # empty lists: zeros by contract
+    valid = np.array([rows, 100, rows, 300 if rows > 256 else 256], dtype=np.int32)  # real query rows per list
+    dv = lambda t: torch.from_numpy(t).to(DEV)
+    out = ops.attn_tile_lists(q.to(DEV), k.to(DEV), v.to(DEV), dv(idx), dv(num), dv(vbs), rows, dv(valid), layout="bhsd").cpu()
+    groups = [(0, 256)] * (rows >= 256) + [(256, 512)] * (rows >= 512) + [(rows - 128, rows)] * (rows % 256 == 128)
+    for l_ in range(nl):
+        for r0, r1 in groups:
+            sl = slice(l_ * rows + r0, l_ * rows + r1)
+            if r0 >= valid[l_]:
+                assert (out[:, :, sl] == 0).all(), f"list {l_} rows {r0}..{r1}: skipped group must be zeros"
+            else:
+                _attn_check(out[:, :, sl], ref[:, :, sl], f"tile lists rows_per_list={rows} list {l_} rows {r0}..{r1}")
+    assert (out[0, 1, 2 * rows:3 * rows] == 0).all()  # the empty list
+    # the same lists, one per 128-row block, through the 4-wave kernel
+    o128 = ops.attn_block_sparse(q.to(DEV), k.to(DEV), v.to(DEV), dv(np.repeat(idx, rows // 128, axis=2)), dv(np.repeat(num, rows // 128, axis=2)),
+                                 dv(vbs), layout="bhsd", q_block=128).cpu()
+    full = ops.attn_tile_lists(q.to(DEV), k.to(DEV), v.to(DEV), dv(idx), dv(num), dv(vbs), rows, None, layout="bhsd").cpu()
+    err = (full.float() - o128.float()).abs()
+    assert err.max().item() < 4e-2 and err.mean().item() < 2e-3, (err.max().item(), err.mean().item())
+
+
+def test_attn_tile_lists_refuses_bad_geometry(ops):
+    q, k, v = rnd((1, 1, 768, 128), 1).to(DEV), rnd((1, 1, 256, 128), 2).to(DEV), rnd((1, 1, 256, 128), 3).to(DEV)
+    idx, num, vbs = torch.zeros((1, 1, 2, 4), dtype=torch.int32, device=DEV), torch.ones((1, 1, 2), dtype=torch.int32, device=DEV), \
+        torch.full((4,), 64, dtype=torch.int32, device=DEV)
+    for rows in (128, 320):  # 128-row lists belong to fvk_attn_block_sparse_bf16; 320 is not a multiple of 128
+        with pytest.raises(RuntimeError, match="rows_per_list"):
+            ops.attn_tile_lists(q, k, v, idx, num, vbs, rows, None, layout="bhsd")
+    with pytest.raises(RuntimeError, match="multiple of rows_per_list"):
+        ops.attn_tile_lists(q, k, v, idx, num, vbs, 512, None, layout="bhsd")
+
+
 @pytest.mark.parametrize("canvas,tile,win", [((4, 8, 16), (2, 8, 8), [(1, 1, 1), (3, 1, 3)]),
                                              ((12, 16, 24), (6, 8, 8), [(3, 3, 3), (1, 3, 1), (3, 1, 5)])])
 def test_attn_sta(ops, canvas, tile, win):

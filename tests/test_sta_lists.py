@@ -48,4 +48,21 @@ def test_block_lists_expand_to_the_oracle_mask(grid, tile, window):
             lo, hi = w[coord[rows, ax], 0], w[coord[rows, ax], 1]
             ref &= (coord[None, :, ax] >= lo[:, None]) & (coord[None, :, ax] < hi[:, None])
     assert np.array_equal(got, ref)
+    # the per-TILE form (fvk_attn_tile_lists_bf16, one list per tile) and the query-GROUPED form (queries packed by window class, one list
+    # per 256 packed rows) must expand to the same mask
+    tok = m["tile_tokens"]
+    t_idx, t_num, t_val = m["tile_q2k_idx"].numpy(), m["tile_q2k_num"].numpy(), m["tile_rows_valid"].numpy()
+    assert len(t_num) == m["S_pad"] // tok and (t_val == real.reshape(len(t_num), -1).sum(1)).all()
+    g_src, g_dst, g_unt = m["group_src"].numpy(), m["group_dst"].numpy(), m["group_untile"].numpy()
+    g_idx, g_num = m["group_q2k_idx"].numpy(), m["group_q2k_num"].numpy()
+    assert sorted(g_src.tolist()) == list(range(S)) and len(set(g_dst.tolist())) == S and g_dst.max() < m["group_rows"]
+    assert m["group_rows"] == 256 * len(g_num) and (g_unt[g_src] == g_dst).all()
+    assert m["group_rows"] - S < 256 * m["n_window_classes"]  # less than one 256-row group of padding per window class
+    for form in ("tile", "grouped"):
+        got2 = np.zeros((len(rows), S), dtype=bool)
+        for i, r in enumerate(rows):
+            lst = t_idx[pos_of_raster[r] // tok, :t_num[pos_of_raster[r] // tok]] if form == "tile" else g_idx[g_unt[r] // 256, :g_num[g_unt[r] // 256]]
+            for b in lst:
+                got2[i, raster_of_pos[b * 64:b * 64 + bsz[b]]] = True
+        assert np.array_equal(got2, ref), form
     assert abs(m["density"] - (got.mean() if len(rows) == S else m["density"])) < 1e-9 and 0 < m["density"] <= 1
