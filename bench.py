@@ -379,7 +379,10 @@ def main():
         else:
             dens = next(iter(v for k_, v in model._vsa_cache.items() if isinstance(k_, tuple) and k_ and k_[0] == "sta"))["density"]
         flops_launch = 4.0 * Sq * Skv * h * cfg.head_dim * dens
-        kname = f"{args.attention} self-attention (gather + attn_fwd_kernel block-sparse + untile), density {dens:.3f} of dense"
+        if args.attention == "sta":  # single GPU: no gather passes (wan_dit._sta_fused); queries packed by window class on 256-row workgroups
+            kname = f"sta self-attention (V^T gather-transpose + attn_pp2_kernel over KV block lists, output rows scattered), density {dens:.3f} of dense"
+        else:
+            kname = f"{args.attention} self-attention (gather + attn_fwd_kernel block-sparse + untile), density {dens:.3f} of dense"
     achieved = flops_launch / (mean_ms * 1e-3) / 1e12
     traffic, traffic_src, gui_cycles = None, None, None
     if args.attention == "dense" and args.config == "cfg2" and world == 1:

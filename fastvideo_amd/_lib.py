@@ -32,13 +32,16 @@ SIGNATURES = {
     "fvk_ln_modulate_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "fvk_scale_residual_bf16": [vp, vp, vp, vp, i32, i32, i32, vp],
     "fvk_rmsnorm_rope_bf16": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, i32, i32, i32, i32, i32, i64, i64, f32, vp],
+    "fvk_rmsnorm_rope_scatter_bf16": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, i32, i32, i32, i32, i32, i64, i64, f32,
+                                      C.POINTER(vp), vp],
     "fvk_qkv_norm_rope_pack_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, i32, f32, vp],
     "fvk_v_transpose_bf16": [vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp],
+    "fvk_v_transpose_gather_bf16": [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp],
     "fvk_gemm_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i32, vp, vp, i32, vp],
     "fvk_gemm_bf16_batched": [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i64, i32, f32, vp],
     "fvk_attn_dense_bf16": [C.POINTER(AttnArgs), vp],
     "fvk_attn_block_sparse_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp],
-    "fvk_attn_tile_lists_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp, vp],
+    "fvk_attn_tile_lists_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp, vp, vp],
     "fvk_attn_sta_bf16": [C.POINTER(AttnArgs), i32, i32, i32, i32, C.POINTER(C.c_int32), vp],
     "fvk_vsa_build_metadata_host": [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp],
     "fvk_gather_rows_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, vp],

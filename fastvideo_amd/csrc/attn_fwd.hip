@@ -25,6 +25,7 @@ int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s);   // 
 struct fvk_pp2_lists {  // attn_pp2.hip: 256-row workgroups over shared KV block lists
     const int32_t* q2k_idx; const int32_t* q2k_num; const int32_t* kv_block_sizes; const int32_t* q_rows_valid;
     int max_kv, n_lists, q_stride, q_sub;
+    const int32_t* o_rows;
 };
 int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);
 
@@ -484,7 +485,7 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
 
 extern "C" int fvk_attn_tile_lists_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
                                         const int32_t* kv_block_sizes, int max_kv, int rows_per_list, const int32_t* q_rows_valid,
-                                        void* stream) {
+                                        const int32_t* o_rows, void* stream) {
     int rc = check_common(a, "fvk_attn_tile_lists_bf16");
     if (rc) return rc;
     FVK_CHECK(q2k_idx && q2k_num && kv_block_sizes && max_kv > 0, FVK_ERR_ARG, "fvk_attn_tile_lists_bf16: null index arrays");
@@ -493,9 +494,11 @@ extern "C" int fvk_attn_tile_lists_bf16(const fvk_attn_args* a, const int32_t* q
     FVK_CHECK(a->Sq % rows_per_list == 0 && a->Skv % 64 == 0, FVK_ERR_ARG,
               "fvk_attn_tile_lists_bf16: Sq=%d must be a multiple of rows_per_list=%d and Skv=%d of the 64-token KV block", a->Sq, rows_per_list, a->Skv);
     FVK_CHECK(a->qk_dim == 0 || a->qk_dim == 128, FVK_ERR_ARG, "fvk_attn_tile_lists_bf16: qk_dim=%d unsupported", a->qk_dim);
+    FVK_CHECK(!o_rows || rows_per_list % 256 == 0, FVK_ERR_ARG,
+              "fvk_attn_tile_lists_bf16: o_rows (scattered output rows) needs rows_per_list=%d to be a multiple of 256", rows_per_list);
     const int n_lists = a->Sq / rows_per_list;
     // 256-row workgroups on the ping-pong schedule; a 128-row remainder per list (384-token sliding tiles) on the 4-wave kernel
-    fvk_pp2_lists la{q2k_idx, q2k_num, kv_block_sizes, q_rows_valid, max_kv, n_lists, rows_per_list, rows_per_list / 256};
+    fvk_pp2_lists la{q2k_idx, q2k_num, kv_block_sizes, q_rows_valid, max_kv, n_lists, rows_per_list, rows_per_list / 256, o_rows};
     rc = fvk_attn_pp2_lists_launch(a, &la, (hipStream_t)stream);
     if (rc || rows_per_list % 256 == 0) return rc;
     ModeArgs ma{};

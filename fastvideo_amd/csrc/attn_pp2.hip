@@ -32,6 +32,7 @@ constexpr int LDS_BYTES = RING * (K_TILE + V_TILE);  // 131 072
 struct fvk_pp2_lists {
     const int32_t* q2k_idx; const int32_t* q2k_num; const int32_t* kv_block_sizes; const int32_t* q_rows_valid;
     int max_kv, n_lists, q_stride, q_sub;  // q_sub = 256-row workgroups per list
+    const int32_t* o_rows;                 // optional [Sq]: query row r's output goes to row o_rows[r] of o (negative: dropped)
 };
 namespace {
 
@@ -425,8 +426,10 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a, fvk_p
     // ---- epilogue ------------------------------------------------------------------------------------------------------------------
     const float l_tot = xhalf_sum(l_run);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (q_ok) {
-        bf16_t* orow = op + (long)qrow * a.o_ss;
+    int orow_i = qrow;
+    if (LIST && la.o_rows && q_ok) orow_i = la.o_rows[qrow];  // un-grouping folded into the store
+    if (q_ok && orow_i >= 0) {
+        bf16_t* orow = op + (long)orow_i * a.o_ss;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll

@@ -151,6 +151,9 @@ struct RmsArgs {
     bf16_t* pack_dst;
     int pack_G, pack_U, pack_W;
     int pack_slot[3];
+    // scatter (fvk_rmsnorm_rope_scatter_bf16): row m of tensor t is written to row row_map[t][m] of out[t] (negative: dropped); NULL = row m.
+    // Folds the tile-major / window-class gathers of the sparse attention paths into this pass.
+    const int32_t* row_map[3];
 };
 
 template <int VPL>
@@ -159,8 +162,10 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs a) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.M) return;
     const int t = blockIdx.y;
+    const int orow = a.row_map[t] ? a.row_map[t][row] : row;
+    if (orow < 0) return;
     const bf16_t* in = a.in[t] + (long)row * a.in_stride;
-    bf16_t* out = a.out[t] + (long)row * a.out_stride;
+    bf16_t* out = a.out[t] + (long)orow * a.out_stride;
     const bf16_t* w = a.w[t];
     const int nchunks = a.width >> 3;
     float v[VPL][8];
@@ -249,8 +254,10 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(const bf16_t* resid
 
 // V [B,S,H,128] -> Vt [B,H,128,S_pad], key order within each 16-group permuted (swap bits 2,3), pad zero.
 // One workgroup per (64-key tile, head, batch); transposition through LDS.
+// src_rows (optional, int32 [S_pad]): key position p of V^T takes row src_rows[p] of v (negative: zeros) — the tile-major gather of the sparse
+// attention paths folded into the transpose (S then bounds the SOURCE rows).
 __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* v, bf16_t* vt, int S, int H, long in_stride,
-                                                          long in_batch_stride, long in_head_stride, int S_pad) {
+                                                          long in_batch_stride, long in_head_stride, int S_pad, const int32_t* src_rows) {
     __shared__ bf16_t tile[64][128 + 8];
     const int kt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x;
@@ -259,9 +266,10 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* v, bf16_
     for (int i = 0; i < 4; ++i) {
         const int c = tid + 256 * i;  // 1024 chunks: 64 rows x 16 chunks
         const int r = c >> 4, ch = c & 15;
-        const int key = kt * 64 + r;
+        int key = kt * 64 + r;
+        if (src_rows) key = src_rows[key];
         bf16x8 val;
-        if (key < S) {
+        if (key >= 0 && key < S) {
             val = ld_bf16x8(src + (long)key * in_stride + ch * 8);
         } else {
 #pragma unroll
@@ -335,9 +343,29 @@ extern "C" int fvk_scale_residual_bf16(const void* residual, const void* x, cons
     return FVK_OK;
 }
 
+static int rmsnorm_rope_impl(const void* const* in, void* const* out, const void* const* weight, int n_tensors, const float* cos,
+                             const float* sin, int M, int width, int head_dim, int seq_len, int pos_offset, long in_stride,
+                             long out_stride, float eps, const int32_t* const* row_map, void* stream);
+
 extern "C" int fvk_rmsnorm_rope_bf16(const void* const* in, void* const* out, const void* const* weight, int n_tensors,
                                      const float* cos, const float* sin, int M, int width, int head_dim, int seq_len,
                                      int pos_offset, long in_stride, long out_stride, float eps, void* stream) {
+    return rmsnorm_rope_impl(in, out, weight, n_tensors, cos, sin, M, width, head_dim, seq_len, pos_offset, in_stride, out_stride, eps,
+                             nullptr, stream);
+}
+
+extern "C" int fvk_rmsnorm_rope_scatter_bf16(const void* const* in, void* const* out, const void* const* weight, int n_tensors,
+                                             const float* cos, const float* sin, int M, int width, int head_dim, int seq_len,
+                                             int pos_offset, long in_stride, long out_stride, float eps,
+                                             const int32_t* const* row_map, void* stream) {
+    FVK_CHECK(row_map, FVK_ERR_ARG, "fvk_rmsnorm_rope_scatter_bf16: null row_map array (use fvk_rmsnorm_rope_bf16)");
+    return rmsnorm_rope_impl(in, out, weight, n_tensors, cos, sin, M, width, head_dim, seq_len, pos_offset, in_stride, out_stride, eps,
+                             row_map, stream);
+}
+
+static int rmsnorm_rope_impl(const void* const* in, void* const* out, const void* const* weight, int n_tensors, const float* cos,
+                             const float* sin, int M, int width, int head_dim, int seq_len, int pos_offset, long in_stride,
+                             long out_stride, float eps, const int32_t* const* row_map, void* stream) {
     FVK_CHECK(in && out && n_tensors >= 1 && n_tensors <= 3, FVK_ERR_ARG, "fvk_rmsnorm_rope_bf16: n_tensors=%d", n_tensors);
     FVK_CHECK(width > 0 && width % 8 == 0 && head_dim > 0 && head_dim % 8 == 0 && width % head_dim == 0, FVK_ERR_ARG,
               "fvk_rmsnorm_rope_bf16: width=%d head_dim=%d", width, head_dim);
@@ -350,6 +378,7 @@ extern "C" int fvk_rmsnorm_rope_bf16(const void* const* in, void* const* out, co
         a.in[i] = (const bf16_t*)in[i];
         a.out[i] = (bf16_t*)out[i];
         a.w[i] = weight ? (const bf16_t*)weight[i] : nullptr;
+        a.row_map[i] = row_map ? row_map[i] : nullptr;
     }
     a.cos = cos; a.sin = sin; a.M = M; a.width = width; a.head_dim = head_dim; a.seq_len = seq_len; a.pos_offset = pos_offset;
     a.in_stride = in_stride; a.out_stride = out_stride; a.eps = eps; a.rope_mask = 7;
@@ -399,7 +428,19 @@ extern "C" int fvk_v_transpose_bf16(const void* v, void* vt, int B, int S, int H
     FVK_CHECK(S_pad % 64 == 0 && S_pad >= S && in_stride % 8 == 0 && in_head_stride % 8 == 0, FVK_ERR_ARG, "fvk_v_transpose_bf16: S_pad=%d S=%d", S_pad, S);
     if (B <= 0 || S_pad == 0) return FVK_OK;
     hipLaunchKernelGGL(v_transpose_kernel, dim3(S_pad / 64, H, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v,
-                       (bf16_t*)vt, S, H, in_stride, in_batch_stride, in_head_stride, S_pad);
+                       (bf16_t*)vt, S, H, in_stride, in_batch_stride, in_head_stride, S_pad, (const int32_t*)nullptr);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+extern "C" int fvk_v_transpose_gather_bf16(const void* v, void* vt, const int32_t* src_rows, int B, int S, int H, int D, long in_stride,
+                                           long in_batch_stride, long in_head_stride, int S_pad, void* stream) {
+    FVK_CHECK(v && vt && src_rows, FVK_ERR_ARG, "fvk_v_transpose_gather_bf16: null pointer");
+    FVK_CHECK(D == 128, FVK_ERR_ARG, "fvk_v_transpose_gather_bf16: head_dim %d != 128", D);
+    FVK_CHECK(S_pad % 64 == 0 && S > 0 && in_stride % 8 == 0 && in_head_stride % 8 == 0, FVK_ERR_ARG, "fvk_v_transpose_gather_bf16: S_pad=%d S=%d", S_pad, S);
+    if (B <= 0 || S_pad == 0) return FVK_OK;
+    hipLaunchKernelGGL(v_transpose_kernel, dim3(S_pad / 64, H, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)v,
+                       (bf16_t*)vt, S, H, in_stride, in_batch_stride, in_head_stride, S_pad, src_rows);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }

@@ -203,7 +203,53 @@ def sliding_tile_attention(q, k, v, window_size, text_length=0, has_text=False, 
     tiles = tuple(c // t for c, t in zip(canvas, tile_size))
     if len(window_size) != q.shape[1]:
         raise ValueError(f"window_size must list one (t,h,w) per head ({q.shape[1]}), got {len(window_size)}")
-    return ops.attn_sta(q, k, v, tiles, math.prod(tile_size), window_size, layout="bhsd")
+    tok = math.prod(tile_size)
+    windows = tuple(tuple(int(x) for x in w) for w in window_size)
+    if tok >= 256 and tok % 128 == 0 and max(w[0] * w[1] * w[2] for w in windows) * (tok // 64) <= 4096:
+        # one KV block list per (head, tile): 256 of a tile's query rows share a workgroup on the dense kernel's schedule
+        # (fvk_attn_tile_lists_bf16; 906 -> 1031 TF on 18x48x80 against the per-128-row canvas kernel, scripts/sta_lists_ab.py)
+        idx, num, sizes = _canvas_tile_lists(tiles, tok, windows, q.shape[0], q.device)
+        return ops.attn_tile_lists(q, k, v, idx, num, sizes, tok, None, layout="bhsd")
+    return ops.attn_sta(q, k, v, tiles, tok, window_size, layout="bhsd")
+
+
+_CANVAS_LISTS = {}
+
+
+def _canvas_tile_lists(tiles, tok, windows, batch, device):
+    """Per-(head, tile) KV lists of 64-token blocks for a whole-tile canvas (every block full), cached per geometry on the device.
+    Window rule: fastvideo-kernel/tests/support_flex_sta.py:44-51 (clamped centre, integer k//2; identical to fvk_attn_sta_bf16's)."""
+    key = (tiles, tok, windows, batch, str(device))
+    hit = _CANVAS_LISTS.get(key)
+    if hit is not None:
+        return hit
+    import numpy as np
+    sub = tok // 64
+    n_tiles = tiles[0] * tiles[1] * tiles[2]
+
+    def win(q_, n, k_):
+        c = min(max(q_, k_ // 2), (n - 1) - k_ // 2)
+        return range(max(c - k_ // 2, 0), min(c + k_ // 2 + 1, n))
+
+    per_head = {}
+    for w in set(windows):
+        lists = [[((x * tiles[1] + y) * tiles[2] + z) * sub + s_ for x in win(a, tiles[0], w[0]) for y in win(b, tiles[1], w[1])
+                  for z in win(c, tiles[2], w[2]) for s_ in range(sub)]
+                 for a in range(tiles[0]) for b in range(tiles[1]) for c in range(tiles[2])]
+        per_head[w] = lists
+    mx = max(len(l) for ls in per_head.values() for l in ls)
+    idx = np.zeros((len(windows), n_tiles, mx), dtype=np.int32)
+    num = np.zeros((len(windows), n_tiles), dtype=np.int32)
+    for h_, w in enumerate(windows):
+        for t, l in enumerate(per_head[w]):
+            idx[h_, t, :len(l)], num[h_, t] = l, len(l)
+    out = (torch.from_numpy(idx).to(device)[None].expand(batch, -1, -1, -1).contiguous(),
+           torch.from_numpy(num).to(device)[None].expand(batch, -1, -1).contiguous(),
+           torch.full((n_tiles * sub,), 64, dtype=torch.int32, device=device))
+    if len(_CANVAS_LISTS) >= 16:
+        _CANVAS_LISTS.clear()
+    _CANVAS_LISTS[key] = out
+    return out
 
 
 def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3)):

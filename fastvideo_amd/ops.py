@@ -87,9 +87,11 @@ def scale_residual(residual, x, gate=None, rows_per_batch=None):
     return out.view(x.shape)
 
 
-def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_len=None, eps=1e-6, outs=None, pos_offset=0):
+def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_len=None, eps=1e-6, outs=None, pos_offset=0, row_maps=None):
     """tensors: list (<=3) of bf16 2-D views [M, width] sharing one row stride (e.g. q,k column slices of a fused
-    QKV buffer).  Returns a list of new contiguous [M, width] tensors (or writes `outs`)."""
+    QKV buffer).  Returns a list of new contiguous [M, width] tensors (or writes `outs`).
+    row_maps (with `outs`): per tensor an int32 [M] map (or None) — row m is written to row map[m] of its output (negative: dropped);
+    the outputs then share one row stride and may have any number of rows (fvk_rmsnorm_rope_scatter_bf16)."""
     n = len(tensors)
     M, width = tensors[0].shape
     stride = tensors[0].stride(0)
@@ -109,6 +111,16 @@ def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_le
         keep = [None if w is None else _chk(w, BF16, "weight").contiguous() for w in weights]
         ws = arr(*[0 if w is None else w.data_ptr() for w in keep])
     cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
+    if row_maps is not None:
+        if len(row_maps) != n or any(o.stride(0) != ostride or o.stride(1) != 1 for o in outs):
+            raise RuntimeError("rmsnorm_rope: row_maps needs one entry per tensor and outputs with one common row stride")
+        maps = [None if r is None else _chk(r, torch.int32, "row_map").contiguous() for r in row_maps]
+        if any(r is not None and r.numel() != M for r in maps):
+            raise RuntimeError("rmsnorm_rope: every row map must have one entry per input row")
+        rm = arr(*[0 if r is None else r.data_ptr() for r in maps])
+        _lib.call("fvk_rmsnorm_rope_scatter_bf16", ins, os_, ws, n, _p(cos), _p(sin), M, width, head_dim, seq_len or M, int(pos_offset), stride,
+                  ostride, float(eps), rm, _stream())
+        return outs
     _lib.call("fvk_rmsnorm_rope_bf16", ins, os_, ws, n, _p(cos), _p(sin), M, width, head_dim, seq_len or M, int(pos_offset), stride, ostride,
               float(eps), _stream())
     return outs
@@ -137,15 +149,24 @@ def qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, G, U, head_dim=128, seq_len=No
     return out
 
 
-def v_transpose(v):
-    """v: bf16 [B,S,H,128] view (any strides with unit stride on D).  -> Vt [B,H,128,S_pad] (keys permuted, pad 0)."""
+def v_transpose(v, src_rows=None):
+    """v: bf16 [B,S,H,128] view (any strides with unit stride on D).  -> Vt [B,H,128,S_pad] (keys permuted, pad 0).
+    src_rows (int32 [n]): key position p of Vt takes row src_rows[p] of v (negative = zero column), S_pad = round_up(n, 128) — the
+    tile-major gather of V folded into the transpose (fvk_v_transpose_gather_bf16)."""
     _chk(v, BF16, "v")
     B, S, H, D = v.shape
     if v.stride(3) != 1:
         v = v.contiguous()
-    S_pad = (S + 127) // 128 * 128  # whole 128-key tiles: the 128-key-tile attention kernel reads V^T rows in 256-B pieces
+    n_keys = S if src_rows is None else src_rows.numel()
+    S_pad = (n_keys + 127) // 128 * 128  # whole 128-key tiles: the 128-key-tile attention kernel reads V^T rows in 256-B pieces
     vt = torch.empty((B, H, D, S_pad), dtype=BF16, device=v.device)
-    _lib.call("fvk_v_transpose_bf16", _p(v), _p(vt), B, S, H, D, v.stride(1), v.stride(0), v.stride(2), S_pad, _stream())
+    if src_rows is None:
+        _lib.call("fvk_v_transpose_bf16", _p(v), _p(vt), B, S, H, D, v.stride(1), v.stride(0), v.stride(2), S_pad, _stream())
+    else:
+        src_rows = _chk(src_rows, torch.int32, "src_rows").contiguous()
+        if src_rows.numel() != S_pad:
+            raise RuntimeError(f"v_transpose: src_rows must cover whole 128-key tiles (got {src_rows.numel()} entries)")
+        _lib.call("fvk_v_transpose_gather_bf16", _p(v), _p(vt), _p(src_rows), B, S, H, D, v.stride(1), v.stride(0), v.stride(2), S_pad, _stream())
     return vt
 
 
@@ -295,13 +316,24 @@ def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, lay
     return (o, lse) if return_lse else o
 
 
-def attn_tile_lists(q, k, v, q2k_idx, q2k_num, kv_block_sizes, rows_per_list, q_rows_valid=None, scale=None, layout="bhsd"):
+def attn_tile_lists(q, k, v, q2k_idx, q2k_num, kv_block_sizes, rows_per_list, q_rows_valid=None, scale=None, layout="bhsd", vt=None,
+                    o_rows=None, n_out_rows=None):
     """Block-sparse attention with one KV block list per ``rows_per_list`` consecutive query rows (fvk_attn_tile_lists_bf16): sliding-tile
     windows in tile-major order.  q2k_idx int32 [B,H,Nl,max_kv], q2k_num int32 [B,H,Nl], kv_block_sizes int32 [Nkv],
-    q_rows_valid int32 [Nl] or None."""
+    q_rows_valid int32 [Nl] or None.  vt: a ready V^T (then v is ignored).  o_rows int32 [Sq] + n_out_rows: query row r's output is stored at
+    row o_rows[r] of an [.., n_out_rows, ..] output (negative: dropped; rows no entry points at are left unwritten)."""
     scale = q.shape[-1]**-0.5 if scale is None else scale
-    vt = _vt_of(v, layout)
-    o = torch.empty_like(q)
+    if vt is None:
+        vt = _vt_of(v, layout)
+    if o_rows is None:
+        o = torch.empty_like(q)
+    else:
+        o_rows = _chk(o_rows, torch.int32, "o_rows").contiguous()
+        Sq = q.shape[1] if layout == "bshd" else q.shape[2]
+        if o_rows.numel() != Sq or n_out_rows is None:
+            raise RuntimeError("attn_tile_lists: o_rows needs one entry per query row and n_out_rows")
+        shape = (q.shape[0], n_out_rows, q.shape[2], q.shape[3]) if layout == "bshd" else (q.shape[0], q.shape[1], n_out_rows, q.shape[3])
+        o = torch.empty(shape, dtype=BF16, device=q.device)
     a = _attn_args(q, k, vt, o, scale, layout)
     q2k_idx = _chk(q2k_idx, torch.int32, "q2k_idx").contiguous()
     q2k_num = _chk(q2k_num, torch.int32, "q2k_num").contiguous()
@@ -309,7 +341,7 @@ def attn_tile_lists(q, k, v, q2k_idx, q2k_num, kv_block_sizes, rows_per_list, q_
     if q_rows_valid is not None:
         q_rows_valid = _chk(q_rows_valid, torch.int32, "q_rows_valid").contiguous()
     _lib.call("fvk_attn_tile_lists_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), q2k_idx.shape[-1], int(rows_per_list),
-              _p(q_rows_valid) if q_rows_valid is not None else None, _stream())
+              _p(q_rows_valid), _p(o_rows), _stream())
     return o
 
 

@@ -64,6 +64,7 @@ class WanTransformer3DModelHip:
         # sliding-tile list form: "grouped" (shipped) = queries packed by window class on 256-row workgroups; "tile" = one list per 384-token
         # tile (256-row workgroups + a 128-row remainder); "block128" = one list per 128-row query block on the 4-wave kernel (A/B, tests)
         self.sta_lists = "grouped"
+        self.sta_fold = True  # single GPU: no gather passes at all (q / k scattered by the norm pass, V^T gathered, output scattered)
         self.attn_events = None  # set to a list to collect (start, end, Sq, Skv, heads) HIP-event pairs
         self.vsa_trace = None    # set to a list to collect every layer's VSA block mask (tests)
 
@@ -153,7 +154,17 @@ class WanTransformer3DModelHip:
         if m is None:
             h = kernel_api.sliding_tile_block_lists(grid, self.sta_tile, self.sta_window)
             dev = self.device
-            m = dict(S_pad=h["S_pad"], perm=h["tile_partition_indices"].to(dev), non_pad=h["non_pad_index"].to(dev),
+            # row maps of the gather-free path (_sta_fused): token -> K row (tile-major, padded), V^T key position -> token, grouped query
+            # row -> token
+            n_tok = h["tile_partition_indices"].numel()
+            k_row = torch.empty(n_tok, dtype=torch.int32)
+            k_row[h["tile_partition_indices"].long()] = h["non_pad_index"].to(torch.int32)
+            v_src = torch.full(((h["S_pad"] + 127) // 128 * 128,), -1, dtype=torch.int32)
+            v_src[k_row.long()] = torch.arange(n_tok, dtype=torch.int32)
+            g_tok = torch.full((h["group_rows"],), -1, dtype=torch.int32)
+            g_tok[h["group_dst"].long()] = h["group_src"]
+            m = dict(k_row_of_token=k_row.to(dev), v_src_rows=v_src.to(dev), group_token_of_row=g_tok.to(dev),
+                     S_pad=h["S_pad"], perm=h["tile_partition_indices"].to(dev), non_pad=h["non_pad_index"].to(dev),
                      untile=h["untile_combined_index"].to(dev), block_sizes=h["block_sizes"].to(dev),
                      q2k_idx=h["q2k_idx"].to(dev)[None, None].expand(1, n_heads, -1, -1).contiguous(),
                      q2k_num=h["q2k_num"].to(dev)[None, None].expand(1, n_heads, -1).contiguous(),
@@ -252,6 +263,29 @@ class WanTransformer3DModelHip:
         o = ops.gather_rows(o, S, m["untile"], None)
         if q.shape[0] != S:
             o = torch.cat([o, o.new_zeros((1, q.shape[0] - S, *o.shape[2:]))], 1)
+        return o[0]
+
+    def _sta_fused(self, rows, b, cos, sin, S, grid):
+        """Sliding-tile self-attention of one sample with NO gather pass (single GPU): the QK-norm / RoPE pass scatters q into the
+        window-class packed layout and k into the tile-major one (fvk_rmsnorm_rope_scatter_bf16), V goes from token order straight to the
+        tile-major V^T (fvk_v_transpose_gather_bf16), and the attention epilogue stores every query row at its token's row (o_rows).
+        rows [S, 3d(+d)] = the fused QKV GEMM output -> o [S, H, D] in token order."""
+        d, H, D = self.d, self.H, self.D
+        m = self._sta_meta(grid, H)
+        qg = self._tile_bufs(m["group_rows"], H, 1, grid, "sta_q")[0]
+        kt = self._tile_bufs(m["S_pad"], H, 1, grid, "sta_k")[0]
+        ops.rmsnorm_rope([rows[:, :d], rows[:, d:2 * d]], [b["nq_w"], b["nk_w"]], cos, sin, head_dim=D, seq_len=S, eps=self.eps,
+                         outs=[qg.view(-1, d), kt.view(-1, d)], row_maps=[m["group_untile"], m["k_row_of_token"]])
+        ev = None
+        if self.attn_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        vt = ops.v_transpose(rows[:, 2 * d:3 * d].view(1, S, H, D), src_rows=m["v_src_rows"])
+        o = ops.attn_tile_lists(qg, kt, None, m["group_q2k_idx"], m["group_q2k_num"], m["block_sizes"], 256, None, scale=D**-0.5,
+                                layout="bshd", vt=vt, o_rows=m["group_token_of_row"], n_out_rows=S)
+        if ev is not None:
+            ev[1].record()
+            self.attn_events.append((ev[0], ev[1], S, S, H))
         return o[0]
 
     def _lin(self, x, b, key, bias, **kw):
@@ -355,6 +389,8 @@ class WanTransformer3DModelHip:
                     send = ops.qkv_norm_rope_pack(rows[:, :d], rows[:, d:2 * d], rows[:, 2 * d:3 * d], b["nq_w"], b["nk_w"], cos, sin,
                                                   sp.lay.G, sp.lay.U, head_dim=D, seq_len=S, eps=self.eps, pos_offset=pos0)
                     o = sp.attention_packed(send, S, fn, head_dim=D).reshape(Sl, d)
+                elif P == 1 and self.attention == "sta" and self.sta_lists == "grouped" and self.sta_fold:
+                    o = self._sta_fused(rows, b, cos, sin, S, grid).reshape(Sl, d)
                 else:
                     q, k = ops.rmsnorm_rope([rows[:, :d], rows[:, d:2 * d]], [b["nq_w"], b["nk_w"]], cos, sin, head_dim=D, seq_len=S,
                                             eps=self.eps, pos_offset=pos0)

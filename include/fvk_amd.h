@@ -70,6 +70,15 @@ int fvk_rmsnorm_rope_bf16(const void* const* in, void* const* out, const void* c
                           const float* cos, const float* sin, int M, int width, int head_dim, int seq_len,
                           int pos_offset, long in_stride, long out_stride, float eps, void* stream);
 
+/* The same pass with SCATTERED output rows: row m of tensor i lands in row row_map[i][m] of out[i] (row_map[i] NULL = row m; a negative
+ * entry drops the row).  Folds the tile-major permutation of the sparse attention paths — VideoSparseAttentionImpl.tile
+ * (fastvideo/attention/backends/video_sparse_attn.py:254-264) and the sliding-tile layout (fastvideo_kernel/ops.py:21-62 expects
+ * tile-major q, k, v) — into the norm / RoPE pass that writes q and k anyway: no separate gather, no extra S x d round trip. */
+int fvk_rmsnorm_rope_scatter_bf16(const void* const* in, void* const* out, const void* const* weight, int n_tensors,
+                                  const float* cos, const float* sin, int M, int width, int head_dim, int seq_len,
+                                  int pos_offset, long in_stride, long out_stride, float eps,
+                                  const int32_t* const* row_map, void* stream);
+
 /* Sequence-parallel exchange #1 packing fused into the QK-norm / RoPE pass (one read of the fused QKV buffer, no torch.cat):
  * q,k: RMS-norm across heads (weights wq/wk, NULL = skip) + RoPE (cos/sin NULL = skip); v: copied.  Row m of the rank's shard
  * (Sl rows, `in_stride` elements apart, `width` = heads*head_dim columns) is split into G head groups of W = width/G columns; group
@@ -89,6 +98,11 @@ int fvk_qkv_norm_rope_pack_bf16(const void* q, const void* k, const void* v, con
  * DESIGN.md "Vt layout").  D == 128. */
 int fvk_v_transpose_bf16(const void* v, void* vt, int B, int S, int H, int D, long in_stride, long in_batch_stride,
                          long in_head_stride, int S_pad, void* stream);
+
+/* The same with GATHERED source rows: key position p of Vt takes row src_rows[p] of v (int32 [S_pad]; negative = a zero column) — V goes
+ * from token order straight to the tile-major, zero-padded V^T the sparse kernels read (the `tile` gather of V folded in). */
+int fvk_v_transpose_gather_bf16(const void* v, void* vt, const int32_t* src_rows, int B, int S, int H, int D, long in_stride,
+                                long in_batch_stride, long in_head_stride, int S_pad, void* stream);
 
 /* ------------------------------------------------------------------ dense GEMM (MFMA-bound)
  * ref: fastvideo/layers/linear.py:146-156 (UnquantizedLinearMethod.apply = F.linear), mlp.py:47-51,
@@ -169,10 +183,13 @@ int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, c
  *      fastvideo-kernel/tests/support_flex_sta.py:29-59, kernels st_attn_triton.py:19-121 / csrc/attention/st_attn_h100.cu.
  * q2k_idx int32 [B,H,Nl,max_kv], q2k_num int32 [B,H,Nl], Nl = Sq / rows_per_list; rows_per_list a multiple of 128, >= 256; max_kv <= 4096.
  * q_rows_valid (optional, int32 [Nl]): real query rows at the head of each list's rows — 256- / 128-row groups that start at or past it
- * hold only padding and are written as zeros without touching K / V. */
+ * hold only padding and are written as zeros without touching K / V.
+ * o_rows (optional, int32 [Sq]; rows_per_list a multiple of 256): query row r's output is stored at row o_rows[r] of o (negative:
+ * dropped) instead of row r — the un-tiling gather (VideoSparseAttentionImpl.untile, video_sparse_attn.py:266-272) folded into the
+ * store; o then has as many rows as the map addresses, not Sq. */
 int fvk_attn_tile_lists_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
                              const int32_t* kv_block_sizes, int max_kv, int rows_per_list, const int32_t* q_rows_valid,
-                             void* stream);
+                             const int32_t* o_rows, void* stream);
 
 /* sliding-tile attention: tokens in tile-major order, tile = tile_t*tile_h*tile_w tokens (multiple of 64),
  * canvas of (ct,ch,cw) tiles; head h uses window (win[3h], win[3h+1], win[3h+2]) tiles with the clamped

@@ -109,6 +109,20 @@ def test_rmsnorm_rope(ops, grid, H):
     close(n_only, W.rms_norm(qkv[:, :d].unsqueeze(0), wq)[0], what="rmsnorm only")
     r_only = ops.rmsnorm_rope([n_only], None, cos.to(DEV), sin.to(DEV), head_dim=D, seq_len=S)[0]
     assert torch.equal(r_only, outs[0]), "norm->rope split must equal the fused kernel bit for bit"
+    # scattered output rows (fvk_rmsnorm_rope_scatter_bf16): q through a permutation into a larger buffer, k with every 5th row dropped
+    gperm = torch.randperm(S + 40, generator=g(9))[:S].to(torch.int32)
+    kmap = torch.arange(S, dtype=torch.int32)
+    kmap[::5] = -1
+    qo = torch.full((S + 40, d), 7.0, dtype=torch.bfloat16, device=DEV)
+    ko = torch.full((S + 40, d), 7.0, dtype=torch.bfloat16, device=DEV)
+    ops.rmsnorm_rope([dq[:, :d], dq[:, d:2 * d]], [wq.to(DEV), wk.to(DEV)], cos.to(DEV), sin.to(DEV), head_dim=D, seq_len=S,
+                     outs=[qo, ko], row_maps=[gperm.to(DEV), kmap.to(DEV)])
+    assert torch.equal(qo[gperm.long().to(DEV)], outs[0])
+    untouched = torch.ones(S + 40, dtype=torch.bool)
+    untouched[gperm.long()] = False
+    assert (qo[untouched.to(DEV)] == 7.0).all()
+    keep = (kmap >= 0)
+    assert torch.equal(ko[:S][keep.to(DEV)], outs[1][keep.to(DEV)]) and (ko[:S][~keep.to(DEV)] == 7.0).all() and (ko[S:] == 7.0).all()
 
 
 def test_v_transpose_layout(ops):
@@ -127,6 +141,14 @@ def test_v_transpose_layout(ops):
     # strided (bhsd) source
     v2 = v.permute(0, 2, 1, 3).contiguous().to(DEV)  # [B,H,S,D]
     assert torch.equal(ops.v_transpose(v2.transpose(1, 2)).cpu(), ref)
+    # gathered source rows (fvk_v_transpose_gather_bf16): key position p takes row src[p] (negative: a zero column) == gather, then transpose
+    src = torch.full((384,), -1, dtype=torch.int32)
+    src[torch.randperm(384, generator=g(4))[:S]] = torch.randperm(S, generator=g(5)).to(torch.int32)
+    vg = torch.zeros(B, 384, H, D, dtype=torch.bfloat16)
+    vg[:, src >= 0] = v[:, src[src >= 0].long()]
+    assert torch.equal(ops.v_transpose(v.to(DEV), src_rows=src.to(DEV)), ops.v_transpose(vg.to(DEV)))
+    with pytest.raises(RuntimeError, match="whole 128-key tiles"):
+        ops.v_transpose(v.to(DEV), src_rows=src[:300].to(DEV))
 
 
 # ------------------------------------------------------------------ GEMM
@@ -276,6 +298,18 @@ def test_attn_tile_lists_shared_kv_lists(ops, rows):
     full = ops.attn_tile_lists(q.to(DEV), k.to(DEV), v.to(DEV), dv(idx), dv(num), dv(vbs), rows, None, layout="bhsd").cpu()
     err = (full.float() - o128.float()).abs()
     assert err.max().item() < 4e-2 and err.mean().item() < 2e-3, (err.max().item(), err.mean().item())
+    if rows % 256 == 0:  # scattered output rows: row r -> o_rows[r] (a permutation with some rows dropped), bit-identical values
+        Sq = nl * rows
+        o_rows = torch.randperm(Sq + 64, generator=g(6))[:Sq].to(torch.int32)
+        o_rows[::7] = -1
+        sc = ops.attn_tile_lists(q.to(DEV), k.to(DEV), v.to(DEV), dv(idx), dv(num), dv(vbs), rows, None, layout="bhsd", o_rows=o_rows.to(DEV),
+                                 n_out_rows=Sq + 64).cpu()
+        kept = o_rows >= 0
+        assert sc.shape == (B, H, Sq + 64, 128) and torch.equal(sc[:, :, o_rows[kept].long()], full[:, :, kept])
+    else:
+        with pytest.raises(RuntimeError, match="o_rows"):
+            ops.attn_tile_lists(q.to(DEV), k.to(DEV), v.to(DEV), dv(idx), dv(num), dv(vbs), rows, None, layout="bhsd",
+                                o_rows=torch.zeros(nl * rows, dtype=torch.int32, device=DEV), n_out_rows=nl * rows)
 
 
 def test_attn_tile_lists_refuses_bad_geometry(ops):

@@ -66,3 +66,26 @@ def test_block_lists_expand_to_the_oracle_mask(grid, tile, window):
                 got2[i, raster_of_pos[b * 64:b * 64 + bsz[b]]] = True
         assert np.array_equal(got2, ref), form
     assert abs(m["density"] - (got.mean() if len(rows) == S else m["density"])) < 1e-9 and 0 < m["density"] <= 1
+
+
+@pytest.mark.parametrize("canvas,tile,windows", [((12, 16, 24), (6, 8, 8), ((3, 3, 3), (1, 3, 1), (3, 1, 5), (2, 2, 3))),
+                                                 ((6, 16, 32), (6, 8, 8), ((1, 1, 1), (3, 1, 10)))])
+def test_canvas_tile_lists_expand_to_the_oracle_mask(canvas, tile, windows):
+    """kernel_api.sliding_tile_attention's per-(head, tile) KV lists (the form fvk_attn_tile_lists_bf16 consumes) against the oracle's
+    sliding-tile mask (oracle/vsa_oracle.py sta_mask = fastvideo-kernel/tests/support_flex_sta.py:29-59), even window sizes included."""
+    from fastvideo_amd import kernel_api as K
+    tok = tile[0] * tile[1] * tile[2]
+    tiles = tuple(c // t for c, t in zip(canvas, tile))
+    idx, num, sizes = K._canvas_tile_lists(tiles, tok, windows, 2, torch.device("cpu"))
+    S = canvas[0] * canvas[1] * canvas[2]
+    assert idx.shape[:3] == (2, len(windows), S // tok) and (sizes == 64).all() and sizes.numel() == S // 64
+    assert torch.equal(idx[0], idx[1]) and torch.equal(num[0], num[1])
+    for h, w in enumerate(windows):
+        ref = V.sta_mask(canvas, w, tile).numpy()           # [S, S] in tile-major token order
+        got = np.zeros((S, S), dtype=bool)
+        for t in range(S // tok):
+            blocks = idx[0, h, t, :num[0, h, t]].numpy()
+            assert len(set(blocks.tolist())) == len(blocks)
+            for b in blocks:
+                got[t * tok:(t + 1) * tok, b * 64:(b + 1) * 64] = True
+        assert np.array_equal(got, ref), (h, w)
