@@ -51,6 +51,7 @@ SIGNATURES = {
     "fvk_map_to_index": [vp, vp, vp, i32, i32, vp],
     "fvk_softmax_rows_bf16": [vp, vp, i32, i32, vp],
     "fvk_vsa_combine_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, vp],
+    "fvk_vsa_combine_scatter_bf16": [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, i64, i64, i64, i64, i64, i64, vp],
     "fvk_patchify_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "fvk_unpatchify_bf16": [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp],
     "fvk_timestep_embedding_bf16": [vp, vp, i32, i32, f32, vp],

@@ -283,8 +283,12 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const bf16_t* in, bf1
     for (int i = threadIdx.x; i < n; i += 256) out[row * n + i] = (bf16_t)__fdiv_rn(expf((float)in[row * n + i] - mx), s);
 }
 
+// token_of_row (optional, int32 [S]): tile-major row s holds token token_of_row[s] (negative: a padding row, skipped); gate is then read and
+// out written at the TOKEN's row with their own strides (g_* / o_*) — the gate's tile gather and the output's untile gather folded in.
 __global__ __launch_bounds__(256) void vsa_combine_kernel(const bf16_t* out_c, const bf16_t* out_s, const bf16_t* gate, bf16_t* out,
-                                                          int S, int H, int block, long bs, long ss, long hs, long total) {
+                                                          int S, int H, int block, long bs, long ss, long hs, long total,
+                                                          const int32_t* token_of_row, long g_bs, long g_ss, long g_hs, long o_bs,
+                                                          long o_ss, long o_hs) {
     // one 16-B chunk (8 of D=128) per thread; chunk id -> (b, s, h, ch)
     for (long c = blockIdx.x * 256L + threadIdx.x; c < total; c += (long)gridDim.x * 256L) {
         const int ch = (int)(c & 15);
@@ -293,18 +297,25 @@ __global__ __launch_bounds__(256) void vsa_combine_kernel(const bf16_t* out_c, c
         const int s = (int)(r % S);
         const int b = (int)(r / S);
         const long off = b * bs + s * ss + h * hs + ch * 8;
+        long goff = off, ooff = off;
+        if (token_of_row) {
+            const int tok = token_of_row[s];
+            if (tok < 0) continue;
+            goff = b * g_bs + tok * g_ss + h * g_hs + ch * 8;
+            ooff = b * o_bs + tok * o_ss + h * o_hs + ch * 8;
+        }
         const bf16x8 oc = ld_bf16x8(out_c + ((((long)b * H + h) * (S / block)) + s / block) * 128 + ch * 8);
         const bf16x8 os = ld_bf16x8(out_s + off);
         bf16x8 o;
         if (gate) {
-            const bf16x8 g = ld_bf16x8(gate + off);
+            const bf16x8 g = ld_bf16x8(gate + goff);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(bf16_round((float)oc[j] * (float)g[j]) + (float)os[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)oc[j] + (float)os[j]);
         }
-        st_bf16x8(out + off, o);
+        st_bf16x8(out + ooff, o);
     }
 }
 
@@ -465,7 +476,23 @@ extern "C" int fvk_vsa_combine_bf16(const void* out_c, const void* out_s, const 
     const long total = (long)B * S * H * 16;
     if (total <= 0) return FVK_OK;
     hipLaunchKernelGGL(vsa_combine_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)out_c,
-                       (const bf16_t*)out_s, (const bf16_t*)gate, (bf16_t*)out, S, H, block, bs, ss, hs, total);
+                       (const bf16_t*)out_s, (const bf16_t*)gate, (bf16_t*)out, S, H, block, bs, ss, hs, total, (const int32_t*)nullptr, 0L, 0L,
+                       0L, 0L, 0L, 0L);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+extern "C" int fvk_vsa_combine_scatter_bf16(const void* out_c, const void* out_s, const void* gate, void* out, const int32_t* token_of_row,
+                                            int B, int S, int H, int D, int block, long bs, long ss, long hs, long g_bs, long g_ss,
+                                            long g_hs, long o_bs, long o_ss, long o_hs, void* stream) {
+    FVK_CHECK(out_c && out_s && out && token_of_row, FVK_ERR_ARG, "fvk_vsa_combine_scatter_bf16: null pointer");
+    FVK_CHECK(D == 128 && block > 0 && S % block == 0, FVK_ERR_ARG, "fvk_vsa_combine_scatter_bf16: D=%d S=%d block=%d", D, S, block);
+    FVK_CHECK((g_bs | g_ss | g_hs | o_bs | o_ss | o_hs) % 8 == 0, FVK_ERR_ARG, "fvk_vsa_combine_scatter_bf16: strides must keep 16-byte alignment");
+    const long total = (long)B * S * H * 16;
+    if (total <= 0) return FVK_OK;
+    hipLaunchKernelGGL(vsa_combine_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)out_c,
+                       (const bf16_t*)out_s, (const bf16_t*)gate, (bf16_t*)out, S, H, block, bs, ss, hs, total, token_of_row, g_bs, g_ss,
+                       g_hs, o_bs, o_ss, o_hs);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }

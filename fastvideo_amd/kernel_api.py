@@ -127,7 +127,7 @@ def _expand_block_lists(idx, num, vbs, block_elements):
     return idx_s.contiguous(), num_s.contiguous(), sizes.contiguous()
 
 
-def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=False, block_elements=64):
+def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=False, block_elements=64, token_of_row=None, n_tokens=None):
     """The VSA composition (fastvideo_kernel/ops.py:108-128) on tensors of either layout: "bhsd" (the package API) or "bshd" (what the model
     host holds — strides go to the kernels, nothing is transposed or copied).  ``block_elements`` 64 (Wan: tile (4,4,4)) runs the 64-row
     list kernel; 128 / 256 (the reference's Blackwell CuTe paths, ops.py:125-128) run the 128-row list kernel over expanded lists."""
@@ -153,7 +153,9 @@ def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=Fa
     else:
         idx_s, num_s, sizes = _expand_block_lists(idx, num, vbs, block_elements)
         out_s = ops.attn_block_sparse(q, k, v, idx_s, num_s, sizes, layout=layout, q_block=128)
-    out = ops.vsa_combine(out_c, out_s, gate, block_elements, layout=layout)
+    # token_of_row (model host only): gate arrives in TOKEN order and the result is returned in token order — tile(gate) and untile(out)
+    # folded into the combine pass
+    out = ops.vsa_combine(out_c, out_s, gate, block_elements, layout=layout, token_of_row=token_of_row, n_tokens=n_tokens)
     if return_intermediates:
         return out, dict(q_c=q_c, k_c=k_c, v_c=v_c, scores=scores, mask=mask, q2k_idx=idx, q2k_num=num, out_c=out_c,
                          out_s=out_s)

@@ -601,12 +601,15 @@ def softmax_rows(x):
     return out
 
 
-def vsa_combine(out_c, out_s, gate=None, block=64, layout="bhsd"):
-    """out_c [B,H,Nblk,D] contiguous; out_s / gate [B,H,S,D] (bhsd) or [B,S,H,D] (bshd)."""
+def vsa_combine(out_c, out_s, gate=None, block=64, layout="bhsd", token_of_row=None, n_tokens=None):
+    """out_c [B,H,Nblk,D] contiguous; out_s / gate [B,H,S,D] (bhsd) or [B,S,H,D] (bshd).
+    token_of_row (int32 [S]) + n_tokens: ``gate`` is in TOKEN order ([B, n_tokens, H, D] / [B, H, n_tokens, D], any strides with unit D
+    stride) and the result comes back in token order — the tile gather of the gate and the untile gather of the output folded in
+    (fvk_vsa_combine_scatter_bf16); rows with a negative entry are padding."""
     _chk(out_c, BF16, "out_c"), _chk(out_s, BF16, "out_s")
     out_c = out_c.contiguous()
     out_s = out_s.contiguous()
-    if gate is not None:
+    if gate is not None and token_of_row is None:
         gate = _chk(gate, BF16, "gate").contiguous()
     if layout == "bhsd":
         B, H, S, D = out_s.shape
@@ -614,6 +617,20 @@ def vsa_combine(out_c, out_s, gate=None, block=64, layout="bhsd"):
     else:
         B, S, H, D = out_s.shape
         bs, ss, hs = out_s.stride(0), out_s.stride(1), out_s.stride(2)
+    if token_of_row is not None:
+        token_of_row = _chk(token_of_row, torch.int32, "token_of_row").contiguous()
+        if token_of_row.numel() != S or n_tokens is None:
+            raise RuntimeError("vsa_combine: token_of_row needs one entry per tile-major row and n_tokens")
+        out = torch.empty((B, H, n_tokens, D) if layout == "bhsd" else (B, n_tokens, H, D), dtype=BF16, device=out_s.device)
+        st = (lambda t: (t.stride(0), t.stride(2), t.stride(1))) if layout == "bhsd" else (lambda t: (t.stride(0), t.stride(1), t.stride(2)))
+        if gate is not None:
+            _chk(gate, BF16, "gate")
+            if gate.stride(-1) != 1 or gate.shape != out.shape:
+                raise RuntimeError("vsa_combine: token-order gate must match the output shape with a unit head_dim stride")
+        g_st = st(gate) if gate is not None else (0, 0, 0)
+        _lib.call("fvk_vsa_combine_scatter_bf16", _p(out_c), _p(out_s), _p(gate), _p(out), _p(token_of_row), B, S, H, D, block, bs, ss, hs,
+                  *g_st, *st(out), _stream())
+        return out
     out = torch.empty_like(out_s)
     _lib.call("fvk_vsa_combine_bf16", _p(out_c), _p(out_s), _p(gate), _p(out), B, S, H, D, block, bs, ss, hs, _stream())
     return out

@@ -64,6 +64,7 @@ class WanTransformer3DModelHip:
         # sliding-tile list form: "grouped" (shipped) = queries packed by window class on 256-row workgroups; "tile" = one list per 384-token
         # tile (256-row workgroups + a 128-row remainder); "block128" = one list per 128-row query block on the 4-wave kernel (A/B, tests)
         self.sta_lists = "grouped"
+        self.vsa_fold = True  # single GPU: tile(q), tile(k), tile(gate), untile(out) folded into the neighbouring kernels (V keeps its gather)
         self.sta_fold = True  # single GPU: no gather passes at all (q / k scattered by the norm pass, V^T gathered, output scattered)
         self.attn_events = None  # set to a list to collect (start, end, Sq, Skv, heads) HIP-event pairs
         self.vsa_trace = None    # set to a list to collect every layer's VSA block mask (tests)
@@ -143,6 +144,13 @@ class WanTransformer3DModelHip:
             m["S_pad"] = math.prod(m["num_tiles"]) * 64
             m["topk"] = max(1, min(math.ceil((1 - self.vsa_sparsity) * m["variable_block_sizes"].numel()),
                                    m["variable_block_sizes"].numel()))
+            # row maps of the gather-free path (_vsa_fused): token -> tile-major padded row, and back (-1 = padding row)
+            n_tok = h["tile_partition_indices"].numel()
+            row = torch.empty(n_tok, dtype=torch.int32)
+            row[h["tile_partition_indices"].long()] = h["non_pad_index"].to(torch.int32)
+            tok = torch.full((m["S_pad"],), -1, dtype=torch.int32)
+            tok[row.long()] = torch.arange(n_tok, dtype=torch.int32)
+            m["row_of_token"], m["token_of_row"] = row.to(self.device), tok.to(self.device)
             self._vsa_cache[grid] = m
         return m
 
@@ -264,6 +272,33 @@ class WanTransformer3DModelHip:
         if q.shape[0] != S:
             o = torch.cat([o, o.new_zeros((1, q.shape[0] - S, *o.shape[2:]))], 1)
         return o[0]
+
+    def _vsa_fused(self, rows, b, cos, sin, S, grid):
+        """Video-sparse self-attention of one sample (single GPU) with ONE gather left (V): the QK-norm / RoPE pass scatters q and k into
+        the tile-major padded layout, the combine pass reads the compress gate in token order and writes the result in token order
+        (tile(q), tile(k), tile(gate) and untile(out) folded away; ref video_sparse_attn.py:254-342).  rows [S, 4d] -> o [S, H, D]."""
+        d, H, D = self.d, self.H, self.D
+        m = self._vsa_meta(grid)
+        has_gate = rows.shape[1] >= 4 * d
+        tq, tk, tv = self._tile_bufs(m["S_pad"], H, 3, grid, "vsa")[:3]
+        ops.rmsnorm_rope([rows[:, :d], rows[:, d:2 * d]], [b["nq_w"], b["nk_w"]], cos, sin, head_dim=D, seq_len=S, eps=self.eps,
+                         outs=[tq.view(-1, d), tk.view(-1, d)], row_maps=[m["row_of_token"], m["row_of_token"]])
+        ev = None
+        if self.attn_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        ops.gather_rows(rows[:, 2 * d:3 * d].view(1, S, H, D), m["S_pad"], m["tile_partition_indices"], m["non_pad_index"], out=tv)
+        gate = rows[:, 3 * d:4 * d].view(1, S, H, D) if has_gate else None
+        vbs = m["variable_block_sizes"]
+        want = self.vsa_trace is not None
+        res = kernel_api._vsa_forward(tq, tk, tv, vbs, vbs, m["topk"], gate, "bshd", want, 64, token_of_row=m["token_of_row"], n_tokens=S)
+        if want:  # tests: keep every layer's block selection so that an oracle can be evaluated with the SAME selection
+            res, inter = res
+            self.vsa_trace.append(inter["mask"])
+        if ev is not None:
+            ev[1].record()
+            self.attn_events.append((ev[0], ev[1], S, S, H))
+        return res[0]
 
     def _sta_fused(self, rows, b, cos, sin, S, grid):
         """Sliding-tile self-attention of one sample with NO gather pass (single GPU): the QK-norm / RoPE pass scatters q into the
@@ -391,6 +426,8 @@ class WanTransformer3DModelHip:
                     o = sp.attention_packed(send, S, fn, head_dim=D).reshape(Sl, d)
                 elif P == 1 and self.attention == "sta" and self.sta_lists == "grouped" and self.sta_fold:
                     o = self._sta_fused(rows, b, cos, sin, S, grid).reshape(Sl, d)
+                elif P == 1 and self.attention == "vsa" and self.vsa_fold:
+                    o = self._vsa_fused(rows, b, cos, sin, S, grid).reshape(Sl, d)
                 else:
                     q, k = ops.rmsnorm_rope([rows[:, :d], rows[:, d:2 * d]], [b["nq_w"], b["nk_w"]], cos, sin, head_dim=D, seq_len=S,
                                             eps=self.eps, pos_offset=pos0)

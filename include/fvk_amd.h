@@ -230,6 +230,13 @@ int fvk_softmax_rows_bf16(const void* in, void* out, int rows, int n, void* stre
  * ref: fastvideo_kernel/ops.py:120-133.  out_s/gate/out share strides (bs, ss, hs); out_c is [B,H,Nblk,D] contiguous. */
 int fvk_vsa_combine_bf16(const void* out_c, const void* out_s, const void* gate, void* out, int B, int S, int H, int D,
                          int block, long bs, long ss, long hs, void* stream);
+/* The same with the tile gather of `gate` and the un-tiling of the result folded in: tile-major row s of out_c / out_s belongs to token
+ * token_of_row[s] (int32 [S]; negative = padding row, skipped); gate is read and out written at the TOKEN's row with their own strides
+ * (elements): gate[b*g_bs + tok*g_ss + h*g_hs], out[b*o_bs + tok*o_ss + h*o_hs].
+ * ref: VideoSparseAttentionImpl.tile / untile (fastvideo/attention/backends/video_sparse_attn.py:254-272) around fastvideo_kernel/ops.py:120-133. */
+int fvk_vsa_combine_scatter_bf16(const void* out_c, const void* out_s, const void* gate, void* out, const int32_t* token_of_row,
+                                 int B, int S, int H, int D, int block, long bs, long ss, long hs, long g_bs, long g_ss, long g_hs,
+                                 long o_bs, long o_ss, long o_hs, void* stream);
 
 /* ------------------------------------------------------------------ Wan VAE decode (causal 3-D conv; MFMA-bound convs, HBM-bound norm)
  * Activations are channels-last bf16 [frames, H, W, C].  ref: fastvideo/models/vaes/wanvae.py:160-207 (WanCausalConv3d),

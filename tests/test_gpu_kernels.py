@@ -339,6 +339,29 @@ def test_attn_sta(ops, canvas, tile, win):
 
 
 # ------------------------------------------------------------------ VSA pieces (integer parts bit exact)
+def test_vsa_combine_and_its_scatter_form(ops):
+    """out = bf16(bf16(out_c * gate) + out_s) per token (fastvideo_kernel/ops.py:120-133) and the form with tile(gate) / untile(out) folded
+    in: gate read and result written in TOKEN order through token_of_row (padding rows skipped) — bit-identical to gather, combine, gather."""
+    B, H, S_pad, n_tok, blk = 1, 3, 320, 250, 64
+    out_c, out_s = rnd((B, H, S_pad // blk, 128), 1).to(DEV), rnd((B, S_pad, H, 128), 2).to(DEV)
+    gate_tok = rnd((B, n_tok, 4 * H, 128), 3).to(DEV)[:, :, 3 * H:]            # a column block of a wider buffer (the fused QKV+gate rows)
+    token_of_row = torch.full((S_pad,), -1, dtype=torch.int32)
+    token_of_row[torch.randperm(S_pad, generator=g(4))[:n_tok]] = torch.randperm(n_tok, generator=g(5)).to(torch.int32)
+    rows_of_tok = torch.empty(n_tok, dtype=torch.long)
+    real = token_of_row >= 0
+    rows_of_tok[token_of_row[real].long()] = torch.arange(S_pad)[real]
+    gate_tiled = torch.zeros((B, S_pad, H, 128), dtype=torch.bfloat16, device=DEV)
+    gate_tiled[:, rows_of_tok.to(DEV)] = gate_tok
+    tiled = ops.vsa_combine(out_c, out_s, gate_tiled, blk, layout="bshd")
+    oc = out_c.float().cpu().repeat_interleave(blk, dim=2).transpose(1, 2)     # [B,S_pad,H,D]
+    ref = ((oc * gate_tiled.float().cpu()).bfloat16().float() + out_s.float().cpu()).bfloat16()
+    assert torch.equal(tiled.cpu(), ref)
+    got = ops.vsa_combine(out_c, out_s, gate_tok, blk, layout="bshd", token_of_row=token_of_row.to(DEV), n_tokens=n_tok)
+    assert got.shape == (B, n_tok, H, 128) and torch.equal(got, tiled[:, rows_of_tok.to(DEV)])
+    nog = ops.vsa_combine(out_c, out_s, None, blk, layout="bshd", token_of_row=token_of_row.to(DEV), n_tokens=n_tok)
+    assert torch.equal(nog, ops.vsa_combine(out_c, out_s, None, blk, layout="bshd")[:, rows_of_tok.to(DEV)])
+
+
 @pytest.mark.parametrize("n,topk", [(50, 9), (624, 125), (624, 63), (1440, 288), (7, 7), (300, 1), (2160, 432), (8192, 100), (65, 64)])
 def test_topk_mask_bit_exact(ops, n, topk):
     sc = rnd((3, 5, n), 1, 2.0)  # bf16 scores have many exact ties

@@ -84,6 +84,11 @@ def test_wan_tiny_vsa_matches_oracle(tiny):
     with torch.no_grad():
         ref2 = orc.forward(case["latent"], case["ctx"], case["timestep"])
     _cmp(y, ref2, "vsa model, oracle with the device's block selection")
+    # the shipped single-GPU path folds tile(q), tile(k) and untile(out) into the neighbouring kernels: the same values reach the same
+    # kernels as with the explicit gathers -> bit-identical output
+    assert model.vsa_fold
+    model.vsa_fold = False
+    assert torch.equal(model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda()), y)
 
 
 def test_smoke_entry():
