@@ -26,6 +26,7 @@ struct fvk_pp2_lists {  // attn_pp2.hip: 256-row workgroups over shared KV block
     const int32_t* q2k_idx; const int32_t* q2k_num; const int32_t* kv_block_sizes; const int32_t* q_rows_valid;
     int max_kv, n_lists, q_stride, q_sub;
     const int32_t* o_rows;
+    int plain_ids;
 };
 int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);
 
@@ -498,7 +499,8 @@ extern "C" int fvk_attn_tile_lists_bf16(const fvk_attn_args* a, const int32_t* q
               "fvk_attn_tile_lists_bf16: o_rows (scattered output rows) needs rows_per_list=%d to be a multiple of 256", rows_per_list);
     const int n_lists = a->Sq / rows_per_list;
     // 256-row workgroups on the ping-pong schedule; a 128-row remainder per list (384-token sliding tiles) on the 4-wave kernel
-    fvk_pp2_lists la{q2k_idx, q2k_num, kv_block_sizes, q_rows_valid, max_kv, n_lists, rows_per_list, rows_per_list / 256, o_rows};
+    fvk_pp2_lists la{q2k_idx, q2k_num, kv_block_sizes, q_rows_valid, max_kv, n_lists, rows_per_list, rows_per_list / 256, o_rows,
+                     fvk::tunable(fvk::TUNE_ATTN_IMPL) == 70};  // "attn_impl" 70: hardware workgroup order (A/B of the XCD-contiguous deal)
     rc = fvk_attn_pp2_lists_launch(a, &la, (hipStream_t)stream);
     if (rc || rows_per_list % 256 == 0) return rc;
     ModeArgs ma{};

@@ -33,6 +33,7 @@ struct fvk_pp2_lists {
     const int32_t* q2k_idx; const int32_t* q2k_num; const int32_t* kv_block_sizes; const int32_t* q_rows_valid;
     int max_kv, n_lists, q_stride, q_sub;  // q_sub = 256-row workgroups per list
     const int32_t* o_rows;                 // optional [Sq]: query row r's output goes to row o_rows[r] of o (negative: dropped)
+    int plain_ids;                         // measurement: 1 = hardware workgroup order (no XCD-contiguous deal)
 };
 namespace {
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a, fvk_p
     if (LIST) {
         // XCD-aware deal: hardware workgroup id x lands on XCD x % 8; XCD c gets the contiguous logical ids [c*q + min(c,r), ...)
         const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
-        const int bid = xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
+        const int bid = la.plain_ids ? (int)blockIdx.x : xcd * xq + (xcd < xr ? xcd : xr) + (blockIdx.x >> 3);
         const int per_head = la.n_lists * la.q_sub;
         const int u = bid % per_head, sub = u % la.q_sub, li = u / la.q_sub;
         h = (bid / per_head) % a.H;

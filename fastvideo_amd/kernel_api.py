@@ -254,7 +254,7 @@ def _canvas_tile_lists(tiles, tok, windows, batch, device):
     return out
 
 
-def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3)):
+def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3), group_order="first_tile"):
     """Host-side (CPU, pure integer) index construction that turns sliding-tile attention on an ARBITRARY token grid into block-sparse
     attention: the grid is padded up to whole tiles, tokens are gathered tile-major with each tile's real tokens first, and the
     clamped-centre window rule (fastvideo-kernel/tests/support_flex_sta.py:44-51) selects, per query block, the 64-token KV blocks of
@@ -316,7 +316,10 @@ def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3)):
     for t, key in enumerate(tile_class):
         classes.setdefault(key, []).append(t)
     g_src, g_dst, g_lists, row0 = [], [], [], 0
-    for key, tiles_c in classes.items():
+    items = list(classes.items())
+    if group_order == "longest_first":  # measurement: longest KV lists first
+        items.sort(key=lambda kv: -len(tile_lists[kv[1][0]]))
+    for key, tiles_c in items:
         toks = np.concatenate([perm[tile_off[t]:tile_off[t + 1]] for t in tiles_c])
         if len(toks) == 0:
             continue
