@@ -248,7 +248,7 @@ class HipSlidingTileAttentionImpl(AttentionImpl):
     def forward(self, query, key, value, attn_metadata=None):
         _require_bf16_cuda(query, key, value)
         tiles = tuple(c // t for c, t in zip(self.canvas, self.tile_thw))
-        return ops.attn_sta(query, key, value, tiles, math.prod(self.tile_thw), self.windows, layout="bshd")
+        return kernel_api.sliding_tile_attention_canvas(query, key, value, tiles, math.prod(self.tile_thw), self.windows, layout="bshd")
 
 
 class HipSlidingTileAttentionBackend(AttentionBackend):

@@ -205,14 +205,20 @@ def sliding_tile_attention(q, k, v, window_size, text_length=0, has_text=False, 
     tiles = tuple(c // t for c, t in zip(canvas, tile_size))
     if len(window_size) != q.shape[1]:
         raise ValueError(f"window_size must list one (t,h,w) per head ({q.shape[1]}), got {len(window_size)}")
-    tok = math.prod(tile_size)
+    return sliding_tile_attention_canvas(q, k, v, tiles, math.prod(tile_size), window_size, layout="bhsd")
+
+
+def sliding_tile_attention_canvas(q, k, v, tiles, tile_tokens, window_size, layout="bhsd"):
+    """Sliding-tile attention over tile-major tokens of a whole-tile canvas (``tiles`` = tiles per axis), either layout.  Tiles of >= 256
+    tokens: one KV block list per (head, tile), 256 of a tile's query rows per workgroup on the dense kernel's schedule
+    (fvk_attn_tile_lists_bf16; 907 -> 1030 TF on 18x48x80 against the per-128-row canvas kernel, profiles/r02_sta_lists_ab.md);
+    smaller tiles: the canvas kernel (fvk_attn_sta_bf16)."""
+    tok = int(tile_tokens)
     windows = tuple(tuple(int(x) for x in w) for w in window_size)
     if tok >= 256 and tok % 128 == 0 and max(w[0] * w[1] * w[2] for w in windows) * (tok // 64) <= 4096:
-        # one KV block list per (head, tile): 256 of a tile's query rows share a workgroup on the dense kernel's schedule
-        # (fvk_attn_tile_lists_bf16; 906 -> 1031 TF on 18x48x80 against the per-128-row canvas kernel, scripts/sta_lists_ab.py)
-        idx, num, sizes = _canvas_tile_lists(tiles, tok, windows, q.shape[0], q.device)
-        return ops.attn_tile_lists(q, k, v, idx, num, sizes, tok, None, layout="bhsd")
-    return ops.attn_sta(q, k, v, tiles, tok, window_size, layout="bhsd")
+        idx, num, sizes = _canvas_tile_lists(tuple(tiles), tok, windows, q.shape[0], q.device)
+        return ops.attn_tile_lists(q, k, v, idx, num, sizes, tok, None, layout=layout)
+    return ops.attn_sta(q, k, v, tiles, tok, window_size, layout=layout)
 
 
 _CANVAS_LISTS = {}

@@ -15,8 +15,12 @@ mkdir -p "$OUT"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  N_LAUNCH=3 timeout 240 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/p$i" -o pmc -- python scripts/attn_only.py > "$OUT/p$i.log" 2>&1 < /dev/null
-  echo "pass $i ($SET) rc=$?"
+  N_LAUNCH=3 timeout ${PASS_TIMEOUT:-120} rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/p$i" -o pmc -- python scripts/attn_only.py > "$OUT/p$i.log" 2>&1 < /dev/null
+  rc=$?
+  echo "pass $i ($SET) rc=$rc"
+  # a pass that faults or hangs (seen once: "Memory access fault" inside rocprofv3's own start-up on a box whose GPU then hung every later
+  # process) must not burn the remaining passes' time-outs
+  if [ $rc -ne 0 ]; then echo "aborting the PMC passes after a failed pass: $(grep -m1 -i "fault\|error" "$OUT/p$i.log")"; break; fi
 done
 python - "$OUT" <<'PY'
 import csv, glob, hashlib, json, sys, collections
