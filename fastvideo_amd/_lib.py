@@ -11,7 +11,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libfvk_amd.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 

@@ -15,7 +15,7 @@ void fvk_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fvk_last_error(void) { return g_err; }
-extern "C" int fvk_abi_version(void) { return 3; }
+extern "C" int fvk_abi_version(void) { return 4; }
 
 extern "C" int fvk_device_arch(char* buf, int len) {
     if (!buf || len <= 0) return FVK_ERR_ARG;

@@ -52,9 +52,40 @@ def test_argument_checks_of_the_newer_entries(lib):
         lib.call("fvk_vae_conv_norm_bf16", p, p, None, p, None, 1, 8, 8, 32, 192, 3, 3, 0, 0, 0, 0, p, p, 3, 0, 1, None)
     with pytest.raises(RuntimeError, match="fvk_vae_conv_norm_bf16"):       # consumer ring shorter than the chunk
         lib.call("fvk_vae_conv_norm_bf16", p, p, None, p, None, 4, 8, 8, 32, 96, 3, 6, 0, 0, 0, 0, p, p, 3, 0, 1, None)
+    # round-2 entries: scattered / gathered row maps and the shared-list attention
+    arr = (C.c_void_p * 1)(p.value)
+    with pytest.raises(RuntimeError, match="fvk_rmsnorm_rope_scatter_bf16"):   # the scatter form needs its row-map array
+        lib.call("fvk_rmsnorm_rope_scatter_bf16", arr, arr, None, 1, None, None, 4, 128, 128, 4, 0, 128, 128, 1e-6, None, None)
+    with pytest.raises(RuntimeError, match="fvk_v_transpose_gather_bf16"):
+        lib.call("fvk_v_transpose_gather_bf16", p, p, None, 1, 64, 1, 128, 128, 0, 128, 64, None)
+    with pytest.raises(RuntimeError, match="fvk_vsa_combine_scatter_bf16"):
+        lib.call("fvk_vsa_combine_scatter_bf16", p, p, None, p, None, 1, 64, 1, 128, 64, 0, 128, 128, 0, 128, 128, 0, 128, 128, None)
+    with pytest.raises(RuntimeError, match="strides must keep 16-byte alignment"):
+        lib.call("fvk_vsa_combine_scatter_bf16", p, p, None, p, p, 1, 64, 1, 128, 64, 0, 128, 128, 0, 130, 128, 0, 128, 128, None)
     with pytest.raises(RuntimeError, match="unknown tunable"):
         lib.call("fvk_set_tunable", b"no_such_knob", 1)
     lib.call("fvk_set_tunable", b"vsa_impl", 0)
+
+
+def test_tile_lists_attention_argument_checks(lib):
+    """fvk_attn_tile_lists_bf16 validates its geometry on the host (no launch): rows_per_list a multiple of 128 and >= 256, Sq a multiple of
+    it, scattered output rows only with whole 256-row groups."""
+    import ctypes as C
+    buf = (C.c_char * 4096)()
+    p = C.cast(buf, C.c_void_p)
+    a = lib.AttnArgs()
+    a.q = a.k = a.vt = a.o = p.value
+    a.B, a.H, a.Sq, a.Skv, a.Skv_pad = 1, 1, 768, 256, 256
+    a.q_ss = a.k_ss = a.o_ss = 128
+    a.q_hs = a.k_hs = a.o_hs = 128
+    a.scale = 1.0
+    for rows, msg in ((128, "rows_per_list=128"), (320, "rows_per_list=320"), (512, "multiple of rows_per_list=512")):
+        with pytest.raises(RuntimeError, match=msg):
+            lib.call("fvk_attn_tile_lists_bf16", C.byref(a), p, p, p, 4, rows, None, None, None)
+    with pytest.raises(RuntimeError, match="o_rows"):
+        lib.call("fvk_attn_tile_lists_bf16", C.byref(a), p, p, p, 4, 384, None, p, None)
+    with pytest.raises(RuntimeError, match="null index arrays"):
+        lib.call("fvk_attn_tile_lists_bf16", C.byref(a), None, p, p, 4, 384, None, None, None)
 
 
 def test_attention_refuses_slices_beyond_the_32bit_descriptor_range(lib):
