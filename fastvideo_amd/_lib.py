@@ -79,6 +79,10 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950).  fastvideo_amd has no CPU / eager fallback.")
+    # torch FIRST: it brings the HIP runtime the process will use for device memory and streams.  Loading this library before torch
+    # (e.g. `build()` then `smoke()` in one fresh process) binds it to a second copy of the runtime, whose first launch then fails with
+    # "no ROCm-capable device is detected" (seen on the GPU box; tests/test_gpu_model.py::test_build_then_smoke_in_a_fresh_process).
+    import torch  # noqa: F401
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

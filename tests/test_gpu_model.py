@@ -96,6 +96,17 @@ def test_smoke_entry():
     G.smoke()
 
 
+def test_build_then_smoke_in_a_fresh_process():
+    """Load-order independence: build() (which loads libfvk_amd.so) BEFORE anything has imported torch, then smoke() — in a fresh
+    interpreter.  The library must share torch's HIP runtime whichever is loaded first."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as G; G.build(); G.smoke(); print('fresh-process smoke ok')"],
+                       cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fresh-process smoke ok" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 @pytest.mark.parametrize("quant", ["fp8", "fp8_channel"])
 def test_wan_tiny_fp8_matches_oracle(tiny, quant):
     """fp8 linear path inside the full model (FP8Config granularity tensor / channel, fastvideo/layers/quantization/fp8_config.py)
