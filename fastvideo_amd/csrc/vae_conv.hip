@@ -453,13 +453,14 @@ extern "C" int fvk_vae_conv_bf16(const void* in, const void* w, const void* bias
     return launch_e<1>(a, epilogue, upsample2x != 0, (hipStream_t)stream);
 }
 
-// 3x3-tap conv with the consumer's RMS-norm (+SiLU) fused into the epilogue (Cout == 96): see include/fvk_amd.h
+// 3x3-tap conv with the consumer's RMS-norm (+SiLU) fused into the epilogue (Cout == 96 or 192): see include/fvk_amd.h
 extern "C" int fvk_vae_conv_norm_bf16(const void* in, const void* w, const void* bias, void* out, const void* residual, int T, int H, int W,
                                       int Cin, int Cout, int KT, int ring, int ring_start, long out_frame_stride, long res_frame_stride,
                                       int upsample2x, const float* norm_gamma, void* norm_out, int norm_ring, int norm_slot0, int norm_silu,
                                       void* stream) {
     FVK_CHECK(in && w && norm_gamma && norm_out, FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: null pointer");
-    FVK_CHECK(T > 0 && H > 0 && W > 0 && Cout == 96, FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: Cout=%d (the fused norm serves the 96-channel stage)", Cout);
+    FVK_CHECK(T > 0 && H > 0 && W > 0 && (Cout == 96 || Cout == 192), FVK_ERR_ARG,
+              "fvk_vae_conv_norm_bf16: Cout=%d (the fused norm serves the 96- and 192-channel stages: one workgroup must hold all channels of a pixel)", Cout);
     FVK_CHECK(Cin > 0 && Cin % 32 == 0 && (KT == 1 || KT == 3), FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: Cin=%d KT=%d", Cin, KT);
     FVK_CHECK(!upsample2x || (KT == 1 && H % 2 == 0 && W % 2 == 0), FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: upsample2x needs KT=1 and even H, W");
     FVK_CHECK(ring >= T + KT - 1 && ring_start >= 0 && ring_start < ring, FVK_ERR_ARG, "fvk_vae_conv_norm_bf16: ring=%d too small (T=%d KT=%d)", ring, T, KT);

@@ -25,8 +25,9 @@ struct Conv3Args {
     int T, H, W, Hin, Win, Cin, Cout, KT;
     int ring, ring_start;
     int tiles_h, tiles_w, ntn;
-    // fused WanRMS_norm (+SiLU) of this conv's output into the CONSUMER conv's input ring (Cout == 96 only: one wave holds all channels of
-    // its 64 pixels): norm_out != NULL.  write_raw == 0 drops the un-normed store (conv1 -> norm2 -> conv2 inside a residual block).
+    // fused WanRMS_norm (+SiLU) of this conv's output into the CONSUMER conv's input ring: norm_out != NULL.  Cout == 96: one wave holds all
+    // channels of its 64 pixels; Cout == 192 (WNW = 2): the two waves of a pixel row pair hold 96 channels each and exchange their partial
+    // sums of squares through LDS (one extra barrier).  write_raw == 0 drops the un-normed store (conv1 -> norm2 -> conv2 in a residual block).
     const float* norm_gamma; bf16_t* norm_out;
     int norm_ring, norm_slot0, norm_silu, write_raw;
 };
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
                 *reinterpret_cast<bf16x4*>(st + (mb * 32 + l31) * EPI_PITCH + nl * 2) = y;
             }
         }
-    if (WNW == 1 && a.norm_out) {
+    if (a.norm_out) {
         // ---- fused RMS-norm (+SiLU): ref WanRMS_norm (wanvae.py:231-232) + SiLU (:418-419), same arithmetic as vae_norm12_kernel on the bf16-rounded
         // conv output: inv = sqrt(C) / max(||x||_2, 1e-12); out = bf16(silu(x * inv * gamma)).  The staged tile is wave-private and a wave's LDS
         // operations execute in order, so the passes below need no barrier.
@@ -334,7 +335,16 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
         }
-        const float inv = sqrtf(96.0f) / fmaxf(sqrtf(ss), 1e-12f);
+        if (WNW == 2) {
+            // the partner wave (same pixels, the other 96 channels) = wave ^ 1: swap partial sums through 2 KiB past the staging tiles
+            // (uniform branch: norm_out is a kernel argument, so all 8 waves reach the barrier)
+            float* xch = reinterpret_cast<float*>(smem + 8 * EPI_WAVE);
+            xch[wave * 64 + lane] = ss;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the write has left this wave before the barrier
+            __builtin_amdgcn_s_barrier();
+            ss += xch[(wave ^ 1) * 64 + lane];
+        }
+        const float inv = sqrtf((float)a.Cout) / fmaxf(sqrtf(ss), 1e-12f);
         int slot = a.norm_slot0 + t_out;
         slot = slot >= a.norm_ring ? slot - a.norm_ring : slot;
         slot = slot >= a.norm_ring ? slot - a.norm_ring : slot;
@@ -347,7 +357,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
             const int h = h0 + 2 * wrow + (px >> 5), w = w0 + (px & 31);
             if (h < a.H && w < a.W) {
                 const bf16x8 v = *reinterpret_cast<const bf16x8*>(st + px * EPI_PITCH + ch * 16);
-                const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.norm_gamma + ch * 8), g1 = *reinterpret_cast<const f32x4*>(a.norm_gamma + ch * 8 + 4);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.norm_gamma + wn * 96 + ch * 8), g1 = *reinterpret_cast<const f32x4*>(a.norm_gamma + wn * 96 + ch * 8 + 4);
                 bf16x8 y;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -357,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
                     if (a.norm_silu) r_ = r_ * __builtin_amdgcn_rcpf(1.0f + __expf(-r_));
                     y[e] = (bf16_t)r_;
                 }
-                st_bf16x8(a.norm_out + ((long)slot * HW + (long)h * a.W + w) * 96 + ch * 8, y);
+                st_bf16x8(a.norm_out + ((long)slot * HW + (long)h * a.W + w) * a.Cout + wn * 96 + ch * 8, y);
             }
         }
         return;

@@ -429,8 +429,8 @@ def vae_conv(inp, w, bias, *, T, H, W, kt, ks, ring_start=0, out=None, out_frame
 
 def vae_conv_norm(inp, w, bias, gamma, norm_ring_buf, *, T, H, W, kt, norm_slot0, ring_start=0, out=None, out_frame_stride=None, residual=None,
                   res_frame_stride=None, upsample2x=False, silu=True, want_raw=True):
-    """3x3-tap conv (Cout = 96) whose epilogue also writes WanRMS_norm(+SiLU) of the result into the consumer conv's input ring
-    (fvk_vae_conv_norm_bf16).  Returns the un-normed output [T,H,W,96] (None with want_raw=False: nothing but the ring is written)."""
+    """3x3-tap conv (Cout = 96 or 192) whose epilogue also writes WanRMS_norm(+SiLU) of the result into the consumer conv's input ring
+    (fvk_vae_conv_norm_bf16).  Returns the un-normed output [T,H,W,Cout] (None with want_raw=False: nothing but the ring is written)."""
     _chk(inp, BF16, "inp"), _chk(w, BF16, "w"), _chk(norm_ring_buf, BF16, "norm_ring_buf")
     gamma = _f32(gamma, "gamma")
     ring, Hin, Win, Cin = inp.shape

@@ -188,10 +188,10 @@ class WanVaeDecoderHip:
         return sites
 
     # ------------------------------------------------------------------ building blocks
-    FUSE_NORM_C = 96  # channel count whose RMS-norm + SiLU is fused into the producing conv's epilogue (fvk_vae_conv_norm_bf16)
+    FUSE_NORM_C = (96, 192)  # channel counts whose RMS-norm + SiLU is fused into the producing conv's epilogue (fvk_vae_conv_norm_bf16)
 
     def _can_fuse(self, conv: _Conv, nxt) -> bool:
-        return self.fuse_norm and nxt is not None and conv.w.shape[0] == self.FUSE_NORM_C and nxt[1].C == self.FUSE_NORM_C
+        return self.fuse_norm and nxt is not None and conv.w.shape[0] in self.FUSE_NORM_C and nxt[1].C == conv.w.shape[0]
 
     def _cached_conv(self, site: _Site, conv: _Conv, x, gamma, T, residual=None, out=None, out_f32=None, plane_stride=0, nxt=None,
                      want_raw=True):

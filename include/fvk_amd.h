@@ -257,8 +257,9 @@ int fvk_vae_conv_bf16(const void* in, const void* w, const void* bias, void* out
                       int H, int W, int Cin, int Cout, int KT, int KH, int KW, int ring, int ring_start, long out_frame_stride,
                       long res_frame_stride, long plane_stride, int upsample2x, int epilogue, void* stream);
 /* fvk_vae_conv_bf16 (3x3 spatial taps, bias [+ residual]) with the CONSUMER's WanRMS_norm (+ SiLU) fused into the epilogue, Cout == 96
- * (the full-resolution stage, where the separate norm pass moves 613 MB per call): the normalised tensor is written straight into the
- * consumer conv's input ring norm_out [norm_ring, H*W, 96] at frame slots (norm_slot0 + t) % norm_ring.  out == NULL drops the un-normed
+ * (the full-resolution stage, where the separate norm pass moves 613 MB per call) or 192 (the half-resolution stage: the two waves that
+ * hold a pixel's 192 channels swap their partial sums of squares through LDS): the normalised tensor is written straight into the
+ * consumer conv's input ring norm_out [norm_ring, H*W, Cout] at frame slots (norm_slot0 + t) % norm_ring.  out == NULL drops the un-normed
  * store (conv1 -> norm2 -> conv2 inside a residual block, wanvae.py:418-431); otherwise both are written (the raw tensor feeds the next
  * block's shortcut).  Arithmetic = fvk_vae_rmsnorm_silu_bf16 applied to the bf16-rounded conv output. */
 int fvk_vae_conv_norm_bf16(const void* in, const void* w, const void* bias, void* out, const void* residual, int T, int H, int W, int Cin,

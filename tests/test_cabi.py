@@ -48,8 +48,8 @@ def test_argument_checks_of_the_newer_entries(lib):
         lib.call("fvk_dmd_step", None, p, 0, p, None, None, p, None, 1, 8, None)
     with pytest.raises(RuntimeError, match="fvk_gather_rows_strided_bf16"):  # row stride smaller than the row
         lib.call("fvk_gather_rows_strided_bf16", p, p, None, None, 1, 4, 64, 32, 64, 0, 0, None)
-    with pytest.raises(RuntimeError, match="fvk_vae_conv_norm_bf16"):       # the fused norm serves Cout == 96 only
-        lib.call("fvk_vae_conv_norm_bf16", p, p, None, p, None, 1, 8, 8, 32, 192, 3, 3, 0, 0, 0, 0, p, p, 3, 0, 1, None)
+    with pytest.raises(RuntimeError, match="96- and 192-channel"):          # the fused norm needs all channels of a pixel in one workgroup
+        lib.call("fvk_vae_conv_norm_bf16", p, p, None, p, None, 1, 8, 8, 32, 384, 3, 3, 0, 0, 0, 0, p, p, 3, 0, 1, None)
     with pytest.raises(RuntimeError, match="fvk_vae_conv_norm_bf16"):       # consumer ring shorter than the chunk
         lib.call("fvk_vae_conv_norm_bf16", p, p, None, p, None, 4, 8, 8, 32, 96, 3, 6, 0, 0, 0, 0, p, p, 3, 0, 1, None)
     # round-2 entries: scattered / gathered row maps and the shared-list attention
