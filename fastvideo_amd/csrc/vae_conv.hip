@@ -453,6 +453,8 @@ extern "C" int fvk_vae_conv_bf16(const void* in, const void* w, const void* bias
     return launch_e<1>(a, epilogue, upsample2x != 0, (hipStream_t)stream);
 }
 
+int fvk_vae_conv_tunable() { return fvk::tunable(fvk::TUNE_VAE_CONV_IMPL); }
+
 // 3x3-tap conv with the consumer's RMS-norm (+SiLU) fused into the epilogue (Cout == 96 or 192): see include/fvk_amd.h
 extern "C" int fvk_vae_conv_norm_bf16(const void* in, const void* w, const void* bias, void* out, const void* residual, int T, int H, int W,
                                       int Cin, int Cout, int KT, int ring, int ring_start, long out_frame_stride, long res_frame_stride,

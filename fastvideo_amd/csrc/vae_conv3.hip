@@ -16,6 +16,9 @@
 // ref: WanCausalConv3d.forward (fastvideo/models/vaes/wanvae.py:198-207), WanResample (:277-284, :247-248), WanResidualBlock (:462),
 //      AutoencoderKLWan.decode's clamp (:1210-1211).
 #include "fvk_common.h"
+#include <type_traits>
+
+int fvk_vae_conv_tunable();  // vae_conv.hip: the "vae_conv_impl" measurement switch
 
 namespace {
 
@@ -33,6 +36,7 @@ struct Conv3Args {
 };
 
 enum { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_FINAL = 2 };
+constexpr unsigned OOB = 0xFFFFFF00u;  // a buffer offset past every descriptor's range: the load returns zeros
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {  // counted wait: at most N of this wave's VMEM operations still in flight
@@ -41,22 +45,33 @@ __device__ __forceinline__ void wait_vm() {  // counted wait: at most N of this 
 
 // NB = 32-channel output blocks per wave: 3 everywhere except conv_out (Cout = 3 <= 32, EPI_FINAL), whose NB = 1 instantiation does a third
 // of the padded MFMA work and stages a third of the weight rows.
-template <int WNW, int EPI, bool UPS, int NB = 3>
+// STAG (WNW = 1, NB = 3: the 96-channel full-resolution stage): the two waves of a SIMD run HALF A STEP APART.  With all eight waves in
+// lockstep every step ends with both waves of a SIMD parked at the barrier and the matrix pipe drained (s_memtime: 3300 cycles per step for
+// 2304 of MFMA).  Here waves 0-3 (group A) pass the step barrier at the END of their step and waves 4-7 (group B) in the MIDDLE of theirs,
+// so one of the two always has MFMAs in flight.  What makes that safe: a 4-deep weight ring (the slot A refills during step u was read in
+// step u-2, which B has left by A's barrier u-1), A issues all weight pieces (waited at the end of its next step), B issues all slab
+// pieces in the first halves of dh = 0, 1 (the buffer was last read in the previous slab, which A left before the barrier B passed in
+// mid-step 3s-1) and retires them before the barrier of mid-step dh = 2 — the one A passes before it starts the next slab.
+template <int WNW, int EPI, bool UPS, int NB = 3, bool STAG = false>
 __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(NB == 3 || (NB == 1 && WNW == 1 && EPI == EPI_FINAL && !UPS), "NB = 1 serves the final conv only");
+    static_assert(!STAG || (WNW == 1 && NB == 3), "the staggered schedule needs the 4-deep weight ring to fit: 96-channel tiles only");
     constexpr int TH = WNW == 1 ? 16 : 8, TW = 32;
     constexpr int TN = WNW * NB * 32;
     constexpr int HH = UPS ? TH / 2 + 2 : TH + 2, WW = UPS ? TW / 2 + 2 : TW + 2;  // halo slab in INPUT pixels
     constexpr int XPIECES = (HH * WW + 15) / 16;       // 16-pixel DMA pieces per slab
-    constexpr int XS = (XPIECES + 7) / 8;              // per wave (surplus = zero pieces inside the slab's padded tail)
+    constexpr int NIW = STAG ? 4 : 8;                  // waves that issue a given kind of piece (STAG: weights = group A, slabs = group B)
+    constexpr int XS = (XPIECES + NIW - 1) / NIW;      // per issuing wave (surplus = zero pieces inside the slab's padded tail)
     constexpr int XS0 = (XS + 1) / 2, XS1 = XS - XS0;  // issued during dh = 0 / dh = 1 of the previous slab
     constexpr int SLAB = XPIECES * 1024;               // surplus piece slots (q >= XPIECES) land in the scratch KiB
     constexpr int WPIECES = 3 * TN / 16;               // (dw, 16 n rows) pieces per weight step
-    constexpr int WS = (WPIECES + 7) / 8;
+    constexpr int WS = (WPIECES + NIW - 1) / NIW;
     constexpr int WSTEP = WPIECES * 1024;
     constexpr int W_BASE = 2 * SLAB;
-    constexpr int SCRATCH = W_BASE + 3 * WSTEP;        // 1 KiB landing zone of the surplus (dummy) pieces
+    constexpr int RW = STAG ? 4 : 3;                   // weight ring depth
+    constexpr int SCRATCH = W_BASE + RW * WSTEP;       // 1 KiB landing zone of the surplus (dummy) pieces
+    static_assert(!STAG || XS0 <= 6, "group B issues its slab pieces in the first half of a step: six slots");
     constexpr int EPI_PITCH = 208, EPI_WAVE = 64 * EPI_PITCH;
     static_assert(SCRATCH + 1024 <= 160 * 1024 && 8 * EPI_WAVE <= 160 * 1024, "LDS budget");  // the launch allocates the larger of ring / staging
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -67,6 +82,8 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int wrow = WNW == 1 ? wave : (wave >> 1), wn = WNW == 1 ? 0 : (wave & 1);  // wave: tile rows 2*wrow, 2*wrow+1; n offset 96*wn
+    const int grp = STAG ? (wave >> 2) : 0;   // STAG: waves 0-3 = group A (weights), 4-7 = group B (slabs); w and w+4 share a SIMD
+    const int iw = STAG ? (wave & 3) : wave;  // index among the waves that issue this wave's kind of piece
 
     // tile id (n fastest so that consecutive workgroups share the halo slab in L2)
     int bid = blockIdx.x;
@@ -81,14 +98,13 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
         (void*)a.in, 0, (unsigned)((long)a.ring * a.Hin * a.Win * a.Cin * 2), 0x00020000);
     const int Ktot = a.KT * 9 * a.Cin;
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)((long)a.Cout * Ktot * 2), 0x00020000);
-    constexpr unsigned OOB = 0xFFFFFF00u;
     const int chunk16 = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
     const int CinB = a.Cin * 2;
     const int hb = UPS ? (h0 >> 1) - 1 : h0 - 1, wb = UPS ? (w0 >> 1) - 1 : w0 - 1;  // input coordinates of slab pixel (0, 0)
     unsigned xvo_[XS];
 #pragma unroll
     for (int i = 0; i < XS; ++i) {
-        const int p = (wave + 8 * i) * 16 + (lane >> 2);
+        const int p = (iw + NIW * i) * 16 + (lane >> 2);
         const int hh = p / WW, ww = p - hh * WW;
         const int h = hb + hh, w = wb + ww;
         const bool ok = hh < HH && (unsigned)h < (unsigned)a.Hin && (unsigned)w < (unsigned)a.Win;
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
     int wdw_[WS];
 #pragma unroll
     for (int j = 0; j < WS; ++j) {
-        const int q = wave + 8 * j;
+        const int q = iw + NIW * j;
         const int dw = q / (TN / 16), nb16 = q - dw * (TN / 16);
         const int n = n0 + nb16 * 16 + (lane >> 2);
         wvo_[j] = (q < WPIECES && n < a.Cout) ? (unsigned)((long)n * Ktot * 2) + chunk16 : OOB;
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
     {                                                                                                               \
         const bool live_ = xn_s < nslab;                                                                            \
         const unsigned so_ = __builtin_amdgcn_readfirstlane(live_ ? (unsigned)slot_of(xn_dt) * frameB + (unsigned)xn_cc * 64u : 0u); \
-        const int q_ = wave + 8 * (I);                                                                              \
+        const int q_ = iw + NIW * (I);                                                                              \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + (q_ < XPIECES ? (xn_s & 1) * SLAB + q_ * 1024 : SCRATCH)), 16, \
                                                  live_ ? xvo_[I] : OOB, so_, 0, 0);                                 \
     }
@@ -130,11 +146,11 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
         const bool live_ = wn_u < nstep;                                                                            \
         const unsigned so_ = __builtin_amdgcn_readfirstlane(                                                        \
             live_ ? (unsigned)((((wn_dt * 3 + wn_dh) * 3) * a.Cin + wn_cc * 32) * 2) + (unsigned)wdw_[J] * dwB : 0u); \
-        const int q_ = wave + 8 * (J);                                                                              \
+        const int q_ = iw + NIW * (J);                                                                              \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + (q_ < WPIECES ? W_BASE + wn_slot * WSTEP + q_ * 1024 : SCRATCH)), 16, \
                                                  live_ ? wvo_[J] : OOB, so_, 0, 0);                                 \
     }
-#define C3_ADVANCE_W() { ++wn_u; wn_slot = wn_slot == 2 ? 0 : wn_slot + 1; if (++wn_dh == 3) { wn_dh = 0; if (++wn_cc == cpt) { wn_cc = 0; ++wn_dt; } } }
+#define C3_ADVANCE_W() { ++wn_u; wn_slot = wn_slot == RW - 1 ? 0 : wn_slot + 1; if (++wn_dh == 3) { wn_dh = 0; if (++wn_cc == cpt) { wn_cc = 0; ++wn_dt; } } }
     int wn_slot = 0;
 
     // ---- per-lane slab pixel of output pixel (row 2*wrow + mb, column l31) under tap (dh, dw): p = rowt[mb][dh] + colt[dw] -----------
@@ -160,16 +176,23 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ---- prologue: slab 0 and weight steps 0, 1 in flight; slab 0 + step 0 landed ----------------------------------------------------
+    if (!STAG || grp == 1) {
 #pragma unroll
-    for (int i = 0; i < XS; ++i) C3_ISSUE_X(i)
+        for (int i = 0; i < XS; ++i) C3_ISSUE_X(i)
+    }
     C3_ADVANCE_X()
+    if (!STAG || grp == 0) {
 #pragma unroll
-    for (int j = 0; j < WS; ++j) C3_ISSUE_W(j)
+        for (int j = 0; j < WS; ++j) C3_ISSUE_W(j)
+    }
     C3_ADVANCE_W()
+    if (!STAG || grp == 0) {
 #pragma unroll
-    for (int j = 0; j < WS; ++j) C3_ISSUE_W(j)
+        for (int j = 0; j < WS; ++j) C3_ISSUE_W(j)
+    }
     C3_ADVANCE_W()
-    wait_vm<WS>();
+    if (!STAG || grp == 0) wait_vm<WS>();  // STAG: group A holds only weight pieces: step 0 landed, step 1 in flight
+    else wait_vm<0>();                     // STAG: group B holds only slab 0
     __builtin_amdgcn_s_barrier();
 
 #ifdef FVK_C3_PROBE  // timing probe build: workgroup 0 sums s_memtime deltas per step phase into out_f32 (as uint64) — EPI_BIAS launches only
@@ -184,6 +207,10 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
 #define C3_STAMP(K)
 #endif
     int u = 0, rd_slot = 0;
+    // The K loop, instantiated once per schedule role so that each role is one straight-line loop (an if / else on the wave group INSIDE the
+    // unrolled steps made hipcc spill 120-150 VGPRs): MODE 0 = lockstep, 1 = STAG group A, 2 = STAG group B.
+    auto kloop = [&](auto mode_) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_)::value;
     for (int s = 0; s < nslab; ++s) {
         const unsigned char* xs = smem + (s & 1) * SLAB;
 #pragma unroll
@@ -201,51 +228,80 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
             xf[BUF][(R) - NB] = *reinterpret_cast<const bf16x8*>(xs + p_ * 64 + ((c_ ^ ((p_ >> 2) & 3)) << 4));    \
         }                                                                                                           \
     }
-#pragma unroll
-            for (int r = 0; r < NB + 2; ++r) C3_READ(0, 0, r)
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int g = 0; g < 6; ++g) {
-#pragma unroll
-                for (int i = 0; i < 2 * NB; ++i) {
-                    const int nb = i >> 1, mb = i & 1;
-                    acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g & 1][nb], xf[g & 1][mb], acc[nb][mb], 0, 0, 0);
-                    if (NB == 3) {
-                        if (g < 5 && i < 5) C3_READ(g + 1, (g + 1) & 1, i)
-                    } else if (g < 5) {  // NB = 1: three fragment reads behind two MFMAs
-                        if (i == 0) { C3_READ(g + 1, (g + 1) & 1, 0) C3_READ(g + 1, (g + 1) & 1, 1) }
-                        else C3_READ(g + 1, (g + 1) & 1, 2)
-                    }
-                    // this wave's DMA pieces ride in the gaps: weights of step u+2 (its ring slot was read in step u-1), and the
-                    // next slab (its buffer was read in the previous slab) during dh = 0 and 1 so that it has landed by this slab's end
-                    if (NB == 3 ? (i == 2 || i == 4) : true) {
-                        const int k = NB == 3 ? 2 * g + (i == 4) : 2 * g + i;  // two issue slots per group, 12 per step
-                        if (k < WS) C3_ISSUE_W(k)
-                        else if (dh == 0 && k - WS < XS0) C3_ISSUE_X(k - WS)
-                        else if (dh == 1 && k - WS < XS1) C3_ISSUE_X(XS0 + (k - WS))
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            __builtin_amdgcn_s_setprio(0);
+            // MODE 0: lockstep (every wave issues its share of both kinds of piece); 1: STAG group A (weights); 2: STAG group B (slabs in the
+            // first half of dh = 0, 1; the step barrier in MID-step, after the third fragment group)
+#define C3_STREAM(MODE)                                                                                             \
+    {                                                                                                               \
+        _Pragma("unroll") for (int r = 0; r < NB + 2; ++r) C3_READ(0, 0, r)                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                          \
+        __builtin_amdgcn_s_setprio(1);                                                                              \
+        _Pragma("unroll") for (int g = 0; g < 6; ++g) {                                                             \
+            _Pragma("unroll") for (int i = 0; i < 2 * NB; ++i) {                                                    \
+                const int nb = i >> 1, mb = i & 1;                                                                  \
+                acc[nb][mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[g & 1][nb], xf[g & 1][mb], acc[nb][mb], 0, 0, 0); \
+                if (NB == 3) {                                                                                      \
+                    if (g < 5 && i < 5) C3_READ(g + 1, (g + 1) & 1, i)                                              \
+                } else if (g < 5) { /* NB = 1: three fragment reads behind two MFMAs */                             \
+                    if (i == 0) { C3_READ(g + 1, (g + 1) & 1, 0) C3_READ(g + 1, (g + 1) & 1, 1) }                   \
+                    else C3_READ(g + 1, (g + 1) & 1, 2)                                                             \
+                }                                                                                                   \
+                /* this wave's DMA pieces ride in the gaps: weights of step u+2 (lockstep: its ring slot was read in step u-1), and the   \
+                   next slab (its buffer was read in the previous slab) during dh = 0 and 1 so that it has landed by this slab's end */ \
+                if (NB == 3 ? (i == 2 || i == 4) : true) {                                                          \
+                    const int k = NB == 3 ? 2 * g + (i == 4) : 2 * g + i; /* two issue slots per group, 12 per step */ \
+                    if ((MODE) == 0) {                                                                              \
+                        if (k < WS) C3_ISSUE_W(k)                                                                   \
+                        else if (dh == 0 && k - WS < XS0) C3_ISSUE_X(k - WS)                                        \
+                        else if (dh == 1 && k - WS < XS1) C3_ISSUE_X(XS0 + (k - WS))                                \
+                    } else if ((MODE) == 1) {                                                                       \
+                        if (k < WS) C3_ISSUE_W(k)                                                                   \
+                    } else {                                                                                        \
+                        if (dh == 0 && k < XS0) C3_ISSUE_X(k)                                                       \
+                        else if (dh == 1 && k < XS1) C3_ISSUE_X(XS0 + k)                                            \
+                    }                                                                                               \
+                }                                                                                                   \
+                __builtin_amdgcn_sched_barrier(0);                                                                  \
+            }                                                                                                       \
+            if ((MODE) == 2 && g == 2) { /* group B's step barrier: the slab pieces of dh = 0, 1 retire before the one of dh = 2 */ \
+                __builtin_amdgcn_s_setprio(0);                                                                      \
+                if (dh == 2) wait_vm<0>();                                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                                  \
+                __builtin_amdgcn_s_barrier();                                                                       \
+                __builtin_amdgcn_sched_barrier(0);                                                                  \
+                __builtin_amdgcn_s_setprio(1);                                                                      \
+            }                                                                                                       \
+        }                                                                                                           \
+        __builtin_amdgcn_s_setprio(0);                                                                              \
+    }
+            C3_STREAM(MODE)
+#undef C3_STREAM
             C3_ADVANCE_W()
             if (dh == 1) C3_ADVANCE_X()
-            rd_slot = rd_slot == 2 ? 0 : rd_slot + 1;
+            rd_slot = rd_slot == RW - 1 ? 0 : rd_slot + 1;
 #undef C3_READ
             // everything issued before this step has landed (only this step's own pieces may still be in flight)
             C3_STAMP(1)
-            static_assert(WS + XS0 <= 12, "DMA issue slots per step exhausted");
-            if (dh == 0) wait_vm<WS + XS0>();
-            else if (dh == 1) wait_vm<WS + XS1>();
-            else wait_vm<WS>();
+            static_assert(STAG || WS + XS0 <= 12, "DMA issue slots per step exhausted");
+            if (MODE == 0) {
+                if (dh == 0) wait_vm<WS + XS0>();
+                else if (dh == 1) wait_vm<WS + XS1>();
+                else wait_vm<WS>();
+            } else if (MODE == 1) {
+                wait_vm<WS>();  // group A: the weights issued in the previous step (for step u+1) have landed; this step's own fly on
+            }
             C3_STAMP(2)
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
+            if (MODE != 2) {  // (group B passed this step's barrier in mid-step)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
             C3_STAMP(3)
         }
     }
+    };  // kloop
+    if (!STAG) kloop(std::integral_constant<int, 0>{});
+    else if (grp == 0) kloop(std::integral_constant<int, 1>{});
+    else kloop(std::integral_constant<int, 2>{});
 #undef C3_ISSUE_X
 #undef C3_ISSUE_W
 #undef C3_ADVANCE_X
@@ -392,16 +448,16 @@ __global__ __launch_bounds__(512, 2) void vae_conv3_kernel(Conv3Args a) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int WNW, int EPI, bool UPS, int NB = 3>
+template <int WNW, int EPI, bool UPS, int NB = 3, bool STAG = false>
 int launch3(Conv3Args a, hipStream_t s) {
     constexpr int TH = WNW == 1 ? 16 : 8;
     constexpr int TN = WNW * NB * 32;
     constexpr int HH = UPS ? TH / 2 + 2 : TH + 2, WW = UPS ? 18 : 34;
-    constexpr int RING = 2 * ((HH * WW + 15) / 16) * 1024 + 3 * (3 * TN / 16) * 1024 + 1024;
+    constexpr int RING = 2 * ((HH * WW + 15) / 16) * 1024 + (STAG ? 4 : 3) * (3 * TN / 16) * 1024 + 1024;
     constexpr int LDS = RING > 8 * 64 * 208 ? RING : 8 * 64 * 208;  // epilogue staging reuses the ring
     static bool configured[FVK_MAX_DEVICES] = {};
     if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)vae_conv3_kernel<WNW, EPI, UPS, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)vae_conv3_kernel<WNW, EPI, UPS, NB, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             fvk_set_error("fvk_vae_conv_bf16 (3x3): cannot set dynamic LDS size %d", LDS);
             return FVK_ERR_LAUNCH;
         }
@@ -410,25 +466,34 @@ int launch3(Conv3Args a, hipStream_t s) {
     a.tiles_w = (a.W + 31) / 32;
     a.ntn = (a.Cout + TN - 1) / TN;
     const long nwg = (long)a.T * a.tiles_h * a.tiles_w * a.ntn;
-    hipLaunchKernelGGL((vae_conv3_kernel<WNW, EPI, UPS, NB>), dim3((unsigned)nwg), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((vae_conv3_kernel<WNW, EPI, UPS, NB, STAG>), dim3((unsigned)nwg), dim3(512), LDS, s, a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
 
-template <int WNW>
-int launch3_e(const Conv3Args& a, int epi, bool ups, hipStream_t s) {
+template <int WNW, bool STAG>
+int launch3_s(const Conv3Args& a, int epi, bool ups, hipStream_t s) {
     if (ups) {
         switch (epi) {
-            case EPI_BIAS: return launch3<WNW, EPI_BIAS, true>(a, s);
-            case EPI_RESIDUAL: return launch3<WNW, EPI_RESIDUAL, true>(a, s);
-            default: return launch3<WNW, EPI_FINAL, true>(a, s);
+            case EPI_BIAS: return launch3<WNW, EPI_BIAS, true, 3, STAG>(a, s);
+            case EPI_RESIDUAL: return launch3<WNW, EPI_RESIDUAL, true, 3, STAG>(a, s);
+            default: return launch3<WNW, EPI_FINAL, true, 3, STAG>(a, s);
         }
     }
     switch (epi) {
-        case EPI_BIAS: return launch3<WNW, EPI_BIAS, false>(a, s);
-        case EPI_RESIDUAL: return launch3<WNW, EPI_RESIDUAL, false>(a, s);
-        default: return launch3<WNW, EPI_FINAL, false>(a, s);
+        case EPI_BIAS: return launch3<WNW, EPI_BIAS, false, 3, STAG>(a, s);
+        case EPI_RESIDUAL: return launch3<WNW, EPI_RESIDUAL, false, 3, STAG>(a, s);
+        default: return launch3<WNW, EPI_FINAL, false, 3, STAG>(a, s);
     }
+}
+
+template <int WNW>
+int launch3_e(const Conv3Args& a, int epi, bool ups, hipStream_t s) {
+    // 96-channel tiles: the staggered schedule (shipped); "vae_conv_impl" 2 = the lockstep schedule, for A/B
+    if constexpr (WNW == 1) {
+        if (fvk_vae_conv_tunable() != 2) return launch3_s<1, true>(a, epi, ups, s);
+    }
+    return launch3_s<WNW, false>(a, epi, ups, s);
 }
 
 }  // namespace
