@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfvk_amd.so")
-SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.hip", "fp8.hip", "attn_fwd.hip", "attn_pp.hip", "attn_pp2.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_post.hip", "sched_step.hip"]
+SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.hip", "fp8.hip", "attn_fwd.hip", "attn_pp.hip", "attn_pp2.hip", "attn_vsa.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_post.hip", "sched_step.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 FLAGS += os.environ.get("FVK_EXTRA_FLAGS", "").split()  # measurement builds only (e.g. -DFVK_ST_ABL=1 timing ablations)
 

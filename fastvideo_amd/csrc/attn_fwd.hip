@@ -29,8 +29,15 @@ struct fvk_pp2_lists {  // attn_pp2.hip: 256-row workgroups over shared KV block
     int plain_ids;
 };
 int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);
+int fvk_attn_vsa_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
+                        hipStream_t s);  // attn_vsa.hip: 64-row lists, key-split, register-staged prefetch
 
 namespace {
+
+template <int N>
+__device__ __forceinline__ void wait_vm_n() {  // counted wait: at most N of this wave's VMEM operations still in flight
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 
 enum { MODE_DENSE = 0, MODE_BLOCKS = 1, MODE_STA = 2 };
 
@@ -72,7 +79,14 @@ template <int DK> struct KGeom {
 // 4-7 the loaders, so the in-order wave -> SIMD placement puts exactly one compute and one loader wave on every SIMD.  (Two
 // independent 4-wave workgroups per CU — the PAIRS = 1 form — land their compute waves on the SAME two SIMDs and leave the other
 // two matrix pipes to the loaders.)  The two pairs share the per-tile barrier and run max(list lengths) iterations.
-template <int NW, int MODE, int DK, int NL, int PAIRS = 1>
+// RSTG (loader waves only): REGISTER-STAGED prefetch.  The LDS-DMA form keeps exactly one stage per list in flight (the other is being read),
+// and the block-sparse kernel's tile time equals the loaded arrival latency (~2 900 cycles, profiles/r02_vsa_block_sparse_ab.md) — LDS
+// (159 of 160 KiB) has no room for a third stage, but the loader waves' register files sit idle.  Here a loader wave fetches its share
+// of a tile global -> VGPR (buffer_load_dwordx4, same per-lane offsets as the DMA pieces) NSET tiles before the stage that will hold it
+// is free, and copies it into the stage with ds_write_b128 (data long arrived: ~300 cycles per tile) right after the barrier that frees
+// it.  Same LDS image, same one barrier per tile, compute waves untouched; loads are retired with counted vmcnt (tiles past the end of a
+// list re-read its last tile so that the counts stay constant).
+template <int NW, int MODE, int DK, int NL, int PAIRS = 1, bool RSTG = false>
 __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1 : 2)) void attn_fwd_kernel(fvk_attn_args a, ModeArgs ma) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the body uses gfx950 LDS-DMA builtins the host pass cannot parse
     constexpr int K_ROW_BYTES = KGeom<DK>::ROW_BYTES, KC = KGeom<DK>::CHUNKS, K_TILE_BYTES = KGeom<DK>::TILE_BYTES;
@@ -248,26 +262,84 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
         }                                                                                                    \
     }
 
-    int kv0 = 0, valid = 64, kv0_n = 0, valid_n = 64;
-    if (n_tiles > 0) {
-        get_tile(0, kv0, valid);
-        if (loader) ISSUE_DMA(kv0, smem_p)
-    }
-    __syncthreads();
-
     int n_loop = n_tiles;  // the workgroup's barrier count: the longer of the two lists
     if (PAIRS == 2 && MODE == MODE_BLOCKS) {
         const int qo = qb ^ 1;
         const int n_other = qo < nqb ? ma.q2k_num[((long)b * a.H + h) * nqb + qo] : 0;
         n_loop = n_other > n_loop ? n_other : n_loop;
     }
+    if (RSTG && NL > 0 && !compute) {
+        // ---- loader wave, register-staged: tile t travels in register set t % NSET; at iteration j the set of tile j+1 is copied into
+        // stage (j+1)&1 (free since the barrier that ended iteration j-1) and refilled with tile j+1+NSET ----------------------------------
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        constexpr int NSET = 2;
+        u32x4_t rb[NSET][N_DMA];
+        int tk0, tvalid;
+#define RS_LOAD(SET, T)                                                                                              \
+    {                                                                                                                \
+        get_tile((T) < n_tiles ? (T) : n_tiles - 1, tk0, tvalid);                                                    \
+        const int ks_ = __builtin_amdgcn_readfirstlane(tk0 * k_tile_stride);                                         \
+        const int vs_ = __builtin_amdgcn_readfirstlane(tk0 * 2);                                                     \
+        _Pragma("unroll") for (int i = 0; i < N_DMA; ++i) {                                                          \
+            const int t_ = i * NI + iw;                                                                              \
+            if (t_ < KC) rb[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, dma_voff[i], ks_, 0);            \
+            else rb[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, t_ < KC + 18 ? dma_voff[i] : (int)0x7fffff00, vs_, 0); \
+        }                                                                                                            \
+    }
+#define RS_STORE(SET, ST)                                                                                            \
+    {                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < N_DMA; ++i) {                                                          \
+            const int t_ = i * NI + iw;                                                                              \
+            if (t_ < KC + 18) *reinterpret_cast<u32x4_t*>((ST) + t_ * 1024 + lane * 16) = rb[SET][i];                \
+        }                                                                                                            \
+    }
+#define RS_BARRIER()                                             \
+    {                                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+        __builtin_amdgcn_s_barrier();                            \
+    }
+        if (n_tiles > 0) {
+#pragma unroll
+            for (int t = 0; t < NSET; ++t) RS_LOAD(t, t)
+            wait_vm_n<(NSET - 1) * N_DMA>();  // tile 0 landed
+            RS_STORE(0, smem_p)
+            RS_LOAD(0, NSET)
+        }
+        RS_BARRIER()
+        for (int j0 = 0; j0 < n_loop; j0 += NSET) {
+#pragma unroll
+            for (int k = 0; k < NSET; ++k) {
+                const int j = j0 + k;  // tile j+1 sits in set (j+1) % NSET = (k+1) % NSET (j0 is a multiple of NSET)
+                if (j < n_loop) {
+                    if (j + 1 < n_tiles) {
+                        wait_vm_n<(NSET - 1) * N_DMA>();  // everything but the NSET-1 youngest tiles has landed
+                        RS_STORE((k + 1) % NSET, smem_p + ((j + 1) & 1) * STAGE_BYTES)
+                        RS_LOAD((k + 1) % NSET, j + 1 + NSET)
+                    }
+                    RS_BARRIER()
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail re-reads
+        return;
+#undef RS_LOAD
+#undef RS_STORE
+#undef RS_BARRIER
+    }
+    int kv0 = 0, valid = 64, kv0_n = 0, valid_n = 64;
+    if (n_tiles > 0) {
+        get_tile(0, kv0, valid);
+        if (loader && !RSTG) ISSUE_DMA(kv0, smem_p)
+    }
+    __syncthreads();
+
     for (int j = 0; j < n_loop; ++j) {
         const unsigned char* cur = smem_p + (j & 1) * STAGE_BYTES;
         const bool more = (j + 1) < n_tiles;
         if (more) {
             get_tile(j + 1, kv0_n, valid_n);
             unsigned char* nxt = smem_p + ((j + 1) & 1) * STAGE_BYTES;
-            if (loader) ISSUE_DMA(kv0_n, nxt)
+            if (loader && !RSTG) ISSUE_DMA(kv0_n, nxt)
         }
         if (compute && j < n_tiles) {
         // ---- S^T = K · Q^T  (2 key blocks of 32 x KS k-steps of 16): one software-pipelined stream, every ds_read_b128 issued FD MFMAs
@@ -415,14 +487,14 @@ int check_common(const fvk_attn_args* a, const char* fn) {
     return FVK_OK;
 }
 
-template <int NW, int MODE, int DK = 128, int NL = 0, int PAIRS = 1>
+template <int NW, int MODE, int DK = 128, int NL = 0, int PAIRS = 1, bool RSTG = false>
 int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
     constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES;
     constexpr int LDS = PAIRS * 2 * STAGE_BYTES + (MODE == MODE_BLOCKS ? PAIRS * 2048 * 4 : 0);  // + the KV lists (LIST_CAP entries each)
     static_assert(LDS <= 163840, "LDS budget");
     static bool configured[FVK_MAX_DEVICES] = {};
     if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE, DK, NL, PAIRS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE, DK, NL, PAIRS, RSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
             hipSuccess) {
             fvk_set_error("fvk_attn: cannot set dynamic LDS size");
             return FVK_ERR_LAUNCH;
@@ -431,7 +503,7 @@ int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
     const int bmq = NW * 32;
     const long nlists = (MODE == MODE_BLOCKS && ma.q_stride) ? ma.n_lists : (a->Sq + bmq - 1) / bmq;
     const long nblk = ((nlists + PAIRS - 1) / PAIRS) * a->H * a->B;
-    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE, DK, NL, PAIRS>), dim3((unsigned)nblk), dim3(PAIRS * (NW + NL) * 64), LDS, s, *a, ma);
+    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE, DK, NL, PAIRS, RSTG>), dim3((unsigned)nblk), dim3(PAIRS * (NW + NL) * 64), LDS, s, *a, ma);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -480,7 +552,16 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     }
     // 64-row lists (the VSA block): two lists per 8-wave workgroup, each with 2 compute + 2 loader waves ("attn_impl" 50 = the former
     // one-list 4-wave workgroups, two per CU, for A/B)
-    if (fvk::tunable(fvk::TUNE_ATTN_IMPL) == 50) return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);
+    const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
+    if (impl == 50) return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);
+    // Shipped: two lists per workgroup, 2 compute + 2 loader waves each, one-stage-ahead LDS-DMA.  Two alternatives were built to attack what
+    // looked like its limits and are kept for A/B because BOTH land on the same ~23 B / clock / CU of K / V^T ingest (2.55-2.60 ms at cfg2):
+    //   53 = the same kernel with register-staged loader waves, two tiles ahead (2.66-2.72 ms, bit-identical output)
+    //   54 = attn_vsa.hip: all 8 waves compute (row half x KEY half per wave: two compute waves per SIMD), register-staged, two tiles ahead
+    //        (2.93 ms, agrees to rounding)
+    // i.e. neither the prefetch depth nor the single compute wave per SIMD is the bound; the per-CU ingest rate is.
+    if (impl == 53) return launch<2, MODE_BLOCKS, 128, 2, 2, true>(a, ma, (hipStream_t)stream);
+    if (impl == 54 && max_kv <= 2048) return fvk_attn_vsa_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, (hipStream_t)stream);
     return launch<2, MODE_BLOCKS, 128, 2, 2>(a, ma, (hipStream_t)stream);
 }
 

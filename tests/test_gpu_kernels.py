@@ -259,6 +259,41 @@ def test_attn_block_sparse(ops):
     assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
 
 
+@pytest.mark.parametrize("impl", [53, 54])
+def test_attn_block_sparse_measurement_variants(ops, impl):
+    """The two A/B variants of the 64-row list kernel kept in the library ("attn_impl" 53: register-staged loader waves, bit-identical to
+    the shipped kernel; 54: attn_vsa.hip, all waves compute, key-split with a final merge: equal to rounding) on ragged block sizes, odd
+    list counts (an unpaired last list), an empty list and lists from 1 to 9 tiles, against the oracle and the shipped kernel."""
+    B, H, nq, nk = 1, 3, 7, 9
+    q, k, v = rnd((B, H, nq * 64, 128), 1), rnd((B, H, nk * 64, 128), 2), rnd((B, H, nk * 64, 128), 3)
+    rng = np.random.default_rng(impl)
+    bm = rng.random((B, H, nq, nk)) < 0.5
+    bm[..., 0] = True
+    bm[0, 0, 2, :] = False
+    bm[0, 0, 2, 4] = True          # a one-tile list
+    bm[0, 1, 3, :] = True          # all nine
+    bm[0, 2, 5, :] = False         # an empty list
+    vbs = np.array([64, 64, 48, 64, 1, 33, 24, 64, 17], dtype=np.int32)
+    ref = torch.nan_to_num(V.block_sparse_attn(q, k, v, bm, vbs), nan=0.0)
+    idx, num = V.map_to_index(bm)
+    args = (q.to(DEV), k.to(DEV), v.to(DEV), torch.from_numpy(idx).to(DEV), torch.from_numpy(num).to(DEV), torch.from_numpy(vbs).to(DEV))
+    base, base_lse = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
+    ops.set_tunable("attn_impl", impl)
+    try:
+        out, lse = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
+    finally:
+        ops.set_tunable("attn_impl", 0)
+    _attn_check(out, ref, f"block sparse, attn_impl {impl}")
+    assert (out[0, 2, 5 * 64:6 * 64] == 0).all()
+    if impl == 53:
+        assert torch.equal(out, base) and torch.equal(lse, base_lse)
+    else:
+        live = torch.ones(nq, dtype=torch.bool); live_h2 = live.clone(); live_h2[5] = False
+        assert (out.float() - base.float()).abs().max().item() < 8e-3
+        sel = lse[0, 2].view(nq, 64)[live_h2.to(DEV)]
+        assert (sel - base_lse[0, 2].view(nq, 64)[live_h2.to(DEV)]).abs().max().item() < 1e-3
+
+
 @pytest.mark.parametrize("rows", [256, 384, 512])
 def test_attn_tile_lists_shared_kv_lists(ops, rows):
     """fvk_attn_tile_lists_bf16: every `rows` consecutive query rows share one list of 64-key blocks (sliding-tile windows).  Against the
