@@ -90,6 +90,35 @@ def test_sliding_tile_attention_full_grid(ops, lists):
     assert 0.15 < mask.float().mean().item() < 0.45   # the window really is sparse
 
 
+def test_sliding_tile_attention_129f_720p_grid_properties(ops):
+    """BASELINE config 5's token grid (33,45,80) = 118 800 tokens through the shipped sliding-tile path (queries packed by window class, 128
+    window classes, 256-row workgroups over KV block lists), 4 heads: rows of P sum to one (V = 1 -> O = 1 for every real token: every list
+    covers its whole window, every partially filled block is masked at its size) and 128 sampled rows against the masked fp32 form."""
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    from oracle import vsa_oracle as V
+    grid, tile, win, Hh = (33, 45, 80), (6, 8, 8), (3, 3, 3), 4
+    Sg = math.prod(grid)
+    m = WanTransformer3DModelHip.__new__(WanTransformer3DModelHip)
+    m.attention, m.sta_tile, m.sta_window, m.D, m.device, m._vsa_cache, m.attn_events = "sta", tile, win, D, torch.device("cuda"), {}, None
+    m.sta_lists = "grouped"
+    g = torch.Generator(device="cuda").manual_seed(6)
+    q, k, v = (torch.randn((Sg, Hh, D), generator=g, device="cuda").bfloat16() for _ in range(3))
+    o1 = m._attn_local(q, k, torch.ones_like(v), Sg, grid)
+    assert (o1.float() - 1).abs().max().item() < 1e-2
+    o = m._attn_local(q, k, v, Sg, grid)
+    rows = torch.randperm(Sg, generator=torch.Generator().manual_seed(8))[:128].sort().values
+    nt = tuple(-(-a // b) for a, b in zip(grid, tile))
+    coord = torch.stack(torch.meshgrid(*[torch.arange(n) for n in grid], indexing="ij"), -1).reshape(-1, 3)
+    tcoord = coord // torch.tensor(tile)
+    mask = torch.ones((len(rows), Sg), dtype=torch.bool)
+    for ax in range(3):
+        win_t = torch.tensor([V.sta_window(q_, nt[ax], win[ax]) for q_ in range(nt[ax])])
+        lo, hi = win_t[tcoord[rows, ax], 0], win_t[tcoord[rows, ax], 1]
+        mask &= (tcoord[None, :, ax] >= lo[:, None]) & (tcoord[None, :, ax] < hi[:, None])
+    ref = _attn_ref_rows(q[None], k[None], v[None], rows.cuda(), mask.cuda())
+    _bounded((o[rows.cuda()].float() - ref).abs(), ref, "sliding-tile attention, grid 33x45x80")
+
+
 @pytest.mark.parametrize("name,N,K,epi", [("qkv", 3 * d, d, "none"), ("ffn_in", F, d, "gelu"), ("ffn_out", d, F, "resgate")])
 def test_gemm_full_size_sampled_rows(ops, name, N, K, epi):
     g = torch.Generator(device="cuda").manual_seed(4)

@@ -347,6 +347,25 @@ def test_attn_tile_lists_shared_kv_lists(ops, rows):
                                 o_rows=torch.zeros(nl * rows, dtype=torch.int32, device=DEV), n_out_rows=nl * rows)
 
 
+def test_attn_tile_lists_batch_and_head_specific_lists(ops):
+    """B = 2, H = 3 with a DIFFERENT list for every (batch, head, group): the list and count arrays are indexed [b, h, list]."""
+    B, H, nl, nk, rows = 2, 3, 3, 8, 256
+    q, k, v = rnd((B, H, nl * rows, 128), 11), rnd((B, H, nk * 64, 128), 12), rnd((B, H, nk * 64, 128), 13)
+    rng = np.random.default_rng(5)
+    bm = rng.random((B, H, nl, nk)) < 0.5
+    bm[..., 3] = True
+    vbs = np.array([64, 10, 64, 64, 64, 40, 64, 64], dtype=np.int32)
+    idx, num = V.map_to_index(bm)
+    assert len({tuple(idx[b_, h_, l_, :num[b_, h_, l_]]) for b_ in range(B) for h_ in range(H) for l_ in range(nl)}) > 12
+    ref = V.block_sparse_attn(q, k, v, np.repeat(bm, rows // 64, axis=2), vbs)
+    dv = lambda t: torch.from_numpy(t).to(DEV)
+    out = ops.attn_tile_lists(q.to(DEV), k.to(DEV), v.to(DEV), dv(idx), dv(num), dv(vbs), rows, None, layout="bhsd")
+    _attn_check(out, ref, "tile lists, per-(batch, head) lists")
+    out_s = ops.attn_tile_lists(q.transpose(1, 2).contiguous().to(DEV), k.transpose(1, 2).contiguous().to(DEV),
+                                v.transpose(1, 2).contiguous().to(DEV), dv(idx), dv(num), dv(vbs), rows, None, layout="bshd")
+    assert torch.equal(out_s.transpose(1, 2), out)   # the two layouts differ in strides only
+
+
 def test_attn_tile_lists_refuses_bad_geometry(ops):
     q, k, v = rnd((1, 1, 768, 128), 1).to(DEV), rnd((1, 1, 256, 128), 2).to(DEV), rnd((1, 1, 256, 128), 3).to(DEV)
     idx, num, vbs = torch.zeros((1, 1, 2, 4), dtype=torch.int32, device=DEV), torch.ones((1, 1, 2), dtype=torch.int32, device=DEV), \
