@@ -68,6 +68,7 @@ def _build_locked(verbose: bool) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     import ctypes
+    import torch  # noqa: F401  (first: the process must end up with ONE HIP runtime — torch's; see fastvideo_amd/_lib.py load())
     try:  # catches e.g. a kernel whose host stub was not emitted (undefined symbol at dlopen time)
         ctypes.CDLL(LIB)
     except OSError as e:
