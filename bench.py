@@ -72,7 +72,19 @@ def cpu_baseline_reference(cfg, latent_shape, S, L_text, sample_layers=2):
                        f"{cores} cores) with {sample_layers} of {cfg.num_layers} blocks, one forward on the full latent {list(latent_shape)}: "
                        f"{total:.2f} s, blocks {', '.join(f'{b:.2f}' for b in blocks)} s; forward = mean block x {cfg.num_layers} + "
                        f"{total - sum(blocks):.2f} s outside the blocks", ms_per_step=round(per_forward * 1e3, 1),
-                reference_root=("live checkout" if R.REF_ROOT.startswith("/root/reference") else "oracle/_ref (staged by oracle/stage_ref.py)"))
+                reference_root=("live checkout" if R.REF_ROOT.startswith("/root/reference") else "oracle/_ref (staged by oracle/stage_ref.py)"),
+                staged_tree_sha256=_staged_tree_sha())
+
+
+def _staged_tree_sha():
+    """Digest of the staged reference tree (oracle/_ref/MANIFEST.json: sha256 over every path:sha256 line) — makes a
+    "reference"-kind baseline reproducible from the commit + the reference revision, although oracle/_ref itself is untracked."""
+    try:
+        from oracle import stage_ref
+        man = stage_ref.manifest()
+        return man.get("tree_sha256") if man else None
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def cpu_baseline_port(cfg, S, L_text, budget_s=25.0):

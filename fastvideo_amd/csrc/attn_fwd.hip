@@ -492,14 +492,8 @@ int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
     constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES;
     constexpr int LDS = PAIRS * 2 * STAGE_BYTES + (MODE == MODE_BLOCKS ? PAIRS * 2048 * 4 : 0);  // + the KV lists (LIST_CAP entries each)
     static_assert(LDS <= 163840, "LDS budget");
-    static bool configured[FVK_MAX_DEVICES] = {};
-    if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)attn_fwd_kernel<NW, MODE, DK, NL, PAIRS, RSTG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-            hipSuccess) {
-            fvk_set_error("fvk_attn: cannot set dynamic LDS size");
-            return FVK_ERR_LAUNCH;
-        }
-    }
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_fwd_kernel<NW, MODE, DK, NL, PAIRS, RSTG>, LDS, "fvk_attn")) return rc;
     const int bmq = NW * 32;
     const long nlists = (MODE == MODE_BLOCKS && ma.q_stride) ? ma.n_lists : (a->Sq + bmq - 1) / bmq;
     const long nblk = ((nlists + PAIRS - 1) / PAIRS) * a->H * a->B;

@@ -333,14 +333,8 @@ __global__ __launch_bounds__(512, 2) void attn_pp_kernel(fvk_attn_args a) {
 
 template <int SPLIT, bool PIPE, int PRIO = 0, int ABL = 0>
 int launch(const fvk_attn_args* a, hipStream_t s) {
-    static bool configured[FVK_MAX_DEVICES] = {};
-    if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)attn_pp_kernel<SPLIT, PIPE, PRIO, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
-            hipSuccess) {
-            fvk_set_error("fvk_attn_dense_bf16 (pp): cannot set dynamic LDS size");
-            return FVK_ERR_LAUNCH;
-        }
-    }
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_pp_kernel<SPLIT, PIPE, PRIO, ABL>, LDS_BYTES, "fvk_attn_dense_bf16 (pp)")) return rc;
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
     hipLaunchKernelGGL((attn_pp_kernel<SPLIT, PIPE, PRIO, ABL>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a);
     FVK_LAUNCH_CHECK();

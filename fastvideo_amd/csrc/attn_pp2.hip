@@ -451,13 +451,8 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a, fvk_p
 int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s) {
     constexpr int LDS_LIST = LDS_BYTES + 2048 * 8;  // + the packed list: up to 2048 tiles = 4096 blocks
     FVK_CHECK(la->max_kv <= 4096, FVK_ERR_ARG, "fvk_attn_tile_lists_bf16: lists of more than 4096 blocks (max_kv=%d) do not fit the LDS copy", la->max_kv);
-    static bool configured[FVK_MAX_DEVICES] = {};
-    if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)attn_pp2_kernel<false, true, false, true, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LIST) != hipSuccess) {
-            fvk_set_error("fvk_attn_tile_lists_bf16: cannot set dynamic LDS size");
-            return FVK_ERR_LAUNCH;
-        }
-    }
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_pp2_kernel<false, true, false, true, true, true, true>, LDS_LIST, "fvk_attn_tile_lists_bf16")) return rc;
     const long nblk = (long)la->n_lists * la->q_sub * a->H * a->B;
     hipLaunchKernelGGL((attn_pp2_kernel<false, true, false, true, true, true, true>), dim3((unsigned)nblk), dim3(512), LDS_LIST, s, *a, *la);
     FVK_LAUNCH_CHECK();
@@ -466,13 +461,8 @@ int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, h
 
 template <bool PROBE, bool PRIO, bool VSTREAM = true, bool ONEBAR = false, bool LDMA = false, bool LSTREAM = false>
 static int launch_pp2(const fvk_attn_args* a, hipStream_t s) {
-    static bool configured[FVK_MAX_DEVICES] = {};
-    if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-            fvk_set_error("fvk_attn_dense_bf16 (pp2): cannot set dynamic LDS size");
-            return FVK_ERR_LAUNCH;
-        }
-    }
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM>, LDS_BYTES, "fvk_attn_dense_bf16 (pp2)")) return rc;
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
     hipLaunchKernelGGL((attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a, fvk_pp2_lists{});
     FVK_LAUNCH_CHECK();

@@ -338,13 +338,8 @@ __global__ __launch_bounds__(512, 2) void attn_vsa_kernel(fvk_attn_args a, const
 int fvk_attn_vsa_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
                         hipStream_t s) {
     static_assert(LDS_BYTES <= 163840 && 4 * 64 * 67 * 4 <= 4 * STAGE_BYTES, "LDS budget");
-    static bool configured[FVK_MAX_DEVICES] = {};
-    if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)attn_vsa_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-            fvk_set_error("fvk_attn_block_sparse_bf16 (key-split kernel): cannot set dynamic LDS size");
-            return FVK_ERR_LAUNCH;
-        }
-    }
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_vsa_kernel, LDS_BYTES, "fvk_attn_block_sparse_bf16 (key-split kernel)")) return rc;
     const long nlists = a->Sq / 64;
     const long nblk = ((nlists + 1) / 2) * a->H * a->B;
     hipLaunchKernelGGL(attn_vsa_kernel, dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a, q2k_idx, q2k_num, kv_block_sizes, max_kv);

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/fvk_amd.h"
 
 typedef __bf16 bf16_t;
@@ -34,15 +36,28 @@ void fvk_set_error(const char* fmt, ...);
     } while (0)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of (function, device): a process that drives several GPUs must set it
-// on each.  `flags` = one function-local static array per kernel instantiation; returns true when the caller still has to set the
-// attribute on the CURRENT device.
+// on each.  One function-local static FvkLdsConfigured per kernel instantiation; the per-device flag is committed only AFTER
+// hipFuncSetAttribute succeeded (a failed call is retried — and reported — by the next launch instead of surfacing later as an
+// unrelated launch error), and it is atomic, so host threads driving different GPUs do not race (setting the attribute twice
+// from two threads is harmless).
 #define FVK_MAX_DEVICES 64
-inline bool fvk_needs_lds_config(bool* flags) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FVK_MAX_DEVICES) return true;  // unknown device: always (re)configure
-    if (flags[dev]) return false;
-    flags[dev] = true;
-    return true;
+struct FvkLdsConfigured {
+    std::atomic<bool> done[FVK_MAX_DEVICES];
+    FvkLdsConfigured() {
+        for (auto& d : done) d.store(false, std::memory_order_relaxed);
+    }
+};
+inline int fvk_config_lds(FvkLdsConfigured& c, const void* func, int bytes, const char* who) {
+    int dev = -1;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < FVK_MAX_DEVICES;  // unknown device: always (re)configure
+    if (known && c.done[dev].load(std::memory_order_acquire)) return FVK_OK;
+    hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+        fvk_set_error("%s: cannot set dynamic LDS size %d on device %d: %s", who, bytes, dev, hipGetErrorString(e));
+        return FVK_ERR_LAUNCH;
+    }
+    if (known) c.done[dev].store(true, std::memory_order_release);
+    return FVK_OK;
 }
 
 // device helpers ----------------------------------------------------------------------------

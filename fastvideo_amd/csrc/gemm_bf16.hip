@@ -162,14 +162,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
 
 template <int EPI>
 int launch(const GemmArgs& a, int batch, hipStream_t s) {
-    static bool configured[FVK_MAX_DEVICES] = {};
-    if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)gemm_bf16_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                2 * STAGE_BYTES) != hipSuccess) {
-            fvk_set_error("fvk_gemm_bf16: cannot set dynamic LDS size");
-            return FVK_ERR_LAUNCH;
-        }
-    }
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)gemm_bf16_kernel<EPI>, 2 * STAGE_BYTES, "fvk_gemm_bf16")) return rc;
     hipLaunchKernelGGL((gemm_bf16_kernel<EPI>), dim3(a.ntm * a.ntn, batch), dim3(256), 2 * STAGE_BYTES, s, a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;

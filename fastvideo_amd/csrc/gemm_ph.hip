@@ -278,13 +278,8 @@ __global__ __launch_bounds__(512, 2) void gemm_ph_kernel(GemmArgs a) {
 
 template <int EPI, int VAR>
 int launch(const GemmArgs& a, int batch, hipStream_t s) {
-    static bool configured[FVK_MAX_DEVICES] = {};
-    if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)gemm_ph_kernel<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) {
-            fvk_set_error("fvk_gemm_bf16 (ph): cannot set dynamic LDS size %d", LDS_BYTES);
-            return FVK_ERR_LAUNCH;
-        }
-    }
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)gemm_ph_kernel<EPI, VAR>, LDS_BYTES, "fvk_gemm_bf16 (ph)")) return rc;
     const int tiles = a.ntm * a.ntn;
     const int grid = (VAR & 128) ? (tiles < 256 ? tiles : 256) : tiles;  // 256 CUs, one resident workgroup each
     hipLaunchKernelGGL((gemm_ph_kernel<EPI, VAR>), dim3(grid, batch), dim3(512), LDS_BYTES, s, a);

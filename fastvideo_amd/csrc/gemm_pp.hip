@@ -195,14 +195,8 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs a) {
 
 template <int EPI, bool FP8 = false, bool LATE = false>
 int launch(const GemmArgs& a, int batch, hipStream_t s) {
-    static bool configured[FVK_MAX_DEVICES] = {};
-    if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)gemm_pp_kernel<EPI, FP8, LATE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
-            hipSuccess) {
-            fvk_set_error("fvk_gemm_bf16 (pp): cannot set dynamic LDS size %d", LDS_BYTES);
-            return FVK_ERR_LAUNCH;
-        }
-    }
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)gemm_pp_kernel<EPI, FP8, LATE>, LDS_BYTES, "fvk_gemm_bf16 (pp)")) return rc;
     hipLaunchKernelGGL((gemm_pp_kernel<EPI, FP8, LATE>), dim3(a.ntm * a.ntn, batch), dim3(512), LDS_BYTES, s, a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;

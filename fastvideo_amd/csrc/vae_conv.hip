@@ -288,14 +288,8 @@ int launch(ConvArgs a, hipStream_t s) {
     constexpr int TM = WNW == 1 ? 512 : 256;
     constexpr int TN = WNW == 1 ? 96 : 192;
     constexpr int LDS = NSLOT * (TM + TN) * 64 + 1024;
-    static bool configured[FVK_MAX_DEVICES] = {};
-    if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)vae_conv_kernel<WNW, EPI, UPS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
-            hipSuccess) {
-            fvk_set_error("fvk_vae_conv_bf16: cannot set dynamic LDS size %d", LDS);
-            return FVK_ERR_LAUNCH;
-        }
-    }
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)vae_conv_kernel<WNW, EPI, UPS>, LDS, "fvk_vae_conv_bf16")) return rc;
     a.ntm = (a.M + TM - 1) / TM;
     a.ntn = (a.Cout + TN - 1) / TN;
     hipLaunchKernelGGL((vae_conv_kernel<WNW, EPI, UPS>), dim3(a.ntm * a.ntn), dim3(512), LDS, s, a);

@@ -455,13 +455,8 @@ int launch3(Conv3Args a, hipStream_t s) {
     constexpr int HH = UPS ? TH / 2 + 2 : TH + 2, WW = UPS ? 18 : 34;
     constexpr int RING = 2 * ((HH * WW + 15) / 16) * 1024 + (STAG ? 4 : 3) * (3 * TN / 16) * 1024 + 1024;
     constexpr int LDS = RING > 8 * 64 * 208 ? RING : 8 * 64 * 208;  // epilogue staging reuses the ring
-    static bool configured[FVK_MAX_DEVICES] = {};
-    if (fvk_needs_lds_config(configured)) {
-        if (hipFuncSetAttribute((const void*)vae_conv3_kernel<WNW, EPI, UPS, NB, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-            fvk_set_error("fvk_vae_conv_bf16 (3x3): cannot set dynamic LDS size %d", LDS);
-            return FVK_ERR_LAUNCH;
-        }
-    }
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)vae_conv3_kernel<WNW, EPI, UPS, NB, STAG>, LDS, "fvk_vae_conv_bf16 (3x3)")) return rc;
     a.tiles_h = (a.H + TH - 1) / TH;
     a.tiles_w = (a.W + 31) / 32;
     a.ntn = (a.Cout + TN - 1) / TN;

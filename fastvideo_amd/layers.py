@@ -129,9 +129,12 @@ class HipRMSNorm(_RefRMSNorm):
     """``RMSNorm`` whose ``forward`` is the gfx950 kernel ``fvk_rmsnorm_rope_bf16`` (norm only: no rotary tables).
 
     Arithmetic = ``forward_native`` (layernorm.py:48-83): fp32 normalise -> round to bf16 -> multiply by the weight -> round.
-    The weight is used in bf16 (what FSDP mixed precision / ``model.to(bf16)`` gives the reference); an fp32 weight whose values
-    are not bf16-representable is refused rather than silently rounded.  ``residual`` and ``var_hidden_size`` (not on the Wan
-    path: wanvideo.py:316-319) are refused."""
+    A bf16 weight (what FSDP mixed precision / ``model.to(bf16)`` gives the reference) is multiplied inside the kernel and the
+    output is bf16.  An fp32 weight (the reference's default-constructed ``torch.ones`` parameter) follows the reference's type
+    promotion instead: ``x.to(bf16) * weight_fp32`` is an UNROUNDED fp32 product, so the kernel runs without a weight and the
+    bf16 normalised rows are promoted and multiplied by the fp32 weight — the result is fp32, bit-identical to ``forward_native``'s
+    promotion (one extra elementwise pass; not the Wan hot path, whose modules are cast to bf16).  Other weight dtypes are refused.
+    ``residual`` and ``var_hidden_size`` (not on the Wan path: wanvideo.py:316-319) are refused."""
 
     def dispatch_forward(self):
         return self.forward_cuda
@@ -141,9 +144,9 @@ class HipRMSNorm(_RefRMSNorm):
         cached = getattr(self, "_hip_w", None)
         if cached is not None and cached[0] == (w.data_ptr(), w._version, w.device, w.dtype) and cached[1].device == device:
             return cached[1]
-        wb = w.detach().to(device=device, dtype=BF16).contiguous()
-        if w.dtype != BF16 and not torch.equal(wb.float().cpu(), w.detach().float().cpu()):
-            raise RuntimeError("HipRMSNorm: fp32 weight is not exactly representable in bf16; cast the module to bf16 first")
+        if w.dtype != BF16:
+            raise RuntimeError(f"HipRMSNorm: the in-kernel weight must be bf16, got {w.dtype}")
+        wb = w.detach().to(device=device).contiguous()
         self._hip_w = ((w.data_ptr(), w._version, w.device, w.dtype), wb)
         return wb
 
@@ -158,9 +161,16 @@ class HipRMSNorm(_RefRMSNorm):
         x2 = x.reshape(-1, self.hidden_size)
         if x2.stride(1) != 1:
             x2 = x2.contiguous()
-        out = ops.rmsnorm_rope([x2], [self._weight_bf16(x.device)], None, None, head_dim=self.hidden_size, seq_len=x2.shape[0],
-                               eps=self.variance_epsilon)[0]
-        return out.view(x.shape)
+        w = self.weight if self.has_weight else None
+        if w is not None and w.dtype not in (BF16, torch.float32):
+            raise RuntimeError(f"HipRMSNorm: weight must be bf16 or fp32, got {w.dtype}")
+        in_kernel = w is not None and w.dtype == BF16
+        out = ops.rmsnorm_rope([x2], [self._weight_bf16(x.device)] if in_kernel else None, None, None, head_dim=self.hidden_size,
+                               seq_len=x2.shape[0], eps=self.variance_epsilon)[0]
+        out = out.view(x.shape)
+        if w is not None and not in_kernel:  # forward_native: `x.to(orig_dtype) * self.weight` promotes to fp32, product unrounded
+            out = out * w.detach().to(x.device)
+        return out
 
 
 # ------------------------------------------------------------------ rotary (ref: rotary_embedding.py:105-150, 153-236)
@@ -186,11 +196,12 @@ def apply_rotary_emb(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, is_n
     if cos.shape[0] != S:
         raise ValueError(f"rotary tables hold {cos.shape[0]} positions, x has {S} tokens")
     c, s = _full_tables(cos.to(x.device), sin.to(x.device), D)
-    x3 = x.reshape(-1, S, H * D)
-    out = torch.empty_like(x3)
-    for b in range(x3.shape[0]):  # the position of row m is m % S
-        xb = x3[b] if x3[b].stride(1) == 1 else x3[b].contiguous()
-        ops.rmsnorm_rope([xb], None, c, s, head_dim=D, seq_len=S, outs=[out[b]])
+    x3 = x.reshape(-1, S, H * D)  # [batch, S, H*D]: the position of row m of the flattened [batch*S, H*D] view is m % S
+    if x3.stride(2) != 1 or (x3.shape[0] > 1 and x3.stride(0) != S * x3.stride(1)):
+        x3 = x3.contiguous()
+    x2 = x3.as_strided((x3.shape[0] * S, H * D), (x3.stride(1), 1), x3.storage_offset())  # batches are stride(1)*S apart: one row stride
+    out = torch.empty((x3.shape[0] * S, H * D), dtype=BF16, device=x.device)  # explicitly contiguous
+    ops.rmsnorm_rope([x2], None, c, s, head_dim=D, seq_len=S, outs=[out])  # ONE launch for every batch element
     return out.view(x.shape)
 
 

@@ -87,6 +87,24 @@ def scale_residual(residual, x, gate=None, rows_per_batch=None):
     return out.view(x.shape)
 
 
+_ROW_MAPS_OK: dict = {}
+
+
+def _check_row_map(rmap, n_out_rows):
+    """A scatter map is dereferenced by the kernel without a bound: check max(map) < rows of the output ONCE per (map storage,
+    version, output rows) — the maps are per-geometry metadata built once and reused every layer, so this costs one device
+    sync per geometry, not per call."""
+    key = (rmap.data_ptr(), rmap.numel(), rmap._version, int(n_out_rows))
+    if key in _ROW_MAPS_OK:
+        return
+    hi = int(rmap.max().item()) if rmap.numel() else -1
+    if hi >= n_out_rows:
+        raise RuntimeError(f"rmsnorm_rope: row map addresses row {hi} of an output with {n_out_rows} rows")
+    if len(_ROW_MAPS_OK) > 256:
+        _ROW_MAPS_OK.clear()
+    _ROW_MAPS_OK[key] = True
+
+
 def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_len=None, eps=1e-6, outs=None, pos_offset=0, row_maps=None):
     """tensors: list (<=3) of bf16 2-D views [M, width] sharing one row stride (e.g. q,k column slices of a fused
     QKV buffer).  Returns a list of new contiguous [M, width] tensors (or writes `outs`).
@@ -101,7 +119,15 @@ def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_le
             raise RuntimeError("rmsnorm_rope: tensors must be [M,width] views with unit column stride and a common row stride")
     if outs is None:
         outs = [torch.empty((M, width), dtype=BF16, device=tensors[0].device) for _ in range(n)]
+    elif len(outs) != n:
+        raise RuntimeError("rmsnorm_rope: `outs` needs one output per tensor")
     ostride = outs[0].stride(0)
+    for o in outs:  # caller-supplied outputs are written by raw pointer: same checks as the inputs
+        _chk(o, BF16, "out")
+        if o.dim() != 2 or o.shape[1] != width or o.stride(1) != 1 or o.stride(0) != ostride:
+            raise RuntimeError("rmsnorm_rope: outputs must be [rows,width] bf16 views with unit column stride and a common row stride")
+        if row_maps is None and o.shape[0] != M:
+            raise RuntimeError(f"rmsnorm_rope: output has {o.shape[0]} rows, the inputs {M}")
     arr = C.c_void_p * n
     ins = arr(*[t.data_ptr() for t in tensors])
     os_ = arr(*[t.data_ptr() for t in outs])
@@ -117,6 +143,12 @@ def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_le
         maps = [None if r is None else _chk(r, torch.int32, "row_map").contiguous() for r in row_maps]
         if any(r is not None and r.numel() != M for r in maps):
             raise RuntimeError("rmsnorm_rope: every row map must have one entry per input row")
+        for r, o in zip(maps, outs):
+            if r is None:
+                if o.shape[0] != M:
+                    raise RuntimeError(f"rmsnorm_rope: an output without a row map needs {M} rows, got {o.shape[0]}")
+            else:
+                _check_row_map(r, o.shape[0])
         rm = arr(*[0 if r is None else r.data_ptr() for r in maps])
         _lib.call("fvk_rmsnorm_rope_scatter_bf16", ins, os_, ws, n, _p(cos), _p(sin), M, width, head_dim, seq_len or M, int(pos_offset), stride,
                   ostride, float(eps), rm, _stream())

@@ -85,7 +85,8 @@ class FlowUniPCOracle:
             corr = 0
             if order > 1:
                 D1s = torch.stack([(self.model_outputs[-(i + 1)] - m0) / c["rks"][i - 1] for i in range(1, order)], dim=1)
-                corr = torch.einsum("k,bkc...->bc...", c["rhos"][:-1], D1s)
+                corr = torch.einsum("k,bkc...->bc...", c["rhos"][:-1].to(D1s.device), D1s)  # .to(): a no-op on the CPU; lets the
+                #                       same restatement run as torch GPU-eager ops (tests/test_gpu_sched.py, scalar_rounding="fp32")
             sample = (x_t_ - c["c_B"] * (corr + c["rhos"][-1] * (x0 - m0))).to(x.dtype)
         for i in range(self.order - 1):
             self.model_outputs[i] = self.model_outputs[i + 1]
@@ -99,7 +100,7 @@ class FlowUniPCOracle:
         x_t = c["c_x"] * sample - c["c_m0"] * m0
         if order > 1:
             D1s = torch.stack([(self.model_outputs[-(i + 1)] - m0) / c["rks"][i - 1] for i in range(1, order)], dim=1)
-            x_t = x_t - c["c_B"] * torch.einsum("k,bkc...->bc...", c["rhos"], D1s)
+            x_t = x_t - c["c_B"] * torch.einsum("k,bkc...->bc...", c["rhos"].to(D1s.device), D1s)
         else:
             x_t = x_t - c["c_B"] * 0
         if self.lower_order_nums < self.order:

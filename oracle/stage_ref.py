@@ -12,11 +12,15 @@ snapshot, like the built ``libfvk_amd.so``.  There it serves two purposes:
     kernels as a GPU-side checker: ``block_sparse_attn_triton.py``, ``fused_compress_topk.py``, ``index.py``,
     ``st_attn_triton.py``.
 
-What is copied: exactly the reference modules that the App. A import recipe loads for a DiT forward, a VAE decode, the VSA backend
-and the UniPC scheduler (found by running the recipe in a subprocess and listing ``sys.modules``), plus the four Triton kernel files
-and ``vsa_utils.py`` of the kernel wheel.  Files are copied byte for byte; ``MANIFEST.json`` records path + sha256.
+What is copied: the reference modules listed in the committed ``oracle/ref_files.json`` (paths only) — the modules the App. A
+import recipe loads for a DiT forward, a VAE decode, the VSA backend and the UniPC scheduler, plus the four Triton kernel files and
+``vsa_utils.py`` of the kernel wheel.  Files are copied byte for byte; ``MANIFEST.json`` records path + sha256 and a digest of the
+whole tree (``tree_sha256``), which ``bench.py`` prints next to a ``kind: "reference"`` CPU baseline.
 
-Run by ``__graft_entry__.build()`` when ``/root/reference`` is present; a no-op (returns False) otherwise.
+``stage()`` is a PURE FILE COPY: it never imports or executes reference code.  It is an explicit step of the test / bench harness
+(``python -m oracle.stage_ref``, also called by ``scripts/gpu_round.sh`` before a gpurun); ``__graft_entry__.build()`` does not call
+it.  The list itself is regenerated only on request (``python -m oracle.stage_ref --discover``: runs the import recipe in a
+subprocess and lists ``sys.modules`` — the one place reference code executes, never part of a build).
 """
 from __future__ import annotations
 
@@ -88,6 +92,31 @@ def staged_root() -> str | None:
     return DST if os.path.isdir(os.path.join(DST, "fastvideo")) else None
 
 
+FILE_LIST = os.path.join(HERE, "ref_files.json")
+
+
+def discover() -> list[str]:
+    """Explicit opt-in: run the App. A import recipe in a subprocess (this EXECUTES reference code) and rewrite ref_files.json."""
+    env = dict(os.environ, MASTER_PORT=os.environ.get("FVK_STAGE_PORT", "29533"), WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, "-c", _PROBE.format(root=ROOT, src=SRC)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, env=env, cwd=ROOT)
+    line = [l for l in r.stdout.splitlines() if l.startswith("FILES=")]
+    if r.returncode != 0 or not line:
+        raise RuntimeError(f"stage_ref: the reference import probe failed:\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}")
+    files = sorted(set([os.path.relpath(f, SRC) for f in json.loads(line[0][6:])] + KERNEL_FILES))
+    old = json.load(open(FILE_LIST)) if os.path.exists(FILE_LIST) else {}
+    json.dump({"comment": old.get("comment", "paths copied by oracle/stage_ref.py"), "files": files}, open(FILE_LIST, "w"), indent=1)
+    return files
+
+
+def manifest() -> dict | None:
+    """The manifest of the staged tree ({"files": {path: sha256}, "tree_sha256": ...}) or None."""
+    try:
+        return json.load(open(MANIFEST)) if staged_root() else None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def stage(force: bool = False, verbose: bool = False) -> bool:
     if not available():
         return False
@@ -99,13 +128,7 @@ def stage(force: bool = False, verbose: bool = False) -> bool:
                 return True
         except Exception:  # noqa: BLE001 - a damaged manifest just means: stage again
             pass
-    env = dict(os.environ, MASTER_PORT=os.environ.get("FVK_STAGE_PORT", "29533"), WORLD_SIZE="1", RANK="0")
-    r = subprocess.run([sys.executable, "-c", _PROBE.format(root=ROOT, src=SRC)], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                       text=True, env=env, cwd=ROOT)
-    line = [l for l in r.stdout.splitlines() if l.startswith("FILES=")]
-    if r.returncode != 0 or not line:
-        raise RuntimeError(f"stage_ref: the reference import probe failed:\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}")
-    files = [os.path.relpath(f, SRC) for f in json.loads(line[0][6:])] + KERNEL_FILES
+    files = json.load(open(FILE_LIST))["files"]
     if os.path.isdir(DST):
         shutil.rmtree(DST)
     man = {}
@@ -115,12 +138,15 @@ def stage(force: bool = False, verbose: bool = False) -> bool:
         shutil.copyfile(src, dst)
         man[rel] = _sha(src)
     os.makedirs(os.path.dirname(MANIFEST), exist_ok=True)
-    json.dump({"source": SRC, "files": man}, open(MANIFEST, "w"), indent=0)
+    tree = hashlib.sha256("".join(f"{k}:{v}\n" for k, v in sorted(man.items())).encode()).hexdigest()
+    json.dump({"source": SRC, "files": man, "tree_sha256": tree}, open(MANIFEST, "w"), indent=0)
     if verbose:
         print(f"stage_ref: {len(man)} reference files -> {DST}")
     return True
 
 
 if __name__ == "__main__":
+    if "--discover" in sys.argv:
+        print(f"discovered {len(discover())} reference files -> {FILE_LIST}")
     ok = stage(force="--force" in sys.argv, verbose=True)
     print("staged" if ok else "reference checkout not present: nothing staged")

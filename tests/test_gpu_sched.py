@@ -51,6 +51,37 @@ def test_unipc_no_guidance_matches_oracle(steps, shift, order):
         assert torch.equal(xg.cpu(), x)
 
 
+@pytest.mark.parametrize("steps,shift,g", [(6, 3.0, 5.0), (4, 8.0, 3.0), (3, 5.0, None)])
+def test_fp32_scalar_mode_is_torch_gpu_eager_bit_exact(steps, shift, g):
+    """``scalar_rounding="fp32"`` (DenoisingLoopHip's default) claims to be what the reference's eager ops do ON AN ACCELERATOR: a 0-d
+    CPU fp32 ``sigma_t`` / a Python ``guidance_scale`` meeting a bf16 device tensor stays fp32 inside the elementwise kernel (on the
+    CPU the scalar is first cast to bf16 — ``scalar_rounding="bf16"``, pinned to tests/golden/unipc.pt above).  Checked here by
+    running the SAME restatement (oracle/sched_oracle.py, pinned bit-exact to the real scheduler class on the CPU) as torch eager ops
+    on the device — bf16 device tensors, 0-d CPU fp32 coefficients, exactly the operand types the reference's step() sees on a GPU —
+    against the fused step kernel in "fp32" mode: bit-exact fp32 latents and bf16 model inputs at every step."""
+    _need_gpu()
+    from fastvideo_amd.scheduler import FlowUniPCStepper
+    from oracle.sched_oracle import FlowUniPCOracle, cfg_combine
+    o = FlowUniPCOracle(steps, shift=shift)
+    st = FlowUniPCStepper(steps, shift=shift, scalar_rounding="fp32")
+    st16 = FlowUniPCStepper(steps, shift=shift, scalar_rounding="bf16")
+    gen = torch.Generator().manual_seed(steps)
+    x = torch.randn((1, 16, 3, 9, 7), generator=gen).cuda()
+    xk, xb = x.clone(), x.clone()
+    differs = False
+    for i in range(steps):
+        text = (torch.randn(x.shape, generator=gen) * 1.7).bfloat16().cuda()
+        unc = None if g is None else (torch.randn(x.shape, generator=gen) * 1.7).bfloat16().cuda()
+        x = o.step(cfg_combine(text, unc, g), x)                 # torch eager ON THE DEVICE
+        xk, x16 = st.step(text, xk, unc, g if g is not None else 1.0)
+        assert x.is_cuda and torch.equal(xk, x), f"step {i}: max diff {(xk - x).abs().max().item()}"
+        assert torch.equal(x16, x.bfloat16())
+        xb, _ = st16.step(text, xb, unc, g if g is not None else 1.0)
+        differs = differs or not torch.equal(xb, xk)
+        xb = xk.clone()
+    assert differs, "the two scalar modes never differed: the test would not notice a wrong default"
+
+
 def test_denoising_loop_two_steps_vs_oracle(golden_dir):
     """Two CFG denoising steps of the tiny Wan model: HIP DiT + fused step vs oracle DiT + oracle scheduler (reference loop
     fastvideo/pipelines/stages/denoising.py:372-596).  Tolerance: the DiT's (atol 1e-1, rtol 1e-2 on bf16 outputs) carried through
