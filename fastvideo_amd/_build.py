@@ -10,7 +10,12 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfvk_amd.so")
-SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.hip", "fp8.hip", "attn_fwd.hip", "attn_pp.hip", "attn_pp2.hip", "attn_vsa.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_post.hip", "sched_step.hip"]
+SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.hip", "fp8.hip", "attn_fwd.hip", "attn_pp2.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_post.hip", "sched_step.hip"]
+# measurement build (scripts/probes/libfvk_probe.so): the same sources with -DFVK_PROBE_BUILD (variant dispatch + fvk_set_tunable knobs
+# compiled in) plus the experiment kernels that never shipped.  Nothing in the product path loads it (fastvideo_amd/_lib.py: FVK_PROBE_LIB=1).
+PROBE_DIR = os.path.join(HERE, "..", "scripts", "probes")
+PROBE_SOURCES = ["attn_pp.hip", "attn_vsa.hip"]
+PROBE_LIB = os.path.join(PROBE_DIR, "libfvk_probe.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 FLAGS += os.environ.get("FVK_EXTRA_FLAGS", "").split()  # measurement builds only (e.g. -DFVK_ST_ABL=1 timing ablations)
 
@@ -22,40 +27,53 @@ def hipcc() -> str:
     return exe
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def needs_build(probe: bool = False) -> bool:
+    lib = PROBE_LIB if probe else LIB
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "fvk_amd.h")]
+    t = os.path.getmtime(lib)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "build"] + [os.path.join(HERE, "..", "include", "fvk_amd.h")]
+    if probe:
+        deps += [os.path.join(PROBE_DIR, f) for f in PROBE_SOURCES]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
-        return LIB
+def build(force: bool = False, verbose: bool = True, probe: bool = False) -> str:
+    lib = PROBE_LIB if probe else LIB
+    if not force and not needs_build(probe):
+        return lib
     # one builder at a time: under torch.distributed.run every rank calls build(), and a snapshot copy may have refreshed mtimes
     import fcntl
     with open(os.path.join(HERE, ".build.lock"), "w") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         try:
-            if not force and not needs_build():  # another rank finished the build while this one waited
-                return LIB
-            return _build_locked(verbose)
+            if not force and not needs_build(probe):  # another rank finished the build while this one waited
+                return lib
+            return _build_locked(verbose, probe)
         finally:
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose: bool) -> str:
-    objdir = os.path.join(CSRC, "build")
+def build_probe(force: bool = False, verbose: bool = True) -> str:
+    """The measurement build (see PROBE_SOURCES)."""
+    return build(force, verbose, probe=True)
+
+
+def _build_locked(verbose: bool, probe: bool = False) -> str:
+    objdir = os.path.join(PROBE_DIR, "build") if probe else os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
     objs = []
     procs = []
-    for src in SOURCES:
+    lib = PROBE_LIB if probe else LIB
+    srcs = [(src, os.path.join(CSRC, src)) for src in SOURCES] + ([(src, os.path.join(PROBE_DIR, src)) for src in PROBE_SOURCES] if probe else [])
+    for src, path in srcs:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         extra = ["-ffp-contract=off"] if src in ("sched_step.hip", "vae_post.hip") else []  # bit-exact fp32 arithmetic (no fused multiply-add)
-        cmd = [cc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
+        if probe:
+            extra += ["-DFVK_PROBE_BUILD=1", "-I", CSRC]
+        cmd = [cc, *FLAGS, *extra, "-c", path, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for src, p in procs:
         out, _ = p.communicate()
@@ -63,19 +81,20 @@ def _build_locked(verbose: bool) -> str:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
         if verbose and out.strip():
             print(out)
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
     import ctypes
     import torch  # noqa: F401  (first: the process must end up with ONE HIP runtime — torch's; see fastvideo_amd/_lib.py load())
     try:  # catches e.g. a kernel whose host stub was not emitted (undefined symbol at dlopen time)
-        ctypes.CDLL(LIB)
+        ctypes.CDLL(lib)
     except OSError as e:
-        os.remove(LIB)
+        os.remove(lib)
         raise RuntimeError(f"built library does not load: {e}") from e
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_probe(force=True))

@@ -10,7 +10,10 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfvk_amd.so")
+# FVK_PROBE_LIB=1 (measurement scripts and the variant tests only): bind the measurement build of the same sources, which also holds
+# the non-shipping kernel variants behind fvk_set_tunable (scripts/probes/libfvk_probe.so, built by _build.build_probe()).
+PROBE = os.environ.get("FVK_PROBE_LIB") == "1"
+LIB_PATH = (os.path.join(os.path.dirname(HERE), "scripts", "probes", "libfvk_probe.so") if PROBE else os.path.join(HERE, "libfvk_amd.so"))
 ABI_VERSION = 4
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -27,6 +30,7 @@ class AttnArgs(C.Structure):
 SIGNATURES = {
     "fvk_last_error": [],
     "fvk_abi_version": [],
+    "fvk_is_probe_build": [],
     "fvk_device_arch": [C.c_char_p, i32],
     "fvk_set_tunable": [C.c_char_p, i32],
     "fvk_ln_modulate_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
@@ -94,6 +98,8 @@ def load() -> C.CDLL:
             raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.argtypes = argtypes
         fn.restype = _RESTYPES.get(name, C.c_int)
+    if bool(lib.fvk_is_probe_build()) != PROBE:
+        raise RuntimeError(f"{LIB_PATH}: probe-build flag {lib.fvk_is_probe_build()} does not match FVK_PROBE_LIB={int(PROBE)}; rebuild it")
     if lib.fvk_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libfvk_amd.so ABI {lib.fvk_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = lib

@@ -519,7 +519,9 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
     // full-length query blocks: 0 = the 128-key-tile ping-pong kernel (attn_pp2.hip, shipped); 1 = this file's 4-wave kernel;
     // >= 2 = the 64-key-tile ping-pong kernel (attn_pp.hip) variant impl-1 (measurement only)
     if ((impl == 0 || impl >= 100) && a->Sq >= 256) return fvk_attn_pp2_launch(a, impl >= 100 ? impl - 99 : 0, (hipStream_t)stream);
+#if FVK_VARIANTS
     if (impl >= 2 && impl < 100 && a->Sq >= 256) return fvk_attn_pp_launch(a, impl - 1, (hipStream_t)stream);
+#endif
     ModeArgs ma{};
     return launch<4, MODE_DENSE>(a, ma, (hipStream_t)stream);
 }
@@ -541,11 +543,14 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     // where all query blocks of a tile attend the same KV blocks)
     if (q_block == 128) {
         // 4 compute waves that also issue the DMA, two workgroups per CU (shipped); "attn_impl" 51 = 4 compute + 4 loader waves, one per CU (A/B)
+#if FVK_VARIANTS
         if (fvk::tunable(fvk::TUNE_ATTN_IMPL) == 51) return launch<4, MODE_BLOCKS, 128, 4>(a, ma, (hipStream_t)stream);
+#endif
         return launch<4, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
     }
     // 64-row lists (the VSA block): two lists per 8-wave workgroup, each with 2 compute + 2 loader waves ("attn_impl" 50 = the former
     // one-list 4-wave workgroups, two per CU, for A/B)
+#if FVK_VARIANTS
     const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
     if (impl == 50) return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);
     // Shipped: two lists per workgroup, 2 compute + 2 loader waves each, one-stage-ahead LDS-DMA.  Two alternatives were built to attack what
@@ -556,6 +561,7 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     // i.e. neither the prefetch depth nor the single compute wave per SIMD is the bound; the per-CU ingest rate is.
     if (impl == 53) return launch<2, MODE_BLOCKS, 128, 2, 2, true>(a, ma, (hipStream_t)stream);
     if (impl == 54 && max_kv <= 2048) return fvk_attn_vsa_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, (hipStream_t)stream);
+#endif
     return launch<2, MODE_BLOCKS, 128, 2, 2>(a, ma, (hipStream_t)stream);
 }
 

@@ -66,7 +66,10 @@ __device__ __forceinline__ float xhalf_sum(float v) {
 // 0 .. Skv/128: K pieces add their block's row offset, V^T pieces select the block per lane (a piece row spans both halves), the softmax
 // masks each half by its block size.  The list lives in LDS (packed per tile: id | size << 24 for both halves) and is read one step
 // ahead.  Workgroup ids are dealt so that each XCD (private L2) owns a contiguous run of lists: neighbouring tiles' windows overlap.
-template <bool PROBE, bool PRIO, bool VSTREAM = true, bool ONEBAR = false, bool LDMA = false, bool LSTREAM = false, bool LIST = false>
+// ABL (measurement build only; results are WRONG, timing is what is measured — "where do the cycles / the power go"):
+//   bit 0: half the LDS fragment reads (every fragment feeds two MFMAs: what a 64-row wave tile would read);  bit 1: no v_exp (the
+//   exponent argument is used as P);  bit 2: no LDS-DMA in the steady state (tiles are re-read from the ring as they are)
+template <bool PROBE, bool PRIO, bool VSTREAM = true, bool ONEBAR = false, bool LDMA = false, bool LSTREAM = false, bool LIST = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a, fvk_pp2_lists la) {
     static_assert(!(VSTREAM && ONEBAR), "in-stream V^T pieces rely on the second barrier");
     static_assert(!LDMA || ONEBAR, "leading-group DMA is a one-barrier schedule");
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a, fvk_p
 
     // piece I (0..7 = K(T+1), 8..15 = V^T(T)) of the set that tile step T makes room for; tiles past the end re-read tile 0 (harmless)
 #define ISSUE_PIECE(T, I)                                                                                            \
-    {                                                                                                                \
+    if (!(ABL & 4)) {                                                                                                \
         if (LIST) {                                                                                                  \
             if ((I) < 8)                                                                                             \
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + (((T) + 1) & 1) * K_TILE + pdst + (I) * 4096), 16, \
@@ -212,13 +215,15 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a, fvk_p
         _Pragma("unroll") for (int i = 0; i < FD; ++i) fr_[i] = FRAG(J, (FIRST) + i);                                \
         __builtin_amdgcn_sched_group_barrier(0x100, FD, 0);                                                          \
         _Pragma("unroll") for (int i = (FIRST); i < (LAST); ++i) {                                                   \
-            if (i < 32) o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[(i - (FIRST)) % FD], pf[i >> 2], o[i & 3], 0, 0, 0); \
-            else if (i < 36) s[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[(i - (FIRST)) % FD], qf[0], zero16, 0, 0, 0); /* S is not live during P·V */ \
-            else s[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[(i - (FIRST)) % FD], qf[(i - 32) >> 2], s[i & 3], 0, 0, 0); \
-            const int n_ = i + FD;                                                                                   \
-            if (n_ < (LAST)) fr_[(n_ - (FIRST)) % FD] = FRAG(J, n_);                                                 \
+            const int fs_ = (((ABL & 1) ? (i & ~1) : i) - (FIRST)) % FD; /* ABL bit 0: odd MFMAs re-use the even fragment */ \
+            if (i < 32) o[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[fs_], pf[i >> 2], o[i & 3], 0, 0, 0); \
+            else if (i < 36) s[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[fs_], qf[0], zero16, 0, 0, 0); /* S is not live during P·V */ \
+            else s[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr_[fs_], qf[(i - 32) >> 2], s[i & 3], 0, 0, 0); \
+            const int n_ = (ABL & 1) ? i + FD - 1 : i + FD;                                                          \
+            const bool rd_ = n_ < (LAST) && (!(ABL & 1) || (i & 1));                                                 \
+            if (rd_) fr_[(n_ - (FIRST)) % FD] = FRAG(J, n_);                                                         \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                       \
-            if (n_ < (LAST)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                      \
+            if (rd_) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                              \
             /* DMA (trailing group only): the wave's 8 V^T pieces of set J+1 ride in the gaps of the Q·K^T half (one per 4 MFMAs); their   \
                ring slot held V^T(J-1), which this wave finished reading with MFMA 31 and the leading group a whole barrier interval ago */ \
             if ((DMA) && VSTREAM && grp == 1 && i >= 32 && ((i - 32) & 3) == 0) ISSUE_PIECE((J) + 1, 8 + ((i - 32) >> 2))          \
@@ -265,7 +270,8 @@ __global__ __launch_bounds__(512, 2) void attn_pp2_kernel(fvk_attn_args a, fvk_p
         const float mc = m_run * c2;                                                                                 \
         float ps4[4] = {0.f, 0.f, 0.f, 0.f};                                                                         \
         _Pragma("unroll") for (int kb = 0; kb < 4; ++kb) _Pragma("unroll") for (int r = 0; r < 16; ++r) {           \
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], c2, -mc));                              \
+            const float e_ = __builtin_fmaf(s[kb][r], c2, -mc);                                                      \
+            const float p = (ABL & 2) ? e_ : __builtin_amdgcn_exp2f(e_);                                            \
             s[kb][r] = p;                                                                                            \
             ps4[r & 3] += p;                                                                                         \
         }                                                                                                            \
@@ -459,18 +465,19 @@ int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, h
     return FVK_OK;
 }
 
-template <bool PROBE, bool PRIO, bool VSTREAM = true, bool ONEBAR = false, bool LDMA = false, bool LSTREAM = false>
+template <bool PROBE, bool PRIO, bool VSTREAM = true, bool ONEBAR = false, bool LDMA = false, bool LSTREAM = false, int ABL = 0>
 static int launch_pp2(const fvk_attn_args* a, hipStream_t s) {
     static FvkLdsConfigured configured;
-    if (int rc = fvk_config_lds(configured, (const void*)attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM>, LDS_BYTES, "fvk_attn_dense_bf16 (pp2)")) return rc;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM, false, ABL>, LDS_BYTES, "fvk_attn_dense_bf16 (pp2)")) return rc;
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
-    hipLaunchKernelGGL((attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a, fvk_pp2_lists{});
+    hipLaunchKernelGGL((attn_pp2_kernel<PROBE, PRIO, VSTREAM, ONEBAR, LDMA, LSTREAM, false, ABL>), dim3((unsigned)nblk), dim3(512), LDS_BYTES, s, *a, fvk_pp2_lists{});
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
 
 // probe != 0: timing probe build (a->lse receives s_memtime sums, see PROBE)
 int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s) {
+#if FVK_VARIANTS
     switch (probe) {
         // 0 (shipped): one barrier per tile step, the LEADING group issues the DMA inside its matrix segment (round 2: -3 % time, -9 % cycles
         // against the round-1 schedule, bit-identical output); 1 = its s_memtime probe; 2 = shipped without s_setprio (A/B).
@@ -488,6 +495,16 @@ int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s) {
         case 8: return launch_pp2<false, true, false, true, true, false>(a, s);
         case 9: return launch_pp2<true, true, false, true, true, false>(a, s);
         case 12: return launch_pp2<false, true, true>(a, s);
-        default: return launch_pp2<false, true, false, true, true, true>(a, s);
+        // timing ablations of the shipped schedule (ABL bits: 1 half the fragment reads, 2 no v_exp, 4 no steady-state DMA): attn_impl 120 + bits
+        case 21: return launch_pp2<false, true, false, true, true, true, 1>(a, s);
+        case 22: return launch_pp2<false, true, false, true, true, true, 2>(a, s);
+        case 23: return launch_pp2<false, true, false, true, true, true, 3>(a, s);
+        case 24: return launch_pp2<false, true, false, true, true, true, 4>(a, s);
+        case 25: return launch_pp2<false, true, false, true, true, true, 5>(a, s);
+        case 27: return launch_pp2<false, true, false, true, true, true, 7>(a, s);
+        default: break;
     }
+#endif
+    (void)probe;
+    return launch_pp2<false, true, false, true, true, true>(a, s);  // shipped: one barrier per tile step, leading-group in-stream DMA
 }

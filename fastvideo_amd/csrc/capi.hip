@@ -16,6 +16,7 @@ void fvk_set_error(const char* fmt, ...) {
 
 extern "C" const char* fvk_last_error(void) { return g_err; }
 extern "C" int fvk_abi_version(void) { return 4; }
+extern "C" int fvk_is_probe_build(void) { return FVK_VARIANTS; }
 
 extern "C" int fvk_device_arch(char* buf, int len) {
     if (!buf || len <= 0) return FVK_ERR_ARG;
@@ -34,11 +35,17 @@ extern "C" int fvk_device_arch(char* buf, int len) {
 static int g_tunables[fvk::TUNE_COUNT] = {0};
 static const char* const g_tunable_names[fvk::TUNE_COUNT] = {"gemm_impl", "attn_impl", "vae_conv_impl", "vsa_impl", nullptr};
 
+#if FVK_VARIANTS
 int fvk::tunable(int id) { return (id >= 0 && id < fvk::TUNE_COUNT) ? g_tunables[id] : 0; }
+#endif
 
 extern "C" int fvk_set_tunable(const char* name, int value) {
     for (int i = 0; i < fvk::TUNE_COUNT; ++i)
         if (name && g_tunable_names[i] && strcmp(name, g_tunable_names[i]) == 0) {
+#if !FVK_VARIANTS
+            FVK_CHECK(value == 0, FVK_ERR_ARG, "fvk_set_tunable: '%s' = %d: the product library holds the shipped configuration only; measurement "
+                      "variants live in scripts/probes/libfvk_probe.so (FVK_PROBE_LIB=1)", name, value);
+#endif
             g_tunables[i] = value;
             return FVK_OK;
         }

@@ -16,6 +16,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FVK_WAVE 64
 
+// 1 only in the measurement build (scripts/probes/libfvk_probe.so, -DFVK_PROBE_BUILD): non-shipping kernel variants, ablation probes and
+// the fvk_set_tunable knobs that select them are compiled in.  The product library compiles none of that (gemm_common.h: fvk::tunable).
+#ifdef FVK_PROBE_BUILD
+#define FVK_VARIANTS 1
+#else
+#define FVK_VARIANTS 0
+#endif
+
 // error plumbing (host) ---------------------------------------------------------------------
 void fvk_set_error(const char* fmt, ...);
 #define FVK_CHECK(cond, code, ...)        \

@@ -189,7 +189,7 @@ static int gemm_impl(const void* x, const void* w, const void* bias, void* out, 
     hipStream_t s = (hipStream_t)stream;
     // token-axis GEMMs go to the 256x256 LDS-DMA kernels: gemm_ph.hip (K-step 64, the default) or gemm_pp.hip (K % 64 != 0, or forced
     // with gemm_impl 2 / 3); this 128x128 kernel keeps the small / odd shapes (gemm_impl 1 forces it)
-    const int impl = fvk::tunable(fvk::TUNE_GEMM_IMPL);
+    const int impl = fvk::tunable(fvk::TUNE_GEMM_IMPL);  // constant 0 in the product library
     if (impl != 1 && fvk::gemm_pp_eligible(a)) {
         if ((impl == 0 || (impl & 7) == 4) && fvk::gemm_ph_eligible(a)) return fvk::gemm_ph_launch(a, epilogue, batch, s);
         return fvk::gemm_pp_launch(a, epilogue, batch, s);

@@ -34,8 +34,16 @@ int gemm_pp_fp8_launch(GemmArgs a, int epilogue, hipStream_t s);
 bool gemm_ph_eligible(const GemmArgs& a);
 int gemm_ph_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
 
-// capi.hip: integer knobs for within-process A/B measurements (fvk_set_tunable); defaults are the shipped configuration.
+// Integer knobs for within-process A/B measurements (fvk_set_tunable).  They exist only in the MEASUREMENT build of the library
+// (scripts/probes/libfvk_probe.so, compiled with -DFVK_PROBE_BUILD by fastvideo_amd/_build.py: build_probe): there FVK_VARIANTS is 1,
+// the non-shipping kernels and schedules (attn_pp.hip, attn_vsa.hip, the attn_pp2 / gemm_ph / vae_conv3 variants, ablation probes) are
+// compiled in and `tunable()` reads the knob.  In the product library libfvk_amd.so FVK_VARIANTS is 0: every knob is the constant 0,
+// the variant dispatch is not compiled, and fvk_set_tunable accepts only the value 0.
 enum Tunable { TUNE_GEMM_IMPL = 0, TUNE_ATTN_IMPL = 1, TUNE_VAE_CONV_IMPL = 2, TUNE_VSA_IMPL = 3, TUNE_COUNT = 8 };
+#if FVK_VARIANTS  // fvk_common.h
 int tunable(int id);
+#else
+constexpr int tunable(int) { return 0; }
+#endif
 
 }  // namespace fvk

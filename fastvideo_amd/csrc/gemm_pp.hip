@@ -234,6 +234,7 @@ int gemm_pp_fp8_launch(GemmArgs a, int epilogue, hipStream_t s) {
 int gemm_pp_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
     a.ntm = (a.M + TM - 1) / TM;
     a.ntn = (a.N + TN - 1) / TN;
+#if FVK_VARIANTS
     if (fvk::tunable(fvk::TUNE_GEMM_IMPL) == 3) {
         switch (epilogue) {
             case FVK_EPI_NONE: return launch<FVK_EPI_NONE, false, true>(a, batch, s);
@@ -243,6 +244,7 @@ int gemm_pp_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
             default: return launch<FVK_EPI_RESIDUAL_GATE, false, true>(a, batch, s);
         }
     }
+#endif
     switch (epilogue) {
         case FVK_EPI_NONE: return launch<FVK_EPI_NONE>(a, batch, s);
         case FVK_EPI_GELU_TANH: return launch<FVK_EPI_GELU_TANH>(a, batch, s);

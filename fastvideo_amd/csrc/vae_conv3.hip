@@ -486,9 +486,13 @@ template <int WNW>
 int launch3_e(const Conv3Args& a, int epi, bool ups, hipStream_t s) {
     // 96-channel tiles: the staggered schedule (shipped); "vae_conv_impl" 2 = the lockstep schedule, for A/B
     if constexpr (WNW == 1) {
-        if (fvk_vae_conv_tunable() != 2) return launch3_s<1, true>(a, epi, ups, s);
+#if FVK_VARIANTS
+        if (fvk_vae_conv_tunable() == 2) return launch3_s<1, false>(a, epi, ups, s);
+#endif
+        return launch3_s<1, true>(a, epi, ups, s);
+    } else {
+        return launch3_s<WNW, false>(a, epi, ups, s);
     }
-    return launch3_s<WNW, false>(a, epi, ups, s);
 }
 
 }  // namespace

@@ -430,7 +430,7 @@ extern "C" int fvk_topk_mask(const void* scores, int scores_is_fp32, uint8_t* ma
     if (rows <= 0) return FVK_OK;
     if (topk > n) topk = n;
     hipStream_t s = (hipStream_t)stream;
-    if (fvk::tunable(fvk::TUNE_VSA_IMPL) != 1) {  // shipped: one wave per row ("vsa_impl" 1 = the block-per-row kernel, A/B)
+    if (fvk::tunable(fvk::TUNE_VSA_IMPL) != 1) {  // shipped: one wave per row ("vsa_impl" 1 = the block-per-row kernel, measurement build)
         const int wv = (n + 63) / 64;
 #define FVK_TOPKW_CASE(V)                                                                                                             \
     if (wv <= V) {                                                                                                                    \
@@ -441,6 +441,7 @@ extern "C" int fvk_topk_mask(const void* scores, int scores_is_fp32, uint8_t* ma
         FVK_TOPKW_CASE(4) FVK_TOPKW_CASE(8) FVK_TOPKW_CASE(16) FVK_TOPKW_CASE(32) FVK_TOPKW_CASE(64) FVK_TOPKW_CASE(128)
 #undef FVK_TOPKW_CASE
     }
+#if FVK_VARIANTS
     const int vpt = (n + 255) / 256;
 #define FVK_TOPK_CASE(V)                                                                                             \
     if (vpt <= V) {                                                                                                  \
@@ -450,6 +451,7 @@ extern "C" int fvk_topk_mask(const void* scores, int scores_is_fp32, uint8_t* ma
     }
     FVK_TOPK_CASE(1) FVK_TOPK_CASE(2) FVK_TOPK_CASE(4) FVK_TOPK_CASE(8) FVK_TOPK_CASE(16) FVK_TOPK_CASE(32)
 #undef FVK_TOPK_CASE
+#endif
     return FVK_ERR_ARG;
 }
 

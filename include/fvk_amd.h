@@ -29,10 +29,17 @@ extern "C" {
 const char* fvk_last_error(void);
 int fvk_abi_version(void);                 /* bumps when a signature changes */
 int fvk_device_arch(char* buf, int len);   /* gcnArchName of the current device ("gfx950...") */
+int fvk_is_probe_build(void);              /* 0: the product library; 1: the measurement build (scripts/probes/libfvk_probe.so) */
 /* Integer knobs for within-process A/B measurements (scripts/microbench.py); 0 = shipped configuration.
- *   "gemm_impl": 0 auto (256x256 LDS-DMA ping-pong kernel when eligible), 1 force the 128x128 register-staged kernel
- *   "vae_conv_impl": 0 auto (halo-reuse kernel for 3x3 spatial taps), 1 force the per-tap gather kernel
- *   "attn_impl": 0 auto (8-wave ping-pong kernel, 128-key tiles), 1 force the 4-wave kernel, 2.. measurement variants */
+ * The PRODUCT library contains the shipped configuration only: it accepts the known names with value 0 and refuses any other value
+ * (FVK_ERR_ARG).  The non-shipping kernels, schedules and timing ablations live in the measurement build of the same sources
+ * (-DFVK_PROBE_BUILD + scripts/probes/{attn_pp,attn_vsa}.hip -> scripts/probes/libfvk_probe.so; FVK_PROBE_LIB=1 makes the Python
+ * binding load it), where:
+ *   "gemm_impl": 0 auto (256x256 LDS-DMA ping-pong kernel when eligible), 1 force the 128x128 register-staged kernel, 2 / 3 gemm_pp,
+ *                4 + 8 * VAR gemm_ph variants
+ *   "vae_conv_impl": 0 auto (halo-reuse kernel for 3x3 spatial taps), 1 force the per-tap gather kernel, 2 lockstep 96-channel schedule
+ *   "attn_impl": 0 auto (8-wave ping-pong kernel, 128-key tiles), 1 force the 4-wave kernel, 2.. measurement variants, 120 + bits ablations
+ *   "vsa_impl": 1 block-per-row top-k kernel */
 int fvk_set_tunable(const char* name, int value);
 
 /* ------------------------------------------------------------------ norm / modulate family (HBM-bound)

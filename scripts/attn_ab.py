@@ -1,4 +1,6 @@
 """Interleaved A/B of the dense attention variants at the cfg2 shape (S=32760, H=12): python scripts/attn_ab.py [impl ...]"""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,6 @@
 """Segment timing probe of the 8-wave ping-pong attention kernel (fvk tunable attn_impl=14): s_memtime stamps of workgroup 0."""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,7 @@
 """Dense attention at sequence-parallel per-rank shapes: the 8-wave 256-row kernel (attn_impl 0, shipped) vs the 4-wave 128-row kernel
 (attn_impl 1) — does the smaller workgroup fill 256 CUs better when a rank holds only 192-384 query blocks?"""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json, math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

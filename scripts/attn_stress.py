@@ -2,6 +2,8 @@
 output compared bit for bit with the round-1 two-barrier schedule (attn_impl 103).  Rescale spikes at random keys make individual waves
 take the slow branch (1 900 extra cycles), i.e. they skew the two wave groups against each other — the situation in which a ring slot
 refilled too early would be read half-overwritten."""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import os, sys, random
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

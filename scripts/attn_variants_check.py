@@ -1,5 +1,7 @@
 """Bit-identity of the attn_pp2 schedule variants (attn_impl 100 + k) against the 4-wave kernel on small and ragged shapes, then an
 interleaved timing at the cfg2 shape.  usage: python scripts/attn_variants_check.py 103 105 107 109"""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

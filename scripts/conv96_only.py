@@ -1,4 +1,6 @@
 """The 96 -> 96 channel 3x3x3 conv of the VAE's full-resolution stage alone (for PMC passes / timing): T output frames of 480 x 832."""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,6 @@
 """Cross-attention shape (Sq = 32 760 queries, 512 text keys, 12 heads): 8-wave 256-row kernel (attn_impl 0) vs 4-wave 128-row kernel (1)."""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

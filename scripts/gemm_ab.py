@@ -1,4 +1,6 @@
 """Interleaved timing of the GEMM kernels at the cfg2 shapes: python scripts/gemm_ab.py [impl ...] (0 stream, 2 ping-pong, 1 128x128)"""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

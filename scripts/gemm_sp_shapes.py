@@ -1,6 +1,8 @@
 """GEMM kernels at the PER-RANK shapes of sequence-parallel runs (cfg2: M = 32760 / P tokens): 256x256 LDS-DMA kernel (impl 0) vs the
 128x128 kernel (impl 1).  Wave quantisation is what matters here: M = 4095, N = 1536 is 96 tiles of 256x256 on 256 CUs.
 usage: python scripts/gemm_sp_shapes.py [impl ...]"""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json
 import os
 import sys

@@ -1,6 +1,8 @@
 """Per-kernel timings at the Wan2.1-1.3B 81f x 480p (cfg2) shapes, with within-process interleaved A/B of the kernel
 variants behind fvk_set_tunable (guide §5.4 rule 24).  Not the contract bench (see bench.py).
 usage: python scripts/microbench.py [--quick]"""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json
 import os
 import sys

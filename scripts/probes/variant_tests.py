@@ -1,0 +1,214 @@
+"""Tests of the NON-SHIPPING kernel variants and of cross-kernel agreement, run against the MEASUREMENT build of the library
+(scripts/probes/libfvk_probe.so = the product sources with -DFVK_PROBE_BUILD + attn_pp.hip / attn_vsa.hip; the product library
+libfvk_amd.so holds the shipped configuration only and refuses non-zero fvk_set_tunable values).
+
+Not collected by `pytest tests/` directly: tests/test_gpu_probe_variants.py runs this file in a subprocess with FVK_PROBE_LIB=1 (one
+process binds one of the two libraries).  By hand:  FVK_PROBE_LIB=1 python -m pytest scripts/probes/variant_tests.py -q"""
+import os
+import sys
+
+assert os.environ.get("FVK_PROBE_LIB") == "1", "run with FVK_PROBE_LIB=1 (see the module docstring)"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vsa_oracle as V
+from oracle import wan_oracle as W
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fastvideo_amd import ops as o
+    return o
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):
+    return (torch.randn(shape, generator=g(seed)) * scale).to(dtype)
+
+
+def close(a, b, atol=1e-2, rtol=1e-2, what=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs()
+    bad = err > atol + rtol * b.abs()
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements off; max abs err {err.max().item():.4g} "
+                           f"at {np.unravel_index(int(err.argmax()), tuple(err.shape))}, ref there "
+                           f"{b.flatten()[err.argmax()].item():.4g}")
+
+
+# ------------------------------------------------------------------ LN / modulate family
+
+def _lin_ref(x, w, b):
+    return (x.float() @ w.float().t() + (0 if b is None else b.float())).bfloat16()
+
+
+def _attn_check(out, ref, what):
+    """max |err| < 4e-2: the reference's own kernel-test bound (fastvideo-kernel/tests/test_sta.py:88-91).  Mean: the kernel's only bf16
+    roundings are P and the output, and the measured mean |err| is 2.1e-3 x mean |ref| on every case (= the rounding of a bf16 output:
+    half an ulp of 2^-8 relative, on average); the bound is 1.4x that plus an absolute floor for near-zero outputs — not the former
+    absolute 2e-3, which was ~15x what the kernel achieves."""
+    err = (out.float().cpu() - ref).abs()
+    assert torch.isfinite(out.float()).all(), f"{what}: non-finite output"
+    mean_bound = 3e-3 * ref.float().abs().mean().item() + 2e-5
+    assert err.max().item() < 4e-2 and err.mean().item() < mean_bound, \
+        f"{what}: max {err.max().item():.4g} mean {err.mean().item():.4g} (bound {mean_bound:.4g})"
+
+
+@pytest.mark.parametrize("impl", [53, 54])
+def test_attn_block_sparse_measurement_variants(ops, impl):
+    """The two A/B variants of the 64-row list kernel kept in the library ("attn_impl" 53: register-staged loader waves, bit-identical to
+    the shipped kernel; 54: attn_vsa.hip, all waves compute, key-split with a final merge: equal to rounding) on ragged block sizes, odd
+    list counts (an unpaired last list), an empty list and lists from 1 to 9 tiles, against the oracle and the shipped kernel."""
+    B, H, nq, nk = 1, 3, 7, 9
+    q, k, v = rnd((B, H, nq * 64, 128), 1), rnd((B, H, nk * 64, 128), 2), rnd((B, H, nk * 64, 128), 3)
+    rng = np.random.default_rng(impl)
+    bm = rng.random((B, H, nq, nk)) < 0.5
+    bm[..., 0] = True
+    bm[0, 0, 2, :] = False
+    bm[0, 0, 2, 4] = True          # a one-tile list
+    bm[0, 1, 3, :] = True          # all nine
+    bm[0, 2, 5, :] = False         # an empty list
+    vbs = np.array([64, 64, 48, 64, 1, 33, 24, 64, 17], dtype=np.int32)
+    ref = torch.nan_to_num(V.block_sparse_attn(q, k, v, bm, vbs), nan=0.0)
+    idx, num = V.map_to_index(bm)
+    args = (q.to(DEV), k.to(DEV), v.to(DEV), torch.from_numpy(idx).to(DEV), torch.from_numpy(num).to(DEV), torch.from_numpy(vbs).to(DEV))
+    base, base_lse = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
+    ops.set_tunable("attn_impl", impl)
+    try:
+        out, lse = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
+    finally:
+        ops.set_tunable("attn_impl", 0)
+    _attn_check(out, ref, f"block sparse, attn_impl {impl}")
+    assert (out[0, 2, 5 * 64:6 * 64] == 0).all()
+    if impl == 53:
+        assert torch.equal(out, base) and torch.equal(lse, base_lse)
+    else:
+        live = torch.ones(nq, dtype=torch.bool); live_h2 = live.clone(); live_h2[5] = False
+        assert (out.float() - base.float()).abs().max().item() < 8e-3
+        sel = lse[0, 2].view(nq, 64)[live_h2.to(DEV)]
+        assert (sel - base_lse[0, 2].view(nq, 64)[live_h2.to(DEV)]).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("n,topk", [(50, 9), (624, 125), (1440, 288), (7, 7), (8192, 100), (65, 64)])
+def test_topk_mask_block_per_row_variant_bit_exact(ops, n, topk):
+    """"vsa_impl" 1 = one workgroup per row (the first version; the shipped kernel runs one wave per row): same masks."""
+    sc = rnd((3, 5, n), 1, 2.0)
+    sc[0, 0, :] = 0.5
+    sc[1, 1, :] = (torch.arange(n) % 3).to(sc.dtype)
+    ref = V.topk_mask_bisect(sc.float().numpy(), topk)
+    base = ops.topk_mask(sc.to(DEV), topk).cpu().numpy()
+    ops.set_tunable("vsa_impl", 1)
+    try:
+        got = ops.topk_mask(sc.to(DEV), topk).cpu().numpy()
+    finally:
+        ops.set_tunable("vsa_impl", 0)
+    assert np.array_equal(got, ref) and np.array_equal(base, ref)
+
+
+# ------------------------------------------------------------------ large-tile kernels (gemm_pp.hip / attn_pp.hip) and their A/B switches
+@pytest.fixture
+def tunables(ops):
+    yield ops.set_tunable
+    ops.set_tunable("gemm_impl", 0)
+    ops.set_tunable("attn_impl", 0)
+
+
+def test_gemm_kernels_agree(ops, tunables):
+    """The two GEMM kernels accumulate 16-k MFMA steps in the same order: identical outputs except for the GELU formulation."""
+    M, N, K, B = 600, 768, 256, 2
+    x, w, b = rnd((M, K), 1), rnd((N, K), 2, K**-0.5), rnd((N, ), 3)
+    res, gate = rnd((M, N), 4, 2.0), rnd((B, N), 5, 0.5, torch.float32)
+    outs = {}
+    for impl in (0, 1):
+        tunables("gemm_impl", impl)
+        outs[impl] = [ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
+                               gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None).cpu()
+                      for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_RESIDUAL_GATE, ops.EPI_GELU_TANH)]
+    for i in range(3):
+        assert torch.equal(outs[0][i], outs[1][i]), f"epilogue #{i}: kernels disagree"
+    close(outs[0][3], outs[1][3], atol=1e-2, rtol=1e-2, what="gelu formulations")
+    y = _lin_ref(x, w, b)
+    close(outs[0][3], W.gelu_tanh(y), what="gelu (pp)")
+    ref = W.scale_residual(res.view(B, M // B, N), y.view(B, M // B, N), gate.view(B, 1, N)).bfloat16().view(M, N)
+    close(outs[0][2], ref, what="residual+gate (pp)")
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (777, 1000, 192), (1030, 520, 1536), (513, 256, 4096)])
+def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
+    """gemm_ph (shipped, K-step 64), its persistent-workgroup variant and gemm_pp (K-step 32) accumulate the same 16-k MFMA steps in the
+    same order: byte-identical outputs for every epilogue, with a gate whose batch boundary cuts through a wave's 128 rows, a strided A
+    operand (column block of a wider buffer) and the batched entry."""
+    B = 3
+    Mb = M // B * B
+    x, w, b = rnd((Mb, 2 * K), 1)[:, K // 2:K // 2 + K], rnd((N, K), 2, K**-0.5), rnd((N, ), 3)
+    res, gate = rnd((Mb, N), 4, 2.0), rnd((B, N), 5, 0.5, torch.float32)
+    xd = rnd((Mb, 2 * K), 1).to(DEV)[:, K // 2:K // 2 + K]  # row stride 2K
+    outs = {}
+    for impl in (0, 2, 1252):  # shipped gemm_ph | gemm_pp | gemm_ph persistent
+        tunables("gemm_impl", impl)
+        outs[impl] = [ops.gemm(xd, w.to(DEV), b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
+                               gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None).cpu()
+                      for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_GELU_TANH, ops.EPI_RESIDUAL_GATE)]
+        xb, wb = rnd((2, 150, K), 7), rnd((2, 140, K), 8)
+        outs[impl].append(ops.gemm_batched(xb.to(DEV), wb.to(DEV), ops.EPI_DIV, 11.0).cpu())
+    for impl in (2, 1252):
+        for i, (a_, b_) in enumerate(zip(outs[0], outs[impl])):
+            assert torch.equal(a_, b_), f"impl {impl}, output #{i}"
+    close(outs[0][0], _lin_ref(x, w, b), what=f"gemm_ph {Mb}x{N}x{K}")
+
+
+@pytest.mark.parametrize("impl", [0, 1, 2, 3])
+@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 700), (2, 3, 512, 130), (1, 1, 256, 64), (1, 2, 1030, 1999)])
+def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
+    """attn_impl 0/2/3 = 8-wave ping-pong kernel (three DMA placements), 1 = 4-wave kernel; ragged Sq / Skv tails, 1..32 KV tiles."""
+    tunables("attn_impl", impl)
+    q, k, v = rnd((B, Sq, H, 128), 1), rnd((B, Skv, H, 128), 2), rnd((B, Skv, H, 128), 3)
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    out = ops.attn_dense(q.to(DEV), k.to(DEV), v.to(DEV), layout="bshd")
+    _attn_check(out, ref, f"dense impl {impl} {B},{H},{Sq},{Skv}")
+
+
+def test_attn_pp2_schedules_are_bit_identical(ops, tunables):
+    """The schedule variants of the 128-key-tile kernel (attn_pp2.hip: attn_impl 0 = shipped one-barrier / leading-group in-stream DMA;
+    103 = round 1's two-barrier schedule; 111 = V^T pieces inside the trailing matrix segment; 105 / 107 = one barrier with the trailing /
+    leading group issuing ahead of the segment) move DMA issue and barriers only: same arithmetic in the same order, so the outputs must
+    be bit-identical — also with a late rescale spike and ragged tails, and across repeated launches (a slot reused too early or a
+    barrier miscount shows up as a difference or a hang)."""
+    B, H, Sq, Skv = 2, 3, 1030, 2999
+    q, k, v = rnd((B, Sq, H, 128), 1, 0.7), rnd((B, Skv, H, 128), 2, 0.7), rnd((B, Skv, H, 128), 3)
+    k[0, 2500, 1] = q[0, 700, 1] * 6
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    outs = {}
+    for impl in (0, 103, 105, 107, 111, 0):
+        tunables("attn_impl", impl)
+        outs.setdefault(impl, []).append(ops.attn_dense(qd, kd, vd, layout="bshd").cpu())
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    _attn_check(outs[0][0], ref, "attn_pp2 shipped schedule")
+    for impl, lst in outs.items():
+        for o in lst:
+            assert torch.equal(o, outs[0][0]), f"attn_impl {impl} differs from the shipped schedule"
+
+
+@pytest.mark.parametrize("impl", [0, 2, 3])
+def test_attn_pp_rescale_branch_and_repeatability(ops, tunables, impl):
+    """Spiked keys force the running-max rescale in late tiles of the ping-pong kernel; 3 launches must agree bit-for-bit
+    (a race between the staggered wave groups or an early LDS read would show up as run-to-run differences)."""
+    tunables("attn_impl", impl)
+    B, H, S = 1, 2, 640
+    q, k, v = rnd((B, S, H, 128), 1, 0.5), rnd((B, S, H, 128), 2, 0.5), rnd((B, S, H, 128), 3)
+    k[0, 250, 0] = q[0, 7, 0] * 6
+    k[0, 600, 1] = q[0, 300, 1] * 6
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    outs = [ops.attn_dense(q.to(DEV), k.to(DEV), v.to(DEV), layout="bshd").cpu() for _ in range(3)]
+    _attn_check(outs[0], ref, f"rescale branch impl {impl}")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

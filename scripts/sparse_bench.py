@@ -2,6 +2,8 @@
   VSA: 624 blocks of 64 (grid 21x30x52 -> S_pad 39 936), random top-125 lists, 12 heads, the real variable block sizes
   STA: window (3,3,3) of (6,8,8) tiles on the ragged 21x30x52 grid as 128-row block lists (kernel_api.sliding_tile_block_lists)
 Prints ms per launch and algorithmic TFLOP/s (FLOPs of the selected (query, key) pairs only)."""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json
 import os
 import sys

@@ -1,5 +1,7 @@
 """A/B of the 128-row block-sparse (sliding-tile) attention at the 81f x 480p grid: attn_impl 0 (4 compute waves issuing their own DMA, 2 workgroups per CU)
 vs 51 (4 compute + 4 loader waves, 1 workgroup per CU).  Measured on MI355X: 2.87 vs 3.04 ms per launch, bit-identical."""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import sys, json, torch
 sys.path.insert(0, "/root/repo")
 from fastvideo_amd import ops, kernel_api

@@ -1,5 +1,7 @@
 """Workgroup order of the query-grouped sliding-tile attention (fvk_attn_tile_lists_bf16, grid 21x30x52, 12 heads): XCD-contiguous deal vs
 hardware order ("attn_impl" 70), window classes in first-tile order vs longest KV list first."""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

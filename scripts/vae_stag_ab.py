@@ -1,5 +1,7 @@
 """VAE decode A/B of the 96-channel conv schedule: staggered wave groups (shipped, "vae_conv_impl" 0) vs lockstep ("vae_conv_impl" 2),
 interleaved on one box; the two must produce bit-identical pixels (same per-wave MFMA order)."""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -4,6 +4,8 @@
   54 = the key-split kernel (attn_vsa.hip): 8 compute waves, register-staged prefetch two tiles ahead (merges two key halves per row:
        equal to rounding)
 LAYOUT=bhsd makes every 64-key K block one contiguous 16 KiB (bshd: 64 pieces of 256 B, 3 KiB apart)."""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

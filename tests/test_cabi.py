@@ -65,6 +65,9 @@ def test_argument_checks_of_the_newer_entries(lib):
     with pytest.raises(RuntimeError, match="unknown tunable"):
         lib.call("fvk_set_tunable", b"no_such_knob", 1)
     lib.call("fvk_set_tunable", b"vsa_impl", 0)
+    with pytest.raises(RuntimeError, match="libfvk_probe"):   # the product library holds the shipped configuration only
+        lib.call("fvk_set_tunable", b"vsa_impl", 1)
+    assert lib.load().fvk_is_probe_build() == 0
 
 
 def test_tile_lists_attention_argument_checks(lib):
@@ -160,3 +163,17 @@ def test_no_cpu_fallback(lib):
     from fastvideo_amd import ops
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.gemm(torch.zeros(4, 64, dtype=torch.bfloat16), torch.zeros(4, 64, dtype=torch.bfloat16))
+
+
+def test_measurement_build_loads_and_exports_the_same_abi():
+    """scripts/probes/libfvk_probe.so (built by build()): the product sources + the non-shipping variants behind fvk_set_tunable.  It
+    must export every symbol of include/fvk_amd.h too (the measurement scripts run the whole Python binding on it) and say what it is."""
+    import subprocess
+    import sys
+    code = ("import os; os.environ['FVK_PROBE_LIB']='1'\n"
+            "from fastvideo_amd import _lib\n"
+            "l=_lib.load(); assert l.fvk_is_probe_build()==1 and _lib.LIB_PATH.endswith('libfvk_probe.so')\n"
+            "_lib.call('fvk_set_tunable', b'attn_impl', 103); _lib.call('fvk_set_tunable', b'attn_impl', 0); print('probe-ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "probe-ok" in r.stdout, r.stdout[-2000:]

@@ -259,41 +259,6 @@ def test_attn_block_sparse(ops):
     assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
 
 
-@pytest.mark.parametrize("impl", [53, 54])
-def test_attn_block_sparse_measurement_variants(ops, impl):
-    """The two A/B variants of the 64-row list kernel kept in the library ("attn_impl" 53: register-staged loader waves, bit-identical to
-    the shipped kernel; 54: attn_vsa.hip, all waves compute, key-split with a final merge: equal to rounding) on ragged block sizes, odd
-    list counts (an unpaired last list), an empty list and lists from 1 to 9 tiles, against the oracle and the shipped kernel."""
-    B, H, nq, nk = 1, 3, 7, 9
-    q, k, v = rnd((B, H, nq * 64, 128), 1), rnd((B, H, nk * 64, 128), 2), rnd((B, H, nk * 64, 128), 3)
-    rng = np.random.default_rng(impl)
-    bm = rng.random((B, H, nq, nk)) < 0.5
-    bm[..., 0] = True
-    bm[0, 0, 2, :] = False
-    bm[0, 0, 2, 4] = True          # a one-tile list
-    bm[0, 1, 3, :] = True          # all nine
-    bm[0, 2, 5, :] = False         # an empty list
-    vbs = np.array([64, 64, 48, 64, 1, 33, 24, 64, 17], dtype=np.int32)
-    ref = torch.nan_to_num(V.block_sparse_attn(q, k, v, bm, vbs), nan=0.0)
-    idx, num = V.map_to_index(bm)
-    args = (q.to(DEV), k.to(DEV), v.to(DEV), torch.from_numpy(idx).to(DEV), torch.from_numpy(num).to(DEV), torch.from_numpy(vbs).to(DEV))
-    base, base_lse = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
-    ops.set_tunable("attn_impl", impl)
-    try:
-        out, lse = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
-    finally:
-        ops.set_tunable("attn_impl", 0)
-    _attn_check(out, ref, f"block sparse, attn_impl {impl}")
-    assert (out[0, 2, 5 * 64:6 * 64] == 0).all()
-    if impl == 53:
-        assert torch.equal(out, base) and torch.equal(lse, base_lse)
-    else:
-        live = torch.ones(nq, dtype=torch.bool); live_h2 = live.clone(); live_h2[5] = False
-        assert (out.float() - base.float()).abs().max().item() < 8e-3
-        sel = lse[0, 2].view(nq, 64)[live_h2.to(DEV)]
-        assert (sel - base_lse[0, 2].view(nq, 64)[live_h2.to(DEV)]).abs().max().item() < 1e-3
-
-
 @pytest.mark.parametrize("rows", [256, 384, 512])
 def test_attn_tile_lists_shared_kv_lists(ops, rows):
     """fvk_attn_tile_lists_bf16: every `rows` consecutive query rows share one list of 64-key blocks (sliding-tile windows).  Against the
@@ -422,16 +387,11 @@ def test_topk_mask_bit_exact(ops, n, topk):
     sc[0, 0, :] = 0.5            # an all-equal row
     sc[1, 1, :] = (torch.arange(n) % 3).to(sc.dtype)  # three values only: the tie rule decides almost everything
     ref = V.topk_mask_bisect(sc.float().numpy(), topk)
-    for impl in (0, 1):  # 0 = one wave per row (shipped), 1 = one workgroup per row
-        ops.set_tunable("vsa_impl", impl)
-        try:
-            got = ops.topk_mask(sc.to(DEV), topk).cpu().numpy()
-            got32 = ops.topk_mask(sc.float().to(DEV), topk).cpu().numpy()
-        finally:
-            ops.set_tunable("vsa_impl", 0)
-        assert np.array_equal(got, ref), impl
-        assert (got.sum(-1) == min(topk, n)).all()
-        assert np.array_equal(got32, ref), impl
+    got = ops.topk_mask(sc.to(DEV), topk).cpu().numpy()     # one wave per row (the block-per-row variant: scripts/probes/variant_tests.py)
+    got32 = ops.topk_mask(sc.float().to(DEV), topk).cpu().numpy()
+    assert np.array_equal(got, ref)
+    assert (got.sum(-1) == min(topk, n)).all()
+    assert np.array_equal(got32, ref)
 
 
 def test_map_to_index_and_gather(ops):
@@ -515,14 +475,7 @@ def test_errors_are_loud(ops):
         ops.attn_dense(rnd((1, 8, 1, 64), 1).to(DEV), rnd((1, 8, 1, 64), 2).to(DEV), rnd((1, 8, 1, 64), 3).to(DEV))
 
 
-# ------------------------------------------------------------------ large-tile kernels (gemm_pp.hip / attn_pp.hip) and their A/B switches
-@pytest.fixture
-def tunables(ops):
-    yield ops.set_tunable
-    ops.set_tunable("gemm_impl", 0)
-    ops.set_tunable("attn_impl", 0)
-
-
+# ------------------------------------------------------------------ large-tile kernels (gemm_pp.hip) at shapes that take them by default
 @pytest.mark.parametrize("M,N,K", [(1000, 1536, 1536), (777, 520, 96), (513, 264, 32), (2048, 256, 64), (129, 8, 1536)])
 def test_gemm_pp_shapes(ops, M, N, K):
     """Shapes that take the 256x256 LDS-DMA ping-pong kernel: ragged M/N tiles, 1..48 K-steps (ring prologue / tail re-reads)."""
@@ -541,94 +494,3 @@ def test_gemm_pp_identity_asymmetric(ops):
     x2[:, 512:1024] = torch.eye(512).bfloat16()
     w2 = (torch.arange(300 * K2).view(300, K2) % 241).float().bfloat16()[:296]
     assert torch.equal(ops.gemm(x2.to(DEV), w2.to(DEV), None).cpu(), w2[:, 512:1024].t().contiguous())
-
-
-def test_gemm_kernels_agree(ops, tunables):
-    """The two GEMM kernels accumulate 16-k MFMA steps in the same order: identical outputs except for the GELU formulation."""
-    M, N, K, B = 600, 768, 256, 2
-    x, w, b = rnd((M, K), 1), rnd((N, K), 2, K**-0.5), rnd((N, ), 3)
-    res, gate = rnd((M, N), 4, 2.0), rnd((B, N), 5, 0.5, torch.float32)
-    outs = {}
-    for impl in (0, 1):
-        tunables("gemm_impl", impl)
-        outs[impl] = [ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
-                               gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None).cpu()
-                      for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_RESIDUAL_GATE, ops.EPI_GELU_TANH)]
-    for i in range(3):
-        assert torch.equal(outs[0][i], outs[1][i]), f"epilogue #{i}: kernels disagree"
-    close(outs[0][3], outs[1][3], atol=1e-2, rtol=1e-2, what="gelu formulations")
-    y = _lin_ref(x, w, b)
-    close(outs[0][3], W.gelu_tanh(y), what="gelu (pp)")
-    ref = W.scale_residual(res.view(B, M // B, N), y.view(B, M // B, N), gate.view(B, 1, N)).bfloat16().view(M, N)
-    close(outs[0][2], ref, what="residual+gate (pp)")
-
-
-@pytest.mark.parametrize("M,N,K", [(300, 264, 128), (777, 1000, 192), (1030, 520, 1536), (513, 256, 4096)])
-def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
-    """gemm_ph (shipped, K-step 64), its persistent-workgroup variant and gemm_pp (K-step 32) accumulate the same 16-k MFMA steps in the
-    same order: byte-identical outputs for every epilogue, with a gate whose batch boundary cuts through a wave's 128 rows, a strided A
-    operand (column block of a wider buffer) and the batched entry."""
-    B = 3
-    Mb = M // B * B
-    x, w, b = rnd((Mb, 2 * K), 1)[:, K // 2:K // 2 + K], rnd((N, K), 2, K**-0.5), rnd((N, ), 3)
-    res, gate = rnd((Mb, N), 4, 2.0), rnd((B, N), 5, 0.5, torch.float32)
-    xd = rnd((Mb, 2 * K), 1).to(DEV)[:, K // 2:K // 2 + K]  # row stride 2K
-    outs = {}
-    for impl in (0, 2, 1252):  # shipped gemm_ph | gemm_pp | gemm_ph persistent
-        tunables("gemm_impl", impl)
-        outs[impl] = [ops.gemm(xd, w.to(DEV), b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
-                               gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None).cpu()
-                      for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_GELU_TANH, ops.EPI_RESIDUAL_GATE)]
-        xb, wb = rnd((2, 150, K), 7), rnd((2, 140, K), 8)
-        outs[impl].append(ops.gemm_batched(xb.to(DEV), wb.to(DEV), ops.EPI_DIV, 11.0).cpu())
-    for impl in (2, 1252):
-        for i, (a_, b_) in enumerate(zip(outs[0], outs[impl])):
-            assert torch.equal(a_, b_), f"impl {impl}, output #{i}"
-    close(outs[0][0], _lin_ref(x, w, b), what=f"gemm_ph {Mb}x{N}x{K}")
-
-
-@pytest.mark.parametrize("impl", [0, 1, 2, 3])
-@pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 700), (2, 3, 512, 130), (1, 1, 256, 64), (1, 2, 1030, 1999)])
-def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
-    """attn_impl 0/2/3 = 8-wave ping-pong kernel (three DMA placements), 1 = 4-wave kernel; ragged Sq / Skv tails, 1..32 KV tiles."""
-    tunables("attn_impl", impl)
-    q, k, v = rnd((B, Sq, H, 128), 1), rnd((B, Skv, H, 128), 2), rnd((B, Skv, H, 128), 3)
-    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
-    out = ops.attn_dense(q.to(DEV), k.to(DEV), v.to(DEV), layout="bshd")
-    _attn_check(out, ref, f"dense impl {impl} {B},{H},{Sq},{Skv}")
-
-
-def test_attn_pp2_schedules_are_bit_identical(ops, tunables):
-    """The schedule variants of the 128-key-tile kernel (attn_pp2.hip: attn_impl 0 = shipped one-barrier / leading-group in-stream DMA;
-    103 = round 1's two-barrier schedule; 111 = V^T pieces inside the trailing matrix segment; 105 / 107 = one barrier with the trailing /
-    leading group issuing ahead of the segment) move DMA issue and barriers only: same arithmetic in the same order, so the outputs must
-    be bit-identical — also with a late rescale spike and ragged tails, and across repeated launches (a slot reused too early or a
-    barrier miscount shows up as a difference or a hang)."""
-    B, H, Sq, Skv = 2, 3, 1030, 2999
-    q, k, v = rnd((B, Sq, H, 128), 1, 0.7), rnd((B, Skv, H, 128), 2, 0.7), rnd((B, Skv, H, 128), 3)
-    k[0, 2500, 1] = q[0, 700, 1] * 6
-    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
-    outs = {}
-    for impl in (0, 103, 105, 107, 111, 0):
-        tunables("attn_impl", impl)
-        outs.setdefault(impl, []).append(ops.attn_dense(qd, kd, vd, layout="bshd").cpu())
-    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
-    _attn_check(outs[0][0], ref, "attn_pp2 shipped schedule")
-    for impl, lst in outs.items():
-        for o in lst:
-            assert torch.equal(o, outs[0][0]), f"attn_impl {impl} differs from the shipped schedule"
-
-
-@pytest.mark.parametrize("impl", [0, 2, 3])
-def test_attn_pp_rescale_branch_and_repeatability(ops, tunables, impl):
-    """Spiked keys force the running-max rescale in late tiles of the ping-pong kernel; 3 launches must agree bit-for-bit
-    (a race between the staggered wave groups or an early LDS read would show up as run-to-run differences)."""
-    tunables("attn_impl", impl)
-    B, H, S = 1, 2, 640
-    q, k, v = rnd((B, S, H, 128), 1, 0.5), rnd((B, S, H, 128), 2, 0.5), rnd((B, S, H, 128), 3)
-    k[0, 250, 0] = q[0, 7, 0] * 6
-    k[0, 600, 1] = q[0, 300, 1] * 6
-    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
-    outs = [ops.attn_dense(q.to(DEV), k.to(DEV), v.to(DEV), layout="bshd").cpu() for _ in range(3)]
-    _attn_check(outs[0], ref, f"rescale branch impl {impl}")
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
