@@ -39,6 +39,7 @@ SIGNATURES = {
     "fvk_rmsnorm_rope_scatter_bf16": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, i32, i32, i32, i32, i32, i64, i64, f32,
                                       C.POINTER(vp), vp],
     "fvk_qkv_norm_rope_pack_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, i32, f32, vp],
+    "fvk_qkvg_norm_rope_pack_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, i32, f32, vp],
     "fvk_v_transpose_bf16": [vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp],
     "fvk_v_transpose_gather_bf16": [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp],
     "fvk_gemm_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i32, vp, vp, i32, vp],

@@ -137,9 +137,9 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs a) {
 }
 
 struct RmsArgs {
-    const bf16_t* in[3];
-    bf16_t* out[3];
-    const bf16_t* w[3];
+    const bf16_t* in[4];
+    bf16_t* out[4];
+    const bf16_t* w[4];
     const float* cos;
     const float* sin;
     int M, width, head_dim, seq_len, pos_offset;
@@ -147,13 +147,13 @@ struct RmsArgs {
     float eps;
     int rope_mask;       // bit t: tensor t is rotated (when cos/sin are given)
     // sequence-parallel exchange packing (fvk_qkv_norm_rope_pack_bf16): when pack_dst is set, column block g (pack_W wide) of row m of
-    // tensor t is written to every destination rank rp = g + pack_G*u', u' < pack_U, at pack_dst[((rp*M + m)*3 + pack_slot[t])*pack_W + cc]
+    // tensor t is written to every destination rank rp = g + pack_G*u', u' < pack_U, at pack_dst[((rp*M + m)*pack_ns + pack_slot[t])*pack_W + cc]
     bf16_t* pack_dst;
-    int pack_G, pack_U, pack_W;
-    int pack_slot[3];
+    int pack_G, pack_U, pack_W, pack_ns;  // pack_ns = slots per message row: 3 = [K | V | Q], 4 = [K | V | Q | gate]
+    int pack_slot[4];
     // scatter (fvk_rmsnorm_rope_scatter_bf16): row m of tensor t is written to row row_map[t][m] of out[t] (negative: dropped); NULL = row m.
     // Folds the tile-major / window-class gathers of the sparse attention paths into this pass.
-    const int32_t* row_map[3];
+    const int32_t* row_map[4];
 };
 
 template <int VPL>
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs a) {
                 const int col = c * 8, g = col / a.pack_W, cc = col - g * a.pack_W;
                 for (int uu = 0; uu < a.pack_U; ++uu) {
                     const long rp = g + (long)a.pack_G * uu;
-                    st_bf16x8(a.pack_dst + ((rp * a.M + row) * 3 + a.pack_slot[t]) * a.pack_W + cc, o);
+                    st_bf16x8(a.pack_dst + ((rp * a.M + row) * a.pack_ns + a.pack_slot[t]) * a.pack_W + cc, o);
                 }
             } else {
                 st_bf16x8(out + c * 8, o);
@@ -392,9 +392,26 @@ static int rmsnorm_rope_impl(const void* const* in, void* const* out, const void
     return FVK_OK;
 }
 
+static int qkv_pack_impl(const void* q, const void* k, const void* v, const void* gate, const void* wq, const void* wk, const float* cos,
+                         const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset, long in_stride, int G, int U,
+                         float eps, void* stream);
+
 extern "C" int fvk_qkv_norm_rope_pack_bf16(const void* q, const void* k, const void* v, const void* wq, const void* wk, const float* cos,
                                            const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset,
                                            long in_stride, int G, int U, float eps, void* stream) {
+    return qkv_pack_impl(q, k, v, nullptr, wq, wk, cos, sin, send, Sl, width, head_dim, seq_len, pos_offset, in_stride, G, U, eps, stream);
+}
+
+extern "C" int fvk_qkvg_norm_rope_pack_bf16(const void* q, const void* k, const void* v, const void* gate, const void* wq, const void* wk,
+                                            const float* cos, const float* sin, void* send, int Sl, int width, int head_dim, int seq_len,
+                                            int pos_offset, long in_stride, int G, int U, float eps, void* stream) {
+    FVK_CHECK(gate, FVK_ERR_ARG, "fvk_qkvg_norm_rope_pack_bf16: null gate (use fvk_qkv_norm_rope_pack_bf16)");
+    return qkv_pack_impl(q, k, v, gate, wq, wk, cos, sin, send, Sl, width, head_dim, seq_len, pos_offset, in_stride, G, U, eps, stream);
+}
+
+static int qkv_pack_impl(const void* q, const void* k, const void* v, const void* gate, const void* wq, const void* wk, const float* cos,
+                         const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset, long in_stride, int G, int U,
+                         float eps, void* stream) {
     FVK_CHECK(q && k && v && send, FVK_ERR_ARG, "fvk_qkv_norm_rope_pack_bf16: null pointer");
     FVK_CHECK(width > 0 && head_dim > 0 && head_dim % 8 == 0 && width % head_dim == 0, FVK_ERR_ARG,
               "fvk_qkv_norm_rope_pack_bf16: width=%d head_dim=%d", width, head_dim);
@@ -404,16 +421,17 @@ extern "C" int fvk_qkv_norm_rope_pack_bf16(const void* q, const void* k, const v
     FVK_CHECK(pos_offset >= 0 && seq_len > 0 && in_stride % 8 == 0, FVK_ERR_ARG, "fvk_qkv_norm_rope_pack_bf16: strides must be multiples of 8");
     if (Sl <= 0) return FVK_OK;
     RmsArgs a{};
-    a.in[0] = (const bf16_t*)q; a.in[1] = (const bf16_t*)k; a.in[2] = (const bf16_t*)v;
-    a.out[0] = a.out[1] = a.out[2] = (bf16_t*)send;  // unused: every store goes through pack_dst
-    a.w[0] = (const bf16_t*)wq; a.w[1] = (const bf16_t*)wk; a.w[2] = nullptr;  // V: no norm
+    const int ns = gate ? 4 : 3;
+    a.in[0] = (const bf16_t*)q; a.in[1] = (const bf16_t*)k; a.in[2] = (const bf16_t*)v; a.in[3] = (const bf16_t*)gate;
+    a.out[0] = a.out[1] = a.out[2] = a.out[3] = (bf16_t*)send;  // unused: every store goes through pack_dst
+    a.w[0] = (const bf16_t*)wq; a.w[1] = (const bf16_t*)wk; a.w[2] = a.w[3] = nullptr;  // V, gate: no norm
     a.cos = cos; a.sin = sin; a.M = Sl; a.width = width; a.head_dim = head_dim; a.seq_len = seq_len; a.pos_offset = pos_offset;
     a.in_stride = in_stride; a.out_stride = 0; a.eps = eps;
-    a.rope_mask = 3;  // q and k are rotated, v is copied
-    a.pack_dst = (bf16_t*)send; a.pack_G = G; a.pack_U = U; a.pack_W = width / G;
-    a.pack_slot[0] = 2; a.pack_slot[1] = 0; a.pack_slot[2] = 1;  // message row = [K | V | Q] of one token
+    a.rope_mask = 3;  // q and k are rotated, v (and the gate) are copied
+    a.pack_dst = (bf16_t*)send; a.pack_G = G; a.pack_U = U; a.pack_W = width / G; a.pack_ns = ns;
+    a.pack_slot[0] = 2; a.pack_slot[1] = 0; a.pack_slot[2] = 1; a.pack_slot[3] = 3;  // message row = [K | V | Q (| gate)] of one token
     int rc = dispatch_vpl(width, [&](auto vpl) {
-        hipLaunchKernelGGL((rmsnorm_rope_kernel<decltype(vpl)::value>), dim3((Sl + 3) / 4, 3), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((rmsnorm_rope_kernel<decltype(vpl)::value>), dim3((Sl + 3) / 4, ns), dim3(256), 0, (hipStream_t)stream, a);
         return FVK_OK;
     });
     FVK_CHECK(rc == FVK_OK, rc, "fvk_qkv_norm_rope_pack_bf16: unsupported width=%d", width);

@@ -61,6 +61,19 @@ class SPLayout:
         return self.H // self.G
 
 
+@dataclass
+class BlockPlan:
+    """Uneven exchange #2 of the tile-major sparse modes on a G x U grid (``SequenceParallel.block_plan``): rank (g, u) owns the
+    tile-major rows [r0, r1) — whole query blocks, the u-th of U contiguous runs of the block list — of every head of group g."""
+    r0: int
+    r1: int
+    send_tokens: torch.Tensor   # int32 [n_send]: this rank's real tokens, ascending = grouped by destination shard
+    in_splits: list             # rows sent to each rank (the owner of each token's shard)
+    out_splits: list            # rows received from each rank
+    asm_idx: torch.Tensor       # int32 [Sl * G]: row of the received buffer holding (local token p, head group g'); pad tokens -> row 0
+    n_recv: int
+
+
 class SequenceParallel:
 
     def __init__(self, num_heads: int, group=None):
@@ -159,32 +172,105 @@ class SequenceParallel:
         return lambda: (work.wait(), recv, send)[1]  # `send` stays referenced until the exchange has been waited for
 
     # ---- exchange #1, row-interleaved uniform layout ------------------------------------------------------------------------
-    def pack_rows(self, q, k, v):
+    def pack_rows(self, q, k, v, gate=None):
         """Layout restatement (plain torch, any device) of what ``ops.qkv_norm_rope_pack`` writes on the GPU: q, k, v [Sl, H, D]
-        (already normed / rotated) -> send [P, Sl, 3, W], message row = [K | V | Q] of the destination's head group.  Used by the
-        CPU (gloo) tests and as the checker of the kernel's layout; the device path never calls it."""
+        (already normed / rotated) -> send [P, Sl, 3, W], message row = [K | V | Q] of the destination's head group; with ``gate``
+        (the VSA compress gate, a fourth per-token per-head tensor) [P, Sl, 4, W] = [K | V | Q | gate].  Used by the CPU (gloo)
+        tests and as the checker of the kernel's layout; the device path never calls it."""
         L = self.lay
         Sl, H, D = q.shape
         W = (H // L.G) * D
-        rows = torch.stack([t.reshape(Sl, L.G, W) for t in (k, v, q)], dim=2)       # [Sl, G, 3, W]
+        parts = (k, v, q) if gate is None else (k, v, q, gate)
+        rows = torch.stack([t.reshape(Sl, L.G, W) for t in parts], dim=2)           # [Sl, G, NS, W]
         return rows.permute(1, 0, 2, 3).repeat(L.U, 1, 1, 1).contiguous()           # rank rp = g + G*u' gets group g
 
     def exchange_rows(self, send: torch.Tensor) -> torch.Tensor:
-        """send [P, Sl, 3, W] -> recv [P*Sl, 3, hg, D]: row n = s*Sl + m is token m of source rank s = global token n."""
+        """send [P, Sl, NS, W] -> recv [P*Sl, NS, W] (NS = 3 or 4 slots): row n = s*Sl + m is token m of source rank s = global token n."""
         L = self.lay
-        P, Sl, _, W = send.shape
+        P, Sl, NS, W = send.shape
         t0 = self._tick()
-        recv = self._a2a(send.reshape(P * Sl, 3 * W), None, None, P * Sl)
+        recv = self._a2a(send.reshape(P * Sl, NS * W), None, None, P * Sl)
         self._tock(t0, "exchange1", send.numel() * send.element_size() * (P - 1) // P)
-        return recv.view(P * Sl, 3, W)
+        return recv.view(P * Sl, NS, W)
 
     def views_of(self, recv: torch.Tensor, D: int):
-        """(q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all [P*Sl, hg, D]) as strided VIEWS of the received buffer (row stride 3W)."""
+        """(q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all [P*Sl, hg, D]) as strided VIEWS of the received buffer (row stride NS*W)."""
         L = self.lay
-        n, _, W = recv.shape
+        n, NS, W = recv.shape
         Sl = n // L.P
-        r4 = recv.view(n, 3, W // D, D)
+        r4 = recv.view(n, NS, W // D, D)
         return r4[L.u * L.G * Sl:(L.u + 1) * L.G * Sl, 2], r4[:, 0], r4[:, 1]
+
+    # ---- tile-major sparse modes (video-sparse / sliding-tile attention) on the G x U grid -------------------------------------
+    def block_plan(self, token_of_row: torch.Tensor, Sl: int, block: int = 64) -> BlockPlan:
+        """Integer plan of the sparse modes' output exchange.  ``token_of_row`` (int [S_pad], -1 = padding row) maps the tile-major
+        padded rows of the WHOLE sequence to global tokens.  The query blocks (``block`` rows each) are cut into U contiguous runs; rank
+        (g, u) computes run u for head group g — against all keys, which every rank of column g holds after exchange #1, as it holds
+        every query and (VSA) every gate row, because Q travels with K and V.  A run's tokens are scattered over all shards (tiles cut
+        across the raster order), so exchange #2 is an all-to-all with UNEVEN splits: rank (g, u) sends each shard owner the rows of that
+        shard's tokens in run u (ascending token order), and a shard owner assembles [Sl, G, hg*D] from G x U sources through
+        ``asm_idx``.  U = 1 degenerates to the equal-split exchange of the dense path (every run is the whole sequence) and is served by it.
+        Everything here is host-side integer work, identical on every rank, cached by the caller per (grid, layout)."""
+        L = self.lay
+        tor = token_of_row.detach().cpu().to(torch.int64)
+        n_blocks = tor.numel() // block
+        if tor.numel() % block:
+            raise ValueError("block_plan: the tile-major row count must be a multiple of the block size")
+        cuts = [n_blocks * u // L.U * block for u in range(L.U + 1)]
+        own = []                                   # per run: its real tokens, ascending
+        for u in range(L.U):
+            t = tor[cuts[u]:cuts[u + 1]]
+            own.append(torch.sort(t[t >= 0]).values)
+        counts = torch.stack([torch.bincount(torch.div(t, Sl, rounding_mode="floor"), minlength=L.P)[:L.P] for t in own])  # [U, P shards]
+        mine, me = own[L.u], L.rank
+        in_splits = [int(c) for c in counts[L.u]]
+        out_splits = [int(counts[rp // L.G, me]) for rp in range(L.P)]
+        offs = [0]
+        for c in out_splits:
+            offs.append(offs[-1] + c)
+        run_of_token = torch.full((L.P * Sl,), -1, dtype=torch.int64)
+        idx_in_run = torch.zeros((L.P * Sl,), dtype=torch.int64)
+        for u in range(L.U):
+            t = own[u]
+            run_of_token[t] = u
+            shard = torch.div(t, Sl, rounding_mode="floor")
+            first = torch.searchsorted(t, shard * Sl)            # index of the shard's first token inside the run
+            idx_in_run[t] = torch.arange(t.numel()) - first
+        asm = torch.zeros((Sl, L.G), dtype=torch.int64)
+        loc = torch.arange(me * Sl, (me + 1) * Sl)
+        real = run_of_token[loc] >= 0
+        for g in range(L.G):
+            src = g + L.G * run_of_token[loc].clamp_min(0)
+            asm[:, g] = torch.where(real, torch.tensor(offs)[src] + idx_in_run[loc], torch.zeros_like(src))
+        return BlockPlan(r0=cuts[L.u], r1=cuts[L.u + 1], send_tokens=mine.to(torch.int32), in_splits=in_splits, out_splits=out_splits,
+                         asm_idx=asm.reshape(-1).to(torch.int32), n_recv=offs[-1])
+
+    @staticmethod
+    def _take_rows(t: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        """rows t[idx] of a [n, ...] tensor: one gather kernel on the device, index_select on the CPU (gloo tests)."""
+        if t.is_cuda:
+            from . import ops
+            return ops.gather_rows(t.reshape(1, t.shape[0], -1), idx.numel(), src_index=idx.to(t.device))[0].view(idx.numel(), *t.shape[1:])
+        return t.index_select(0, idx.to(torch.int64))
+
+    def attention_blocks(self, send: torch.Tensor, plan: BlockPlan, block_fn, head_dim: int = 128) -> torch.Tensor:
+        """Sparse tile-major attention under sequence parallelism.  ``send`` [P, Sl, NS, W] (``ops.qkv_norm_rope_pack`` with or without
+        the gate slot, or ``pack_rows``).  ``block_fn(recv4, plan)`` gets the received buffer as [P*Sl, NS, hg, D] (token-major: slot 0 K,
+        1 V, 2 Q, 3 gate; rows >= S are padding) and returns o [P*Sl, hg, D] in TOKEN order in which the rows of this rank's own tokens
+        (the real tokens of tile-major rows [plan.r0, plan.r1)) are valid.  Returns this rank's shard [Sl, H, D]."""
+        L = self.lay
+        Sl = send.shape[1]
+        recv = self.exchange_rows(send)
+        n, NS, W = recv.shape
+        o_tok = block_fn(recv.view(n, NS, W // head_dim, head_dim), plan)
+        if L.U == 1:
+            return self.scatter_seq_gather_heads(o_tok, Sl)   # every rank computed all tokens of its head group: the dense path's exchange
+        hg, D = o_tok.shape[1], o_tok.shape[2]
+        packed = self._take_rows(o_tok, plan.send_tokens)
+        t0 = self._tick()
+        got = self._a2a(packed, plan.in_splits, plan.out_splits, plan.n_recv)
+        self._tock(t0, "exchange2", (packed.shape[0] - plan.in_splits[L.rank]) * hg * D * packed.element_size())
+        return self._take_rows(got, plan.asm_idx).reshape(Sl, L.G * hg, D)
 
     def scatter_heads_gather_seq(self, q, k, v):
         """q,k,v: this rank's shard [Sl, H, D] (batch 1).  Returns (q_blk [G*Sl, hg, D], k_all [P*Sl, hg, D], v_all) — views of ONE

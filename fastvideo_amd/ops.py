@@ -158,24 +158,31 @@ def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_le
     return outs
 
 
-def qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, G, U, head_dim=128, seq_len=None, eps=1e-6, pos_offset=0, out=None):
+def qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, G, U, head_dim=128, seq_len=None, eps=1e-6, pos_offset=0, out=None, gate=None):
     """Exchange #1 of the 2-D Ulysses sequence parallelism, packed by the norm / RoPE pass itself (fvk_qkv_norm_rope_pack_bf16).
     q, k, v: bf16 [Sl, width] views with unit column stride and one common row stride (column blocks of the fused QKV buffer).
-    Returns the send buffer [G*U, Sl, 3, width // G]: per destination rank, per token, [K | V | Q] of that rank's head group."""
+    Returns the send buffer [G*U, Sl, 3, width // G]: per destination rank, per token, [K | V | Q] of that rank's head group.
+    gate (the VSA compress gate, a fourth column block of the same buffer): [G*U, Sl, 4, width // G] = [K | V | Q | gate]
+    (fvk_qkvg_norm_rope_pack_bf16)."""
     Sl, width = q.shape
     stride = q.stride(0)
-    for t in (q, k, v):
+    ns = 3 if gate is None else 4
+    for t in (q, k, v) if gate is None else (q, k, v, gate):
         _chk(t, BF16, "tensor")
         if t.shape != (Sl, width) or t.stride(1) != 1 or t.stride(0) != stride:
             raise RuntimeError("qkv_norm_rope_pack: q, k, v must be [Sl,width] views with unit column stride and a common row stride")
     W = width // G
     if out is None:
-        out = torch.empty((G * U, Sl, 3, W), dtype=BF16, device=q.device)
-    elif tuple(out.shape) != (G * U, Sl, 3, W) or out.dtype != BF16 or not out.is_contiguous():
-        raise RuntimeError("qkv_norm_rope_pack: `out` must be a contiguous bf16 [G*U, Sl, 3, width//G] buffer")
+        out = torch.empty((G * U, Sl, ns, W), dtype=BF16, device=q.device)
+    elif tuple(out.shape) != (G * U, Sl, ns, W) or out.dtype != BF16 or not out.is_contiguous():
+        raise RuntimeError(f"qkv_norm_rope_pack: `out` must be a contiguous bf16 [G*U, Sl, {ns}, width//G] buffer")
     wq = None if wq is None else _chk(wq, BF16, "wq").contiguous()
     wk = None if wk is None else _chk(wk, BF16, "wk").contiguous()
     cos, sin = _f32(cos, "cos"), _f32(sin, "sin")
+    if gate is not None:
+        _lib.call("fvk_qkvg_norm_rope_pack_bf16", _p(q), _p(k), _p(v), _p(gate), _p(wq), _p(wk), _p(cos), _p(sin), _p(out), Sl, width, head_dim,
+                  seq_len or Sl, int(pos_offset), stride, int(G), int(U), float(eps), _stream())
+        return out
     _lib.call("fvk_qkv_norm_rope_pack_bf16", _p(q), _p(k), _p(v), _p(wq), _p(wk), _p(cos), _p(sin), _p(out), Sl, width, head_dim,
               seq_len or Sl, int(pos_offset), stride, int(G), int(U), float(eps), _stream())
     return out

@@ -53,11 +53,11 @@ class WanTransformer3DModelHip:
             raise ValueError(f"unknown quantization {quantization!r}")
         self.quant = quantization
         self.sp = SequenceParallel(num_heads, sp_group)
-        if attention != "dense" and self.sp.lay.U != 1:
-            # tiling / block selection needs every token of a head on one rank: plain Ulysses only, like the reference, whose
-            # VSA path tiles after its all-to-all on the full sequence (fastvideo/attention/layer.py:228)
-            raise NotImplementedError(f"{attention} attention needs num_heads divisible by the SP world size "
-                                      f"(heads {num_heads}, world {self.sp.lay.P})")
+        if attention == "sta" and self.sp.lay.U != 1:
+            # sliding-tile queries are packed by window class into 256-row groups that share a KV list: cutting that list over U query
+            # runs is not built; video-sparse attention (block lists per 64-row block) and dense attention run on any G x U grid
+            raise NotImplementedError(f"sta attention needs num_heads divisible by the SP world size (heads {num_heads}, world {self.sp.lay.P}); "
+                                      "vsa and dense attention run on any G x U grid")
         self.num_layers = 1 + max(int(k.split(".")[1]) for k in state_dict if k.startswith("blocks."))
         self._load(state_dict)
         self._vsa_cache = {}
@@ -323,6 +323,82 @@ class WanTransformer3DModelHip:
             self.attn_events.append((ev[0], ev[1], S, S, H))
         return o[0]
 
+    # ------------------------------------------------------------------ sparse attention under sequence parallelism
+    def _sp_plan(self, grid, Sl):
+        """The uneven output-exchange plan of the tile-major sparse modes for this (grid, SP layout): integer host work, cached."""
+        key = ("sp_plan", grid, Sl, self.attention)
+        plan = self._vsa_cache.get(key)
+        if plan is None:
+            L = self.sp.lay
+            if self.attention == "vsa":
+                plan = self.sp.block_plan(self._vsa_meta(grid)["token_of_row"], Sl, 64)
+            else:
+                if L.U != 1:
+                    raise NotImplementedError(f"sliding-tile attention under sequence parallelism needs num_heads % world == 0 (heads {self.H}, world "
+                                              f"{L.P}: G{L.G} x U{L.U}); video-sparse and dense attention run on any G x U grid")
+                plan = self.sp.block_plan(torch.arange(Sl * L.P), Sl, 1)  # U == 1: only the equal-split exchange is used
+            plan.send_tokens, plan.asm_idx = plan.send_tokens.to(self.device), plan.asm_idx.to(self.device)
+            self._vsa_cache[key] = plan
+        return plan
+
+    def _sp_sparse(self, rows, b, cos, sin, S, grid, pos0):
+        """Video-sparse / sliding-tile self-attention of one sample under sequence parallelism (P > 1, any G x U grid for VSA).
+        ONE kernel writes exchange #1's send buffer (QK-norm + RoPE + per-peer packing, the VSA compress gate as a fourth slot next to Q:
+        fvk_qkv(g)_norm_rope_pack_bf16) — the reference sends q, k, v and the gate through all_to_all_4D with cat / transpose copies
+        (attention/layer.py:172-245).  On the receive side the rank holds K, V, Q (and the gate) of ALL tokens for its head group, token-major;
+        q and k are scattered into the tile-major layouts by row maps, V goes straight into the tile-major V^T (STA) / tile buffer (VSA),
+        the kernels compute this rank's run of query blocks and write their output in token order, and the output exchange returns rows to
+        their shard owners (equal split for U = 1, the uneven plan of SequenceParallel.block_plan for U > 1).  rows [Sl, 3d(+d)] -> [Sl, H*D]."""
+        d, D, sp = self.d, self.D, self.sp
+        L = sp.lay
+        Sl = rows.shape[0]
+        gate = rows[:, 3 * d:4 * d] if (self.attention == "vsa" and rows.shape[1] >= 4 * d) else None
+        send = ops.qkv_norm_rope_pack(rows[:, :d], rows[:, d:2 * d], rows[:, 2 * d:3 * d], b["nq_w"], b["nk_w"], cos, sin, L.G, L.U, head_dim=D,
+                                      seq_len=S, eps=self.eps, pos_offset=pos0, gate=gate)
+        plan = self._sp_plan(grid, Sl)
+
+        def vsa_fn(r4, plan):
+            n, NS, hg, _ = r4.shape
+            m = self._vsa_meta(grid)
+            tq, tk, tv = self._tile_bufs(m["S_pad"], hg, 3, grid, "vsa")[:3]
+            for slot, buf in ((2, tq), (0, tk), (1, tv)):
+                ops.gather_rows(r4[:S, slot].unsqueeze(0), m["S_pad"], m["tile_partition_indices"], m["non_pad_index"], out=buf)
+            vbs = m["variable_block_sizes"]
+            b0, b1 = plan.r0 // 64, plan.r1 // 64
+            g4 = r4[:, 3].unsqueeze(0) if NS == 4 else None
+            want = self.vsa_trace is not None
+            res = kernel_api._vsa_forward(tq[:, plan.r0:plan.r1], tk, tv, vbs, vbs[b0:b1], m["topk"], g4, "bshd", want, 64,
+                                          token_of_row=m["token_of_row"][plan.r0:plan.r1], n_tokens=n)
+            if want:
+                res, inter = res
+                self.vsa_trace.append(inter["mask"])
+            return res[0]
+
+        def sta_fn(r4, plan):
+            n, NS, hg, _ = r4.shape
+            m = self._sta_meta(grid, hg)
+            qg = self._tile_bufs(m["group_rows"], hg, 1, grid, "sta_q")[0]
+            kt = self._tile_bufs(m["S_pad"], hg, 1, grid, "sta_k")[0]
+            ops.gather_rows(r4[:S, 2].unsqueeze(0), m["group_rows"], m["group_src"], m["group_dst"], out=qg)
+            ops.gather_rows(r4[:S, 0].unsqueeze(0), m["S_pad"], m["perm"], m["non_pad"], out=kt)
+            vt = ops.v_transpose(r4[:S, 1].unsqueeze(0), src_rows=m["v_src_rows"])
+            o = ops.attn_tile_lists(qg, kt, None, m["group_q2k_idx"], m["group_q2k_num"], m["block_sizes"], 256, None, scale=D**-0.5,
+                                    layout="bshd", vt=vt, o_rows=m["group_token_of_row"], n_out_rows=n)
+            return o[0]
+
+        fn = vsa_fn if self.attention == "vsa" else sta_fn
+        if self.attn_events is not None:
+            inner = fn
+
+            def fn(r4, plan):  # bench.py roofline leg: HIP events around the whole local attention
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                o = inner(r4, plan)
+                e1.record()
+                self.attn_events.append((e0, e1, (plan.r1 - plan.r0) if self.attention == "vsa" else S, S, r4.shape[2]))
+                return o
+        return sp.attention_blocks(send, plan, fn, head_dim=D).reshape(Sl, self.H * D)
+
     def _lin(self, x, b, key, bias, **kw):
         """y = epilogue(x @ W^T + bias) through the bf16 GEMM or the fp8 path (dynamic activation quantisation + fp8 MFMA GEMM)."""
         if not self.quant:
@@ -418,7 +494,9 @@ class WanTransformer3DModelHip:
                 rows = qkv[bi * Sl:(bi + 1) * Sl]
                 gate = rows[:, 3 * d:4 * d].view(Sl, H, D) if nq == 4 else None
                 fn = lambda q_, k_, v_, kv_len, g_=None: self._attn_local(q_, k_, v_, kv_len, grid, g_)
-                if P > 1 and gate is None and not sp.overlap:
+                if P > 1 and self.attention in ("vsa", "sta"):
+                    o = self._sp_sparse(rows, b, cos, sin, S, grid, pos0)
+                elif P > 1 and gate is None and not sp.overlap:
                     # sequence parallel: QK-norm + RoPE + the per-peer packing of exchange #1 in ONE kernel (no torch.cat, no unpack —
                     # attention reads K, V and its query rows out of the received buffer through strides)
                     send = ops.qkv_norm_rope_pack(rows[:, :d], rows[:, d:2 * d], rows[:, 2 * d:3 * d], b["nq_w"], b["nk_w"], cos, sin,

@@ -75,7 +75,20 @@ class WanVaeDecoderHip:
                  tile_sample_min_num_frames: int = 16, tile_sample_stride_height: int = 192, tile_sample_stride_width: int = 192,
                  tile_sample_stride_num_frames: int = 12, blend_num_frames: int | None = None, use_tiling: bool = False,
                  use_temporal_tiling: bool = False, use_parallel_tiling: bool = False, sp_group=None, fuse_norm: bool = True,
-                 frames_per_pass: int = 4):
+                 frames_per_pass: int = 4, precision: str = "bf16"):
+        """``precision``: the reference's ``pipeline_config.vae_precision`` / ``vae_decode_precision`` (configs/pipelines/base.py;
+        decoding.py:164-180 wraps ``vae.decode`` in ``torch.autocast(dtype=...)`` unless it is "fp32").  This decoder serves the
+        **"bf16"** mode only: bf16 activations in HBM, bf16 MFMA operands, fp32 accumulation and fp32 norm / SiLU arithmetic — the
+        same rounding points as the reference's bf16 autocast (conv outputs and residual sums bf16, norms fp32).  Its error against
+        the reference's fp32 decode is bounded, quantile by quantile, by the error of the reference's OWN bf16-autocast decode at
+        real frame sizes (tests/test_gpu_vae_real.py).  "fp32" — the Wan pipeline's default (configs/pipelines/wan.py:54), whose
+        own test tolerance is atol 1e-5 (tests/vaes/test_wan_vae.py:87) — is REFUSED rather than silently served at lower
+        precision: a pipeline that needs fp32 pixels keeps the reference decoder; "fp16" is refused too (no fp16 kernels)."""
+        if precision != "bf16":
+            raise ValueError(f"WanVaeDecoderHip serves vae_precision='bf16' only (got {precision!r}): the gfx950 decode keeps bf16 "
+                             "activations with fp32 accumulation; set pipeline_config.vae_precision / vae_decode_precision to 'bf16' or keep "
+                             "the reference decoder for fp32 pixels")
+        self.precision = precision
         self.device = torch.device(device)
         # VAEConfig / WanVAEConfig fields (configs/models/vaes/base.py:29-46, wanvae.py:72-82)
         self.use_feature_cache = use_feature_cache

@@ -98,6 +98,13 @@ int fvk_rmsnorm_rope_scatter_bf16(const void* const* in, void* const* out, const
 int fvk_qkv_norm_rope_pack_bf16(const void* q, const void* k, const void* v, const void* wq, const void* wk, const float* cos,
                                 const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset,
                                 long in_stride, int G, int U, float eps, void* stream);
+/* The same pass with a FOURTH per-token, per-head tensor copied along (the VSA compress gate `to_gate_compress(x)`, which the reference
+ * sends through the same all-to-all as q, k, v: fastvideo/attention/layer.py:172-245): message row = [K | V | Q | gate], send is
+ * [G*U ranks, Sl, 4, W].  The gate travels with Q — to every rank of its head group's column — so video-sparse attention runs on any
+ * G x U grid (12 heads on 8 GPUs: G4 x U2), where the reference needs num_heads % sp_size == 0. */
+int fvk_qkvg_norm_rope_pack_bf16(const void* q, const void* k, const void* v, const void* gate, const void* wq, const void* wk,
+                                 const float* cos, const float* sin, void* send, int Sl, int width, int head_dim, int seq_len,
+                                 int pos_offset, long in_stride, int G, int U, float eps, void* stream);
 
 /* V[b, s, h, :] at v + b*in_batch_stride + s*in_stride + h*in_head_stride (elements) -> Vt [B, H, D, S_pad] bf16,
  * S_pad = a multiple of 64 >= S (the host wrapper uses round_up(S, 128): whole tiles of the 128-key-tile kernel), pad columns zero.  Within every aligned group of 16 keys the key order is

@@ -92,9 +92,12 @@ def _sparse_forward(fx_path, mode):
     return model(lat.cuda(), c["ctx"].cuda(), c["timestep"].cuda()).cpu()
 
 
-@pytest.mark.parametrize("mode", ["vsa", "sta"])
-def test_sp2_sparse_attention_equals_sp1(mode, golden_dir):
-    """VSA (with its compress gate travelling through the exchange) and sliding-tile attention under plain Ulysses SP=2 == SP=1."""
+@pytest.mark.parametrize("mode,world", [("vsa", 2), ("sta", 2), ("vsa", 4)])
+def test_sp_sparse_attention_equals_sp1(mode, world, golden_dir):
+    """VSA (its compress gate travelling through exchange #1 as a fourth slot of the packed message row) and sliding-tile attention
+    under sequence parallelism == SP=1, bit for bit.  world 2: plain Ulysses (2 heads -> G2 x U1).  world 4 with 2 heads: G2 x U2 — the
+    2-D grid of FastWan-1.3B on 8 GPUs (12 heads -> G4 x U2) that round 2 refused: every rank computes its run of tile-major query
+    blocks for its head group and the uneven output exchange returns rows to the shard owners (fastvideo_amd/distributed.py: block_plan)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     fx_path = os.path.join(golden_dir, "wan_tiny.pt")
@@ -102,7 +105,7 @@ def test_sp2_sparse_attention_equals_sp1(mode, golden_dir):
     ctx = mp.get_context("spawn")
     out_q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_sparse, args=(r, 2, port, fx_path, mode, out_q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_sparse, args=(r, world, port, fx_path, mode, out_q)) for r in range(world)]
     for p in procs:
         p.start()
     out = out_q.get(timeout=300)
@@ -110,4 +113,17 @@ def test_sp2_sparse_attention_equals_sp1(mode, golden_dir):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert torch.isfinite(out.float()).all()
-    assert torch.equal(out, ref), f"{mode} SP=2: max diff {(out.float() - ref.float()).abs().max().item()}"
+    assert torch.equal(out, ref), f"{mode} SP={world}: max diff {(out.float() - ref.float()).abs().max().item()}"
+
+
+def test_sta_refuses_u_gt_1(golden_dir):
+    """Sliding-tile attention on a G x U grid with U > 1 is not built: refused at construction with the reason (VSA and dense run there)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fastvideo_amd.distributed import SPLayout
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    fx = torch.load(os.path.join(golden_dir, "wan_tiny.pt"), weights_only=False)
+    m = WanTransformer3DModelHip(fx["state_dict"], num_heads=fx["config"]["num_heads"], attention="sta")
+    m.sp.lay = SPLayout(P=4, rank=1, H=2, G=2, U=2)
+    with pytest.raises(NotImplementedError, match="sliding-tile"):
+        m._sp_plan((7, 9, 17), 300)
