@@ -27,6 +27,8 @@ struct StepArgs {
     float cc_x, cc_m0, cc_B, c_rho0, c_rho_last, c_rk;  // corrector
     float pc_x, pc_m0, pc_B, p_rho0, p_rk;              // predictor
     int corr_order, pred_order;                          // 0 = no corrector; predictor order 1 or 2
+    int recip;                                           // 1: x / rk is evaluated as x * (1.0f / rk) — torch's eager GPU kernels do that when the
+    float c_irk, p_irk;                                  //    divisor is a 0-d CPU tensor (BinaryDivTrueKernel.cu: "may lose one bit"); 0: true division
 };
 
 __global__ __launch_bounds__(256) void cfg_unipc_step_kernel(StepArgs a) {
@@ -51,14 +53,18 @@ __global__ __launch_bounds__(256) void cfg_unipc_step_kernel(StepArgs a) {
         if (a.corr_order > 0) {  // UniC: x <- c_x*last - c_m0*m0 - c_B*(rho0*(m1-m0)/rk + rho_last*(x0-m0))
             const float xt_ = sub_(mul_(a.cc_x, a.last_sample[i]), mul_(a.cc_m0, m0));
             const float d1t = mul_(a.c_rho_last, sub_(x0, m0));
-            const float corr = a.corr_order > 1 ? add_(mul_(a.c_rho0, div_(sub_(m1, m0), a.c_rk)), d1t) : d1t;
+            const float dm = sub_(m1, m0);
+            const float corr = a.corr_order > 1 ? add_(mul_(a.c_rho0, a.recip ? mul_(dm, a.c_irk) : div_(dm, a.c_rk)), d1t) : d1t;
             x = sub_(xt_, mul_(a.cc_B, corr));
         }
         a.x0_out[i] = x0;
         a.sample_c_out[i] = x;
         // UniP with the shifted history (m0 <- x0, m1 <- old m0)
         float xn = sub_(mul_(a.pc_x, x), mul_(a.pc_m0, x0));
-        if (a.pred_order > 1) xn = sub_(xn, mul_(a.pc_B, mul_(a.p_rho0, div_(sub_(m0, x0), a.p_rk))));
+        if (a.pred_order > 1) {
+            const float dp = sub_(m0, x0);
+            xn = sub_(xn, mul_(a.pc_B, mul_(a.p_rho0, a.recip ? mul_(dp, a.p_irk) : div_(dp, a.p_rk))));
+        }
         a.next_out[i] = xn;
         if (a.next_bf16) a.next_bf16[i] = (bf16_t)xn;  // latent_model_input = latents.to(bf16) of the next step (denoising.py:404)
     }
@@ -115,6 +121,8 @@ extern "C" int fvk_cfg_unipc_step(const void* noise_text, const void* noise_unco
                                   const float* m0, const float* m1, float* x0_out, float* sample_c_out, float* next_out,
                                   void* next_bf16_out, long n, const float* coef_host, int corr_order, int pred_order, void* stream) {
     FVK_CHECK(noise_text && sample && x0_out && sample_c_out && next_out && coef_host && n > 0, FVK_ERR_ARG, "fvk_cfg_unipc_step: null pointer / empty");
+    const int recip = (pred_order >> 8) & 1;  // bit 8 of pred_order: accelerator-eager division (multiply by the fp32 reciprocal of the 0-d divisor)
+    pred_order &= 0xff;
     FVK_CHECK(corr_order >= 0 && corr_order <= 2 && pred_order >= 1 && pred_order <= 2, FVK_ERR_ARG,
               "fvk_cfg_unipc_step: corrector order %d / predictor order %d unsupported (solver_order <= 2)", corr_order, pred_order);
     FVK_CHECK(corr_order == 0 || (last_sample && m0), FVK_ERR_ARG, "fvk_cfg_unipc_step: corrector needs last_sample and m0");
@@ -128,6 +136,9 @@ extern "C" int fvk_cfg_unipc_step(const void* noise_text, const void* noise_unco
     a.g = c[0]; a.sigma_t = c[1]; a.cc_x = c[2]; a.cc_m0 = c[3]; a.cc_B = c[4]; a.c_rho0 = c[5]; a.c_rho_last = c[6]; a.c_rk = c[7];
     a.pc_x = c[8]; a.pc_m0 = c[9]; a.pc_B = c[10]; a.p_rho0 = c[11]; a.p_rk = c[12];
     a.corr_order = corr_order; a.pred_order = pred_order;
+    a.recip = recip;
+    a.c_irk = a.c_rk != 0.f ? 1.0f / a.c_rk : 0.f;
+    a.p_irk = a.p_rk != 0.f ? 1.0f / a.p_rk : 0.f;
     const unsigned blocks = (unsigned)((n + 1023) / 1024);
     hipLaunchKernelGGL(cfg_unipc_step_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     FVK_LAUNCH_CHECK();

@@ -25,8 +25,10 @@ class FlowUniPCStepper:
         # scalar_rounding: how a 0-d fp32 / Python scalar meets a bf16 tensor in `sigma_t * model_output` and `g * (text - uncond)`.
         #   "bf16": the scalar is first cast to the tensors' dtype — what the reference's eager path does when the operands live on the
         #           CPU (TensorIterator common-dtype cast); this is the behaviour the oracle and the golden vectors pin.
-        #   "fp32": the scalar stays fp32 inside the kernel, as the eager CUDA/HIP elementwise kernels do with a CPU scalar operand.
-        # The two differ by at most one bf16 ulp of the product.
+        #   "fp32": the scalar stays fp32 inside the kernel, as the eager CUDA/HIP elementwise kernels do with a CPU scalar operand; the
+        #           divisions by the 0-d `rk` become multiplications by its fp32 reciprocal, as torch's GPU division kernel does for a CPU
+        #           scalar divisor (pinned bit-exactly against torch eager on the device: tests/test_gpu_sched.py).
+        # The two differ by at most one bf16 ulp of the product (and one fp32 ulp of the quotient).
         if scalar_rounding not in ("bf16", "fp32"):
             raise ValueError("scalar_rounding must be 'bf16' or 'fp32'")
         self.scalar_rounding = scalar_rounding
@@ -102,7 +104,7 @@ class FlowUniPCStepper:
         m0, m1 = self._m[1], self._m[0]
         _lib.call("fvk_cfg_unipc_step", p(noise_pred_text.contiguous()), p(None if noise_pred_uncond is None else noise_pred_uncond.contiguous()),
                   p(latents), p(self._last), p(m0), p(m1), p(x0), p(sample_c), p(nxt), p(nxt16), n, coef, int(corr_order),
-                  int(self.this_order), ops._stream())
+                  int(self.this_order) | (0x100 if self.scalar_rounding == "fp32" else 0), ops._stream())
         self._m = [m0, x0]
         self._last = sample_c
         if self.lower_order_nums < self.order:

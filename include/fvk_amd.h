@@ -294,7 +294,8 @@ int fvk_vae_rmsnorm_silu_bf16(const void* x, const float* gamma, void* out, long
  *   next = pc_x*xc - pc_m0*x0 [- pc_B*(p_rho0*(m0-x0)/p_rk)]  (pred_order 2)               -> next_out (fp32), next_bf16_out (optional)
  * fp32 arithmetic in exactly this order without contraction (bit-identical to the eager reference).  n elements; m0 / m1 = x0_out of
  * the previous / second-previous step.  coef_host: HOST float[13] = g, sigma_t, cc_x, cc_m0, cc_B, c_rho0, c_rho_last, c_rk, pc_x,
- * pc_m0, pc_B, p_rho0, p_rk. */
+ * pc_m0, pc_B, p_rho0, p_rk.  pred_order bit 8 (| 0x100): the two divisions by rk are evaluated as x * (1.0f / rk) — what torch's eager
+ * GPU kernels do with a 0-d CPU divisor ("may lose one bit") — instead of a true division (torch's eager CPU kernels). */
 int fvk_cfg_unipc_step(const void* noise_text, const void* noise_uncond, const float* sample, const float* last_sample, const float* m0,
                        const float* m1, float* x0_out, float* sample_c_out, float* next_out, void* next_bf16_out, long n,
                        const float* coef_host, int corr_order, int pred_order, void* stream);
