@@ -21,6 +21,7 @@
 #include "gemm_common.h"
 
 int fvk_attn_pp_launch(const fvk_attn_args* a, int variant, hipStream_t s);  // attn_pp.hip
+int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s); // attn_w64.hip
 int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s);   // attn_pp2.hip
 struct fvk_pp2_lists {  // attn_pp2.hip: 256-row workgroups over shared KV block lists
     const int32_t* q2k_idx; const int32_t* q2k_num; const int32_t* kv_block_sizes; const int32_t* q_rows_valid;
@@ -518,6 +519,9 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
     const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
     // full-length query blocks: 0 = the 128-key-tile ping-pong kernel (attn_pp2.hip, shipped); 1 = this file's 4-wave kernel;
     // >= 2 = the 64-key-tile ping-pong kernel (attn_pp.hip) variant impl-1 (measurement only)
+#if FVK_VARIANTS
+    if (impl >= 200 && impl < 300 && a->Sq >= 256) return fvk_attn_w64_launch(a, impl - 200, (hipStream_t)stream);  // 4 waves x 64 rows
+#endif
     if ((impl == 0 || impl >= 100) && a->Sq >= 256) return fvk_attn_pp2_launch(a, impl >= 100 ? impl - 99 : 0, (hipStream_t)stream);
 #if FVK_VARIANTS
     if (impl >= 2 && impl < 100 && a->Sq >= 256) return fvk_attn_pp_launch(a, impl - 1, (hipStream_t)stream);

@@ -1,0 +1,476 @@
+// Dense flash-style attention forward, head_dim 128, gfx950 — 4 waves x 64 query rows, ONE wave per SIMD, software-pipelined inside the wave.
+//
+// Why (profiles/r03_attn_ablate.md): the 8-wave ping-pong kernel (attn_pp2.hip) is power-bound, and a timing ablation in which every
+// K / V^T fragment read from LDS feeds TWO MFMAs instead of one runs +25 % (1406 -> 1760 TF with the DMA off) — the LDS operand stream
+// (one ds_read_b128 per MFMA, the same 64 KiB tile re-read by all 8 waves) is the largest single consumer after the matrix pipe.  A wave
+// that owns 64 query rows (two 32-row blocks) reads each fragment once for two MFMAs: half the LDS reads and ds_read issue slots per
+// FLOP.  64 rows need the whole 512-entry register file (Q 64 + O 128 + S 2 x 64 + P 2 x 32 + fragments), i.e. one wave per SIMD — so
+// the softmax can no longer hide behind a partner wave's matrix segment and is software-pipelined INSIDE the wave instead:
+//
+//   sub-tile = 64 keys.  iteration t:   phase 1  MFMA: Q·K^T of sub-tile t (32) + the iteration's 8 DMA pieces          (matrix pipe only)
+//                                       phase 2  MFMA: P·V of sub-tile t-1 (32)   ||   VALU: softmax of sub-tile t (exp2 against the running
+//                                                max of the iteration's START, row sums, bf16 pack) — independent, interleaved by
+//                                                sched_group_barrier (1 MFMA : SCHED VALU)
+//   (S double-buffered, so that Q·K^T of t+1 could overlap the softmax too, does not fit: S must live in arch VGPRs for the VALU, and
+//   Q 64 + S 128 + P 64 + fragments exceed the 256 of them; the compiler keeps only MFMA accumulators in AGPRs.)
+//
+// Fixed softmax reference: p = exp2((s - m_ref) * c) with m_ref = the exact row max of the FIRST sub-tile, never updated — the hot loop has
+// no running max, no rescale of O and no branch (a rescale would have to touch the O accumulators with the VALU, which drags them out of
+// the accumulator file).  Mathematically the same softmax (the reference cancels in O / l); P is no longer bounded by 1 but by
+// 2^(row max - m_ref), which bf16 (P) and fp32 (l, O) absorb as long as that growth stays below ~2^90: checked ONCE, after the last key —
+// a row whose l is not a finite number below 2^90 sends its whole workgroup through an exact, un-pipelined online-softmax pass (rescaling
+// O as usual) that overwrites the result.  With RMS-normed q / k (the DiT) or randn inputs the growth is a few units; the recompute is
+// there for arbitrary callers and is exercised by the spiked-key tests.  Results agree with attn_pp2 to rounding, not bit for bit.
+//
+// Staging is attn_pp2's: 128-key stages (K 32 KiB + V^T 32 KiB) by LDS-DMA into a 2-deep XOR-swizzled ring; ONE barrier per iteration
+// (64 keys, 64 MFMAs per wave).  Behind the barrier before iteration 2j every wave has finished reading K(j-1), so K(j+1) is issued there
+// (8 pieces per wave in the gaps of phase 1); behind the one before iteration 2j+1 V^T(j-1) is free and V^T(j+1) is issued.  A set is needed
+// two barriers later, and each barrier is preceded by s_waitcnt vmcnt(8): everything but the youngest set has landed.
+// Same operand orientation as the other kernels (S^T = K·Q^T: a softmax row is lane-local; O^T = V^T·P^T with P^T taken from the packed
+// S^T registers), same V^T input layout (fvk_v_transpose_bf16).
+#include "fvk_common.h"
+
+namespace {
+
+constexpr int KT = 128;               // keys per staged tile (two 64-key sub-tiles)
+constexpr int K_TILE = KT * 256;      // 128 keys x 128 d bf16
+constexpr int V_TILE = 128 * KT * 2;  // 128 d x 128 keys bf16
+constexpr int RING = 2;
+constexpr int V_BASE = RING * K_TILE;
+constexpr int LDS_BYTES = RING * (K_TILE + V_TILE);  // 131 072
+constexpr float L_LIMIT = 1.2379400392853803e27f;  // 2^90: a row sum at or above it (or NaN) triggers the exact recompute
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ float xhalf_max64(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum64(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+struct W64 {
+    // registers of one wave (everything is indexed with compile-time constants after unrolling)
+    bf16x8 qf[2][8];     // Q fragments [q block][d step]
+    f32x16 o[2][4];      // O^T accumulators [q block][d block]
+    f32x16 s[2][2];      // S^T of the current sub-tile [q block][32-key block]
+    bf16x8 pf[2][2][4];  // P^T, packed [sub-tile parity][q block][16-key step]
+    float m_run[2], l_run[2];
+    int foff[8];
+    float c2;
+    // LDS-DMA addressing (attn_pp2's): wave w moves pieces {w, w+4, ..., w+28} of K (4 key rows x 256 B) and of V^T (4 d rows x 256 B)
+    __amdgpu_buffer_rsrc_t k_rsrc, v_rsrc;
+    unsigned kv0, vv0, k_pstride, v_pstride, k_tile_bytes;
+    int pdst, n;
+    unsigned char* smem;
+
+    // piece I (0..7) of the set issued in iteration T: even T = 2j -> K(j+1) into K(j-1)'s slot, odd T = 2j+1 -> V^T(j+1) into V^T(j-1)'s
+    // slot; stages past the end re-read stage 0 (harmless)
+    template <int ODD, int I>
+    __device__ __forceinline__ void issue_piece(int j) const {
+        const int t_ = j + 1 < n ? j + 1 : 0;
+        // the per-piece and per-stage parts of the source address are wave-uniform: they ride in the SGPR offset, the lane part (kv0 / vv0)
+        // is ONE arch VGPR per tensor for all pieces
+        if constexpr (!ODD) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + ((j + 1) & 1) * K_TILE + pdst + I * 4096), 16, kv0,
+                                                     __builtin_amdgcn_readfirstlane(I * k_pstride + (unsigned)t_ * k_tile_bytes), 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + ((j + 1) & 1) * V_TILE + pdst + I * 4096), 16, vv0,
+                                                     __builtin_amdgcn_readfirstlane(I * v_pstride + t_ * (KT * 2)), 0, 0);
+        }
+    }
+    // V^T fragment of stage st: k-step kk (16 keys), d-block db;  K fragment of stage st: d-step ks, key block kb (32 keys)
+    __device__ __forceinline__ bf16x8 frag_v(int st, int kk, int db) const {
+        return *reinterpret_cast<const bf16x8*>(smem + V_BASE + (st & 1) * V_TILE + foff[kk] + db * 8192);
+    }
+    __device__ __forceinline__ bf16x8 frag_k(int st, int ks, int kb) const {
+        return *reinterpret_cast<const bf16x8*>(smem + (st & 1) * K_TILE + foff[ks] + kb * 8192);
+    }
+    // Every MFMA is inline asm with pinned register files: O accumulators "+a" (accumulator file), S accumulators "+v" (arch VGPRs — the
+    // VALU reads them), Q fragments "a", K / V^T / P fragments "v".  For a kernel that may use more than 256 registers hipcc selects the
+    // AGPR-accumulator form for EVERY MFMA builtin (S would pay one v_accvgpr_read per score) and, with builtin and asm forms mixed, shuffles
+    // the accumulators between the two files inside the loop; with asm only, each value's file is fixed by its constraints.
+    // hipcc pads no hazards for asm statements: results are fenced by hand (fence_s / fence_o below) before compiler-generated readers.
+#define FVK_MFMA1(ACC, FR, P) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(FR), "v"(P))
+#define FVK_MFMA_PV(ACC0, ACC1, FR, P0, P1)                                                                             \
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1" : "+a"(ACC0), "+a"(ACC1) : "v"(FR), "v"(P0), "v"(P1))
+    // MFMA result -> compiler-generated reader (VALU / v_accvgpr_read) and VALU / v_accvgpr_write -> MFMA operand: 16-pass XDL op = 18 wait states
+    __device__ __forceinline__ void fence_s() { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1])); }
+    __device__ __forceinline__ void fence_o() {
+        asm volatile("s_nop 15\n\ts_nop 3" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));
+    }
+    // P·V of the sub-tile (stage st, half hf) from pf[PAR]: plain form for the tail
+    template <int PAR>
+    __device__ __forceinline__ void pv_plain(int st, int hf) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int db = 0; db < 4; ++db) {
+                const bf16x8 fr = frag_v(st, 4 * hf + kk, db);
+                FVK_MFMA_PV(o[0][db], o[1][db], fr, pf[PAR][0][kk], pf[PAR][1][kk]);
+            }
+    }
+    // keys of the sub-tile at or beyond `valid` (0..64) get -inf (last stage only)
+    __device__ __forceinline__ void mask_keys(int valid, int hi) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (key >= valid) s[qb][kb][r] = -INFINITY;
+                }
+    }
+    // row max of the sub-tile (this lane holds 32 of its row's 64 scores, lane^32 the other 32)
+    template <int QB>
+    __device__ __forceinline__ float row_max() const {
+        float mx = fmaxf(s[QB][0][0], s[QB][1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[QB][0][r]), s[QB][1][r]);
+        return xhalf_max64(mx);
+    }
+    // p = exp2(s*c2 - mc) for values [8*kk .. 8*kk+8) of q block QB (one packed P fragment): the partial row sums go to ps4, P packed to bf16
+    template <int PAR, int QB, int KK>
+    __device__ __forceinline__ void exp_pack8(float mc, float (&ps4)[4]) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[QB][KK >> 1][(KK & 1) * 8 + jj], c2, -mc));
+            ps4[jj & 3] += p;
+            pf[PAR][QB][KK][jj] = (bf16_t)p;
+        }
+    }
+    template <int PAR, int QB>
+    __device__ __forceinline__ float exp_pack(float mc) {
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+        exp_pack8<PAR, QB, 0>(mc, ps4);
+        exp_pack8<PAR, QB, 1>(mc, ps4);
+        exp_pack8<PAR, QB, 2>(mc, ps4);
+        exp_pack8<PAR, QB, 3>(mc, ps4);
+        return (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+    }
+    // exact online-softmax step (new running max first; O and l rescaled): first sub-tile and the slow path
+    template <int PAR, bool RESCALE>
+    __device__ __forceinline__ void softmax_exact() {
+        float mx[2] = {row_max<0>(), row_max<1>()};
+        if (RESCALE) fence_o();  // the P·V MFMAs just issued have written O before the compiler's v_accvgpr_read
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            const float m_new = fmaxf(m_run[qb], mx[qb]);
+            const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c2);
+            if (RESCALE) {
+#pragma unroll
+                for (int d = 0; d < 4; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[qb][d][r] *= alpha;
+            }
+            m_run[qb] = m_new;
+            const float ps = qb == 0 ? exp_pack<PAR, 0>(m_new * c2) : exp_pack<PAR, 1>(m_new * c2);
+            l_run[qb] = l_run[qb] * alpha + ps;
+        }
+        if (RESCALE) fence_o();  // v_accvgpr_write -> MFMA source C
+    }
+
+    // Q·K^T of the sub-tile (ring slot st, half hf) -> s: plain form (exact pass)
+    __device__ __forceinline__ void qk_plain(int st, int hf) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const bf16x8 fr = frag_k(st, i >> 1, 2 * hf + (i & 1));
+            if (i < 2)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, 0"
+                             : "=&v"(s[0][i & 1]), "=&v"(s[1][i & 1]) : "v"(fr), "a"(qf[0][i >> 1]), "a"(qf[1][i >> 1]));
+            else
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1"
+                             : "+v"(s[0][i & 1]), "+v"(s[1][i & 1]) : "v"(fr), "a"(qf[0][i >> 1]), "a"(qf[1][i >> 1]));
+        }
+        fence_s();
+    }
+    // The exact pass (rare: only when a row's fixed-reference sum left the safe range): plain online softmax over all keys with a running
+    // max and O rescaled by the VALU, one stage at a time through ring slot 0 (load, wait, barrier, compute — no overlap).  Every wave of
+    // the workgroup takes part.  Leaves o, m_run, l_run as the pipelined pass would have.
+    __device__ __forceinline__ void exact_pass(int v_last, int hi) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            m_run[qb] = -1e30f;
+            l_run[qb] = 0.f;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[qb][d][r] = 0.f;
+        }
+        fence_o();
+        for (int st = 0; st < n; ++st) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();  // every wave has finished reading slot 0
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + pdst + i * 4096), 16, kv0,
+                                                         __builtin_amdgcn_readfirstlane(i * k_pstride + (unsigned)st * k_tile_bytes), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + pdst + i * 4096), 16, vv0,
+                                                         __builtin_amdgcn_readfirstlane(i * v_pstride + st * (KT * 2)), 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int valid = st == n - 1 ? v_last : KT;
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {  // (fully unrolled: a runtime index into foff[] would pin the whole register struct to scratch)
+                if (valid > 64 * hf) {
+                    qk_plain(0, hf);
+                    if (valid - 64 * hf < 64) mask_keys(valid - 64 * hf, hi);
+                    softmax_exact<0, true>();
+                    pv_plain<0>(0, hf);
+                }
+            }
+        }
+        fence_o();
+    }
+
+    // ---- iteration t = 2j + ODD: phase 1 Q·K^T(t) (stage j, key blocks 2*ODD, +1) with this wave's 8 DMA pieces of the iteration's set;
+    // phase 2 P·V(t-1) (stage (t-1)>>1, k-steps 4*(1-ODD)..+3, pf[1-ODD]) interleaved with the softmax of sub-tile t -> pf[ODD].
+    // FIRST: t = 0 (no P·V, exact softmax).  MASK: keys >= valid are masked (last stage).  SCHED: VALU per MFMA gap pinned in phase 2.
+    template <int ODD, bool FIRST, bool MASK, int SCHED>
+    __device__ __forceinline__ void iter(int j, int valid, int hi) {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        constexpr int FD = 4;  // fragments in flight
+        {   // ---- phase 1: fragment i = (d-step i>>1, key block i&1), each feeding the two q blocks.  volatile asm statements keep their
+            // order against the LDS reads and the DMA pieces, so the source order below IS the software pipeline (fragments read FD ahead,
+            // one DMA piece per 4 MFMAs).
+            bf16x8 fr[FD];
+#pragma unroll
+            for (int i = 0; i < FD; ++i) fr[i] = frag_k(j, i >> 1, 2 * ODD + (i & 1));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                if (i < 2)
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, 0"
+                                 : "=&v"(s[0][i & 1]), "=&v"(s[1][i & 1])
+                                 : "v"(fr[i % FD]), "a"(qf[0][i >> 1]), "a"(qf[1][i >> 1]));
+                else
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1"
+                                 : "+v"(s[0][i & 1]), "+v"(s[1][i & 1])
+                                 : "v"(fr[i % FD]), "a"(qf[0][i >> 1]), "a"(qf[1][i >> 1]));
+                if (i + FD < 16) fr[i % FD] = frag_k(j, (i + FD) >> 1, 2 * ODD + ((i + FD) & 1));
+                if ((i & 1) == 0) {  // one DMA piece per 4 MFMAs
+                    switch (i >> 1) {
+                        case 0: issue_piece<ODD, 0>(j); break;
+                        case 1: issue_piece<ODD, 1>(j); break;
+                        case 2: issue_piece<ODD, 2>(j); break;
+                        case 3: issue_piece<ODD, 3>(j); break;
+                        case 4: issue_piece<ODD, 4>(j); break;
+                        case 5: issue_piece<ODD, 5>(j); break;
+                        case 6: issue_piece<ODD, 6>(j); break;
+                        default: issue_piece<ODD, 7>(j); break;
+                    }
+                }
+            }
+            fence_s();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MASK) mask_keys(valid, hi);
+        if (FIRST) {  // the reference: exact row max of the first sub-tile (it has at least one valid key)
+            m_run[0] = row_max<0>();
+            m_run[1] = row_max<1>();
+            l_run[0] = exp_pack<ODD, 0>(m_run[0] * c2);
+            l_run[1] = exp_pack<ODD, 1>(m_run[1] * c2);
+            return;
+        }
+        // ---- phase 2: 32 chunks of { 1 MFMA | the softmax of 2 scores: 2 fma, 2 exp, 2 add, 1 cvt_pk }, pinned with sched_barrier: ~7 VALU
+        // (~4 cycles each) in the shadow of one 32-cycle MFMA.  V^T fragment i feeds chunks 2i (q block 0) and 2i+1 (q block 1); chunk c
+        // handles scores 2c, 2c+1 of the lane's 64 (q block c>>4, P fragment (c>>2)&3, values 2*(c&3), +1).
+        const float mc0 = m_run[0] * c2, mc1 = m_run[1] * c2;
+        const int stp = ODD ? j : j - 1;  // stage of sub-tile t-1
+        bf16x8 fr[FD];
+#pragma unroll
+        for (int i = 0; i < FD; ++i) fr[i] = frag_v(stp, 4 * (1 - ODD) + (i >> 2), i & 3);
+        float psA[2] = {0.f, 0.f}, psB[2] = {0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            const int i = c >> 1;  // fragment (k-step i>>2, d-block i&3)
+            if ((c & 1) == 0) FVK_MFMA1(o[0][i & 3], fr[i % FD], pf[1 - ODD][0][i >> 2]);
+            else FVK_MFMA1(o[1][i & 3], fr[i % FD], pf[1 - ODD][1][i >> 2]);
+            if ((c & 1) && i + FD < 16) fr[i % FD] = frag_v(stp, 4 * (1 - ODD) + ((i + FD) >> 2), (i + FD) & 3);
+            const int qb = c >> 4, kk = (c >> 2) & 3, j0 = 2 * (c & 3);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int jj = j0 + e, r = (kk & 1) * 8 + jj;
+                const float sv = qb == 0 ? s[0][kk >> 1][r] : s[1][kk >> 1][r];
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c2, qb == 0 ? -mc0 : -mc1));
+                if (qb == 0) psA[e] += p; else psB[e] += p;
+                pf[ODD][qb][kk][jj] = (bf16_t)p;
+            }
+            // keep the chunk's work IN the chunk (a use here, before the scheduling barrier)
+            if ((c & 3) == 3) asm volatile("" : "+v"(pf[ODD][qb][kk]));
+            if (qb == 0) asm volatile("" : "+v"(psA[0]), "+v"(psA[1])); else asm volatile("" : "+v"(psB[0]), "+v"(psB[1]));
+            if (SCHED > 0) __builtin_amdgcn_sched_barrier(0);
+        }
+        l_run[0] += psA[0] + psA[1];
+        l_run[1] += psB[0] + psB[1];
+    }
+#undef FVK_MFMA_PV
+#undef FVK_MFMA1
+};
+
+template <int SCHED>
+__global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BMQ = 256;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nqb = (a.Sq + BMQ - 1) / BMQ;
+    const int q_first = (blockIdx.x % nqb) * BMQ;
+    const int h = (blockIdx.x / nqb) % a.H;
+    const int b = blockIdx.x / (nqb * a.H);
+    const int n = (a.Skv + KT - 1) / KT;          // stages
+    const int v_last = a.Skv - (n - 1) * KT;      // valid keys of the last stage, 1..128
+
+    const bf16_t* qp = (const bf16_t*)a.q + (long)b * a.q_bs + (long)h * a.q_hs;
+    const bf16_t* kp = (const bf16_t*)a.k + (long)b * a.k_bs + (long)h * a.k_hs;
+    const bf16_t* vtp = (const bf16_t*)a.vt + ((long)b * a.H + h) * 128L * a.Skv_pad;
+    bf16_t* op = (bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs;
+
+    W64 w;
+    w.smem = smem;
+    w.n = n;
+    w.c2 = a.scale * 1.4426950408889634f;
+    // Q fragments of the wave's two 32-row blocks (B operand of S^T = K·Q^T): row q0 + 32*blk + l31, d = 16*ks + 8*hi .. +8
+    const int q0 = q_first + wave * 64;
+    int qrow[2];
+    bool q_ok[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const int r = q0 + 32 * qb + l31;
+        q_ok[qb] = r < a.Sq;
+        qrow[qb] = q_ok[qb] ? r : a.Sq - 1;
+        // loaded STRAIGHT into the accumulator file (gfx950 loads can target AGPRs): a value that is defined in an "a" register and only
+        // ever used as an "a" operand stays there; loaded with a plain C++ load it lives in arch VGPRs and is copied (v_accvgpr_write)
+        // in front of every MFMA.  The loads are invisible to the compiler's vmcnt bookkeeping: the prologue's s_waitcnt vmcnt(0) covers them.
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=a"(w.qf[qb][ks]) : "v"(qp + (long)qrow[qb] * a.q_ss + ks * 16 + hi * 8) : "memory");
+    }
+    // LDS image of both tiles: row r, 16-B chunk c at r*256 + ((c ^ (r&15)) << 4); the hardware writes lane-linearly, so each lane fetches
+    // the SOURCE chunk that belongs at its linear position.  Key rows >= Skv are outside the descriptor's range -> zeros.
+    w.k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (unsigned)((((long)a.Skv - 1) * a.k_ss + 128) * 2), 0x00020000);
+    w.v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vtp, 0, (unsigned)(256L * a.Skv_pad), 0x00020000);
+    const int r0 = 4 * wave + (lane >> 4);
+    const unsigned sw0 = (unsigned)(((lane & 15) ^ (r0 & 15)) << 4);
+    w.kv0 = (unsigned)(((long)r0 * a.k_ss) * 2) + sw0;
+    w.vv0 = (unsigned)(r0 * a.Skv_pad * 2) + sw0;
+    w.k_pstride = (unsigned)(16 * a.k_ss * 2);
+    w.v_pstride = (unsigned)(16 * a.Skv_pad * 2);
+    w.k_tile_bytes = (unsigned)(a.k_ss * 2 * KT);
+    w.pdst = wave * 1024;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) w.foff[ks] = l31 * 256 + (((2 * ks + hi) ^ (l31 & 15)) << 4);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        w.m_run[qb] = -1e30f;
+        w.l_run[qb] = 0.f;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) w.o[qb][d][r] = 0.f;
+    }
+
+    w.fence_o();  // zero-initialised accumulators (v_accvgpr_write) -> first MFMA
+#define WAIT_ALL() asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define WAIT8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // everything but this wave's youngest set (8 pieces) has landed
+#define BAR()                                   \
+    {                                           \
+        __builtin_amdgcn_sched_barrier(0);      \
+        __builtin_amdgcn_s_barrier();           \
+        __builtin_amdgcn_sched_barrier(0);      \
+    }
+    // ---- prologue: K(0), V^T(0) -> slot 0 ---------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w.k_rsrc, (lds_void*)(smem + w.pdst + i * 4096), 16, w.kv0,
+                                                 __builtin_amdgcn_readfirstlane(i * w.k_pstride), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w.v_rsrc, (lds_void*)(smem + V_BASE + w.pdst + i * 4096), 16, w.vv0,
+                                                 __builtin_amdgcn_readfirstlane(i * w.v_pstride), 0, 0);
+    }
+    WAIT_ALL()
+    BAR()
+    const int v0 = v_last < 64 ? v_last : 64, v1 = v_last > 64 ? v_last - 64 : 0;  // valid keys of the last stage's two sub-tiles
+    // iteration 0 (issues K(1)); then pairs (2j+1, 2j+2) for j = 0 .. n-2, the last even iteration masked; then the last odd iteration, masked
+    if (n == 1) w.iter<0, true, true, SCHED>(0, v0, hi); else w.iter<0, true, false, SCHED>(0, 64, hi);
+    for (int j = 0; j + 2 < n; ++j) {  // straight-line body: a conditional inside would make the register assignment of the two paths meet with copies
+        WAIT8()
+        BAR()
+        w.iter<1, false, false, SCHED>(j, 64, hi);          // t = 2j+1: Q·K^T on stage j (second half), P·V(2j); issues V^T(j+1)
+        WAIT8()
+        BAR()
+        w.iter<0, false, false, SCHED>(j + 1, 64, hi);      // t = 2j+2: Q·K^T on stage j+1 (first half), P·V(2j+1); issues K(j+2)
+    }
+    if (n >= 2) {  // the last pair: its even iteration is the first half of the last stage (masked)
+        WAIT8()
+        BAR()
+        w.iter<1, false, false, SCHED>(n - 2, 64, hi);
+        WAIT8()
+        BAR()
+        w.iter<0, false, true, SCHED>(n - 1, v0, hi);
+    }
+    WAIT8()
+    BAR()
+    w.iter<1, false, true, SCHED>(n - 1, v1, hi);              // t = 2n-1
+    // ---- tail: P·V(2n-1) ---------------------------------------------------------------------------------------------------------------
+    w.pv_plain<1>(n - 1, 1);
+    w.fence_o();  // the last MFMAs' results before the epilogue's v_accvgpr_read
+    WAIT_ALL()  // the harmless re-reads of stage 0 have landed (the exact pass below re-uses the ring; afterwards the LDS can be re-assigned)
+    {   // fixed-reference range check: a row sum that is NaN, infinite or >= 2^90 sends the WHOLE workgroup through the exact pass
+        const bool bad = !(xhalf_sum64(w.l_run[0]) < L_LIMIT) || !(xhalf_sum64(w.l_run[1]) < L_LIMIT);
+        if (__syncthreads_or(bad)) w.exact_pass(v_last, hi);
+    }  // the harmless re-reads of stage 0 have landed before this workgroup's LDS can be re-assigned
+#undef WAIT_ALL
+#undef WAIT8
+#undef BAR
+
+    // ---- epilogue -------------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = xhalf_sum64(w.l_run[qb]);
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+        if (q_ok[qb]) {
+            bf16_t* orow = op + (long)qrow[qb] * a.o_ss;
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 v4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(w.o[qb][d][g * 4 + e] * inv);
+                    *reinterpret_cast<bf16x4*>(orow + d * 32 + g * 8 + hi * 4) = v4;
+                }
+            if (a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow[qb]] = w.m_run[qb] * w.c2 + log2f(l_tot);
+        }
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int SCHED>
+int launch_w64(const fvk_attn_args* a, hipStream_t s) {
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_w64_kernel<SCHED>, LDS_BYTES, "fvk_attn_dense_bf16 (w64)")) return rc;
+    const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
+    hipLaunchKernelGGL((attn_w64_kernel<SCHED>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+}  // namespace
+
+// variant (measurement build): 1 = phase 2 without the scheduling barriers (the compiler's own placement of the softmax around the MFMAs)
+int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s) {
+#if FVK_VARIANTS
+    if (variant == 1) return launch_w64<0>(a, s);
+#endif
+    (void)variant;
+    return launch_w64<1>(a, s);
+}

@@ -329,15 +329,21 @@ def _vt_of(v, layout):
     return v_transpose(v if layout == "bshd" else v.transpose(1, 2))
 
 
-def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None):
-    """Dense non-causal attention.  Pass v (same layout as k) or a precomputed vt = v_transpose(v)."""
+def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, return_lse=False):
+    """Dense non-causal attention.  Pass v (same layout as k) or a precomputed vt = v_transpose(v).
+    return_lse: also the base-2 log-sum-exp of the scaled scores per query row, fp32 [B, H, Sq] (full-length kernels only: Sq >= 256)."""
     scale = q.shape[-1]**-0.5 if scale is None else scale
     if vt is None:
         vt = _vt_of(v, layout)
     o = torch.empty_like(q) if out is None else out
-    a = _attn_args(q, k, vt, o, scale, layout)
+    lse = None
+    if return_lse:
+        B, H = (q.shape[0], q.shape[2]) if layout == "bshd" else (q.shape[0], q.shape[1])
+        Sq = q.shape[1] if layout == "bshd" else q.shape[2]
+        lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
+    a = _attn_args(q, k, vt, o, scale, layout, lse)
     _lib.call("fvk_attn_dense_bf16", C.byref(a), _stream())
-    return o
+    return (o, lse) if return_lse else o
 
 
 def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, layout="bhsd", return_lse=False, q_block=64):

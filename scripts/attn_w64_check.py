@@ -1,0 +1,66 @@
+"""attn_w64 (4 waves x 64 rows, attn_impl 200) vs the shipped 8-wave kernel and the fp32 reference: correctness at ragged shapes and with
+spiked keys (the exact-recompute path), then interleaved timing at the cfg2 shape.  Measurement build."""
+import os as _os
+_os.environ.setdefault("FVK_PROBE_LIB", "1")
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from fastvideo_amd import ops
+from oracle import wan_oracle as W
+
+def run(impl, q, k, v):
+    ops.set_tunable("attn_impl", impl)
+    try:
+        o, lse = ops.attn_dense(q, k, v, layout="bshd", return_lse=True)
+        torch.cuda.synchronize()
+        return o, lse
+    finally:
+        ops.set_tunable("attn_impl", 0)
+
+ok = True
+for (B, H, Sq, Skv, spike) in [(1, 2, 256, 128, 0), (1, 2, 256, 64, 0), (1, 1, 256, 1, 0), (1, 2, 700, 700, 0), (2, 3, 512, 130, 0), (1, 2, 1030, 1999, 0), (1, 1, 300, 257, 0),
+                               (1, 2, 640, 640, 1), (1, 2, 1030, 2999, 2), (1, 12, 2048, 4096, 0)]:
+    g = torch.Generator().manual_seed(Sq + Skv)
+    q, k, v = (torch.randn((B, s_, H, 128), generator=g).bfloat16() for s_ in (Sq, Skv, Skv))
+    if spike == 1:
+        k[0, 250, 0] = q[0, 7, 0] * 6
+        k[0, 600, 1] = q[0, 300, 1] * 6
+    if spike == 2:
+        k[0, 2500, 1] = q[0, 700, 1] * 6
+        k[0, 100, 0] = q[0, 5, 0] * 20      # growth far beyond any fixed-reference range
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
+    o0, l0 = run(0, qd, kd, vd)
+    o1, l1 = run(200, qd, kd, vd)
+    e0 = (o0.float().cpu() - ref).abs()
+    e1 = (o1.float().cpu() - ref).abs()
+    d = (o1.float() - o0.float()).abs().max().item()
+    dl = (l1 - l0).abs().max().item()
+    good = bool(torch.isfinite(o1.float()).all()) and e1.max().item() < 4e-2 and e1.mean().item() < 3e-3 * ref.abs().mean().item() + 2e-5 and dl < 2e-2
+    ok = ok and good
+    print(f"B{B} H{H} Sq{Sq} Skv{Skv} spike{spike}: w64 max {e1.max().item():.3g} mean {e1.mean().item():.3g} | pp2 max {e0.max().item():.3g} mean {e0.mean().item():.3g} | "
+          f"w64-pp2 max {d:.3g} lse diff {dl:.3g} {'ok' if good else 'FAIL'}", flush=True)
+# repeatability
+o_a, _ = run(200, qd, kd, vd); o_b, _ = run(200, qd, kd, vd)
+print("repeatable:", bool(torch.equal(o_a, o_b)))
+print("ALL OK" if ok else "SOME FAILED")
+# timing at the cfg2 shape
+S, H, D = 32760, 12, 128
+q, k, v = (torch.randn(1, S, H, D, device="cuda").bfloat16() for _ in range(3))
+vt = ops.v_transpose(v); o = torch.empty_like(q)
+fl = 4.0 * S * S * H * D
+impls = [int(x) for x in sys.argv[1:]] or [0, 200, 201]
+res = {i: [] for i in impls}
+for r in range(5):
+    for i in impls:
+        ops.set_tunable("attn_impl", i)
+        ops.attn_dense(q, k, vt=vt, out=o); torch.cuda.synchronize()
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        for _ in range(5): ops.attn_dense(q, k, vt=vt, out=o)
+        e_.record(); torch.cuda.synchronize()
+        res[i].append(s_.elapsed_time(e_) / 5)
+ops.set_tunable("attn_impl", 0)
+for i in impls:
+    m = sorted(res[i])[len(res[i]) // 2]
+    print(json.dumps({"impl": i, "ms": round(m, 4), "tflops": round(fl / m / 1e9, 1), "best": round(fl / min(res[i]) / 1e9, 1)}))
