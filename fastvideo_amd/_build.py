@@ -71,6 +71,10 @@ def _build_locked(verbose: bool, probe: bool = False) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         extra = ["-ffp-contract=off"] if src in ("sched_step.hip", "vae_post.hip") else []  # bit-exact fp32 arithmetic (no fused multiply-add)
+        if src == "attn_w64.hip":
+            # its 64-chunk iteration must be FULLY unrolled (every register-array index a constant): above clang's default budget for
+            # `#pragma unroll`, silently left as a loop otherwise — with the wave's whole register struct in scratch
+            extra += ["-mllvm", "-pragma-unroll-threshold=100000"]
         if probe:
             extra += ["-DFVK_PROBE_BUILD=1", "-I", CSRC]
         cmd = [cc, *FLAGS, *extra, "-c", path, "-o", obj]

@@ -7,12 +7,15 @@
 // FLOP.  64 rows need the whole 512-entry register file (Q 64 + O 128 + S 2 x 64 + P 2 x 32 + fragments), i.e. one wave per SIMD — so
 // the softmax can no longer hide behind a partner wave's matrix segment and is software-pipelined INSIDE the wave instead:
 //
-//   sub-tile = 64 keys.  iteration t:   phase 1  MFMA: Q·K^T of sub-tile t (32) + the iteration's 8 DMA pieces          (matrix pipe only)
-//                                       phase 2  MFMA: P·V of sub-tile t-1 (32)   ||   VALU: softmax of sub-tile t (exp2 against the running
-//                                                max of the iteration's START, row sums, bf16 pack) — independent, interleaved by
-//                                                sched_group_barrier (1 MFMA : SCHED VALU)
-//   (S double-buffered, so that Q·K^T of t+1 could overlap the softmax too, does not fit: S must live in arch VGPRs for the VALU, and
-//   Q 64 + S 128 + P 64 + fragments exceed the 256 of them; the compiler keeps only MFMA accumulators in AGPRs.)
+//   sub-tile = 64 keys.  iteration t:   MFMA stream:  P·V of sub-tile t-1 (32)  then  Q·K^T of sub-tile t+1 (32)
+//                                       VALU stream:  softmax of sub-tile t (exp2 against the fixed reference, row sums, bf16 pack)
+//   the three are independent inside the iteration: 64 chunks of { 1 MFMA | 1 score: fma, exp, add, (cvt_pk) }, pinned with
+//   sched_barrier — ~3.5 VALU instructions in the shadow of each 32-cycle MFMA.  S is double-buffered (Q·K^T(t+1) writes the other buffer).
+//
+// Register files, pinned by inline-asm constraints (every MFMA is asm): accumulator file: O 128 + Q fragments 64 (loaded there directly);
+// arch VGPRs: S 2 x 64 + P 2 x 32 + 4 fragments in flight + softmax temporaries.  (hipcc selects the AGPR-accumulator form for EVERY MFMA
+// builtin in a kernel that may use more than 256 registers — S would pay a v_accvgpr_read per score — and shuffles accumulators between the
+// files when builtin and asm forms are mixed.)
 //
 // Fixed softmax reference: p = exp2((s - m_ref) * c) with m_ref = the exact row max of the FIRST sub-tile, never updated — the hot loop has
 // no running max, no rescale of O and no branch (a rescale would have to touch the O accumulators with the VALU, which drags them out of
@@ -22,10 +25,9 @@
 // O as usual) that overwrites the result.  With RMS-normed q / k (the DiT) or randn inputs the growth is a few units; the recompute is
 // there for arbitrary callers and is exercised by the spiked-key tests.  Results agree with attn_pp2 to rounding, not bit for bit.
 //
-// Staging is attn_pp2's: 128-key stages (K 32 KiB + V^T 32 KiB) by LDS-DMA into a 2-deep XOR-swizzled ring; ONE barrier per iteration
-// (64 keys, 64 MFMAs per wave).  Behind the barrier before iteration 2j every wave has finished reading K(j-1), so K(j+1) is issued there
-// (8 pieces per wave in the gaps of phase 1); behind the one before iteration 2j+1 V^T(j-1) is free and V^T(j+1) is issued.  A set is needed
-// two barriers later, and each barrier is preceded by s_waitcnt vmcnt(8): everything but the youngest set has landed.
+// Staging is attn_pp2's: 128-key stages (K 32 KiB + V^T 32 KiB) by LDS-DMA into a 2-deep XOR-swizzled ring, ONE barrier per stage (a pair of
+// iterations): behind the barrier that follows iteration 2j the slots of K(j) and V^T(j-1) are free and {K(j+2), V^T(j+1)} is issued — 16
+// pieces per wave riding in the chunks of iteration 2j+1 — and waited for (vmcnt(0)) just before the next barrier, two iterations later.
 // Same operand orientation as the other kernels (S^T = K·Q^T: a softmax row is lane-local; O^T = V^T·P^T with P^T taken from the packed
 // S^T registers), same V^T input layout (fvk_v_transpose_bf16).
 #include "fvk_common.h"
@@ -55,7 +57,7 @@ struct W64 {
     // registers of one wave (everything is indexed with compile-time constants after unrolling)
     bf16x8 qf[2][8];     // Q fragments [q block][d step]
     f32x16 o[2][4];      // O^T accumulators [q block][d block]
-    f32x16 s[2][2];      // S^T of the current sub-tile [q block][32-key block]
+    f32x16 s[2][2][2];   // S^T [sub-tile parity][q block][32-key block]
     bf16x8 pf[2][2][4];  // P^T, packed [sub-tile parity][q block][16-key step]
     float m_run[2], l_run[2];
     int foff[8];
@@ -66,19 +68,18 @@ struct W64 {
     int pdst, n;
     unsigned char* smem;
 
-    // piece I (0..7) of the set issued in iteration T: even T = 2j -> K(j+1) into K(j-1)'s slot, odd T = 2j+1 -> V^T(j+1) into V^T(j-1)'s
-    // slot; stages past the end re-read stage 0 (harmless)
-    template <int ODD, int I>
-    __device__ __forceinline__ void issue_piece(int j) const {
-        const int t_ = j + 1 < n ? j + 1 : 0;
-        // the per-piece and per-stage parts of the source address are wave-uniform: they ride in the SGPR offset, the lane part (kv0 / vv0)
-        // is ONE arch VGPR per tensor for all pieces
-        if constexpr (!ODD) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + ((j + 1) & 1) * K_TILE + pdst + I * 4096), 16, kv0,
+    // piece I (0..7 = K(j+2), 8..15 = V^T(j+1)) of the set issued behind the barrier of pair j; stages past the end re-read stage 0 (harmless).
+    // The per-piece and per-stage parts of the source address are wave-uniform: they ride in the SGPR offset, the lane part (kv0 / vv0) is ONE
+    // arch VGPR per tensor for all pieces.
+    __device__ __forceinline__ void issue_piece(int I, int j) const {  // I is a compile-time constant after unrolling
+        if (I < 8) {
+            const int t_ = j + 2 < n ? j + 2 : 0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + (j & 1) * K_TILE + pdst + I * 4096), 16, kv0,
                                                      __builtin_amdgcn_readfirstlane(I * k_pstride + (unsigned)t_ * k_tile_bytes), 0, 0);
         } else {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + ((j + 1) & 1) * V_TILE + pdst + I * 4096), 16, vv0,
-                                                     __builtin_amdgcn_readfirstlane(I * v_pstride + t_ * (KT * 2)), 0, 0);
+            const int t_ = j + 1 < n ? j + 1 : 0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + ((j + 1) & 1) * V_TILE + pdst + (I - 8) * 4096), 16, vv0,
+                                                     __builtin_amdgcn_readfirstlane((I - 8) * v_pstride + t_ * (KT * 2)), 0, 0);
         }
     }
     // V^T fragment of stage st: k-step kk (16 keys), d-block db;  K fragment of stage st: d-step ks, key block kb (32 keys)
@@ -97,7 +98,8 @@ struct W64 {
 #define FVK_MFMA_PV(ACC0, ACC1, FR, P0, P1)                                                                             \
     asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1" : "+a"(ACC0), "+a"(ACC1) : "v"(FR), "v"(P0), "v"(P1))
     // MFMA result -> compiler-generated reader (VALU / v_accvgpr_read) and VALU / v_accvgpr_write -> MFMA operand: 16-pass XDL op = 18 wait states
-    __device__ __forceinline__ void fence_s() { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1])); }
+    template <int PAR>
+    __device__ __forceinline__ void fence_s() { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s[PAR][0][0]), "+v"(s[PAR][0][1]), "+v"(s[PAR][1][0]), "+v"(s[PAR][1][1])); }
     __device__ __forceinline__ void fence_o() {
         asm volatile("s_nop 15\n\ts_nop 3" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));
     }
@@ -113,6 +115,7 @@ struct W64 {
             }
     }
     // keys of the sub-tile at or beyond `valid` (0..64) get -inf (last stage only)
+    template <int PAR>
     __device__ __forceinline__ void mask_keys(int valid, int hi) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb)
@@ -121,15 +124,15 @@ struct W64 {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= valid) s[qb][kb][r] = -INFINITY;
+                    if (key >= valid) s[PAR][qb][kb][r] = -INFINITY;
                 }
     }
     // row max of the sub-tile (this lane holds 32 of its row's 64 scores, lane^32 the other 32)
-    template <int QB>
+    template <int PAR, int QB>
     __device__ __forceinline__ float row_max() const {
-        float mx = fmaxf(s[QB][0][0], s[QB][1][0]);
+        float mx = fmaxf(s[PAR][QB][0][0], s[PAR][QB][1][0]);
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[QB][0][r]), s[QB][1][r]);
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[PAR][QB][0][r]), s[PAR][QB][1][r]);
         return xhalf_max64(mx);
     }
     // p = exp2(s*c2 - mc) for values [8*kk .. 8*kk+8) of q block QB (one packed P fragment): the partial row sums go to ps4, P packed to bf16
@@ -137,7 +140,7 @@ struct W64 {
     __device__ __forceinline__ void exp_pack8(float mc, float (&ps4)[4]) {
 #pragma unroll
         for (int jj = 0; jj < 8; ++jj) {
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[QB][KK >> 1][(KK & 1) * 8 + jj], c2, -mc));
+            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[PAR][QB][KK >> 1][(KK & 1) * 8 + jj], c2, -mc));
             ps4[jj & 3] += p;
             pf[PAR][QB][KK][jj] = (bf16_t)p;
         }
@@ -154,7 +157,7 @@ struct W64 {
     // exact online-softmax step (new running max first; O and l rescaled): first sub-tile and the slow path
     template <int PAR, bool RESCALE>
     __device__ __forceinline__ void softmax_exact() {
-        float mx[2] = {row_max<0>(), row_max<1>()};
+        float mx[2] = {row_max<PAR, 0>(), row_max<PAR, 1>()};
         if (RESCALE) fence_o();  // the P·V MFMAs just issued have written O before the compiler's v_accvgpr_read
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -174,18 +177,19 @@ struct W64 {
     }
 
     // Q·K^T of the sub-tile (ring slot st, half hf) -> s: plain form (exact pass)
+    template <int PAR>
     __device__ __forceinline__ void qk_plain(int st, int hf) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const bf16x8 fr = frag_k(st, i >> 1, 2 * hf + (i & 1));
             if (i < 2)
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, 0"
-                             : "=&v"(s[0][i & 1]), "=&v"(s[1][i & 1]) : "v"(fr), "a"(qf[0][i >> 1]), "a"(qf[1][i >> 1]));
+                             : "=&v"(s[PAR][0][i & 1]), "=&v"(s[PAR][1][i & 1]) : "v"(fr), "a"(qf[0][i >> 1]), "a"(qf[1][i >> 1]));
             else
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1"
-                             : "+v"(s[0][i & 1]), "+v"(s[1][i & 1]) : "v"(fr), "a"(qf[0][i >> 1]), "a"(qf[1][i >> 1]));
+                             : "+v"(s[PAR][0][i & 1]), "+v"(s[PAR][1][i & 1]) : "v"(fr), "a"(qf[0][i >> 1]), "a"(qf[1][i >> 1]));
         }
-        fence_s();
+        fence_s<PAR>();
     }
     // The exact pass (rare: only when a row's fixed-reference sum left the safe range): plain online softmax over all keys with a running
     // max and O rescaled by the VALU, one stage at a time through ring slot 0 (load, wait, barrier, compute — no overlap).  Every wave of
@@ -220,8 +224,8 @@ struct W64 {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {  // (fully unrolled: a runtime index into foff[] would pin the whole register struct to scratch)
                 if (valid > 64 * hf) {
-                    qk_plain(0, hf);
-                    if (valid - 64 * hf < 64) mask_keys(valid - 64 * hf, hi);
+                    qk_plain<0>(0, hf);
+                    if (valid - 64 * hf < 64) mask_keys<0>(valid - 64 * hf, hi);
                     softmax_exact<0, true>();
                     pv_plain<0>(0, hf);
                 }
@@ -230,82 +234,57 @@ struct W64 {
         fence_o();
     }
 
-    // ---- iteration t = 2j + ODD: phase 1 Q·K^T(t) (stage j, key blocks 2*ODD, +1) with this wave's 8 DMA pieces of the iteration's set;
-    // phase 2 P·V(t-1) (stage (t-1)>>1, k-steps 4*(1-ODD)..+3, pf[1-ODD]) interleaved with the softmax of sub-tile t -> pf[ODD].
-    // FIRST: t = 0 (no P·V, exact softmax).  MASK: keys >= valid are masked (last stage).  SCHED: VALU per MFMA gap pinned in phase 2.
-    template <int ODD, bool FIRST, bool MASK, int SCHED>
+    // ---- iteration t = 2j + 1 + EVEN (pair j): 64 chunks of { 1 MFMA | the softmax of ONE score: fma, exp, add, every second chunk a
+    // cvt_pk }, pinned with sched_barrier.  MFMA stream: P·V of sub-tile t-1 (stage j, k-steps 4*EVEN..+3, pf[EVEN]) then Q·K^T of sub-tile
+    // t+1 (stage j+1, key blocks 2*EVEN, +1 -> s[EVEN]); each of the 32 fragments (read FD ahead) feeds two consecutive chunks (q block 0,
+    // 1).  VALU stream: sub-tile t = s[1-EVEN] -> pf[1-EVEN], against the fixed reference.  EVEN = 0 also carries this wave's 16 DMA
+    // pieces of set j ({K(j+2), V^T(j+1)}: their slots were freed by the pair's barrier), one per 4 chunks.
+    // MASK: keys >= valid of sub-tile t are masked (last stage).
+    // ABL (measurement build; results are wrong, timing is what is measured): bit 0 no DMA pieces in the loop, bit 2 no softmax VALU in the loop
+    template <int EVEN, bool MASK, bool PIN, int ABL = 0>
     __device__ __forceinline__ void iter(int j, int valid, int hi) {
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        constexpr int FD = 4;  // fragments in flight
-        {   // ---- phase 1: fragment i = (d-step i>>1, key block i&1), each feeding the two q blocks.  volatile asm statements keep their
-            // order against the LDS reads and the DMA pieces, so the source order below IS the software pipeline (fragments read FD ahead,
-            // one DMA piece per 4 MFMAs).
-            bf16x8 fr[FD];
-#pragma unroll
-            for (int i = 0; i < FD; ++i) fr[i] = frag_k(j, i >> 1, 2 * ODD + (i & 1));
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (i < 2)
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, 0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, 0"
-                                 : "=&v"(s[0][i & 1]), "=&v"(s[1][i & 1])
-                                 : "v"(fr[i % FD]), "a"(qf[0][i >> 1]), "a"(qf[1][i >> 1]));
-                else
-                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %2, %3, %0\n\tv_mfma_f32_32x32x16_bf16 %1, %2, %4, %1"
-                                 : "+v"(s[0][i & 1]), "+v"(s[1][i & 1])
-                                 : "v"(fr[i % FD]), "a"(qf[0][i >> 1]), "a"(qf[1][i >> 1]));
-                if (i + FD < 16) fr[i % FD] = frag_k(j, (i + FD) >> 1, 2 * ODD + ((i + FD) & 1));
-                if ((i & 1) == 0) {  // one DMA piece per 4 MFMAs
-                    switch (i >> 1) {
-                        case 0: issue_piece<ODD, 0>(j); break;
-                        case 1: issue_piece<ODD, 1>(j); break;
-                        case 2: issue_piece<ODD, 2>(j); break;
-                        case 3: issue_piece<ODD, 3>(j); break;
-                        case 4: issue_piece<ODD, 4>(j); break;
-                        case 5: issue_piece<ODD, 5>(j); break;
-                        case 6: issue_piece<ODD, 6>(j); break;
-                        default: issue_piece<ODD, 7>(j); break;
-                    }
-                }
-            }
-            fence_s();
+        constexpr int CUR = 1 - EVEN, FD = 4;
+        if (MASK) {
+            fence_s<CUR>();  // the previous iteration's last Q·K^T MFMAs wrote these registers a few instructions ago
+            mask_keys<CUR>(valid, hi);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (MASK) mask_keys(valid, hi);
-        if (FIRST) {  // the reference: exact row max of the first sub-tile (it has at least one valid key)
-            m_run[0] = row_max<0>();
-            m_run[1] = row_max<1>();
-            l_run[0] = exp_pack<ODD, 0>(m_run[0] * c2);
-            l_run[1] = exp_pack<ODD, 1>(m_run[1] * c2);
-            return;
-        }
-        // ---- phase 2: 32 chunks of { 1 MFMA | the softmax of 2 scores: 2 fma, 2 exp, 2 add, 1 cvt_pk }, pinned with sched_barrier: ~7 VALU
-        // (~4 cycles each) in the shadow of one 32-cycle MFMA.  V^T fragment i feeds chunks 2i (q block 0) and 2i+1 (q block 1); chunk c
-        // handles scores 2c, 2c+1 of the lane's 64 (q block c>>4, P fragment (c>>2)&3, values 2*(c&3), +1).
         const float mc0 = m_run[0] * c2, mc1 = m_run[1] * c2;
-        const int stp = ODD ? j : j - 1;  // stage of sub-tile t-1
         bf16x8 fr[FD];
 #pragma unroll
-        for (int i = 0; i < FD; ++i) fr[i] = frag_v(stp, 4 * (1 - ODD) + (i >> 2), i & 3);
+        for (int i = 0; i < FD; ++i) fr[i] = frag_v(j, 4 * EVEN + (i >> 2), i & 3);
         float psA[2] = {0.f, 0.f}, psB[2] = {0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const int i = c >> 1;  // fragment (k-step i>>2, d-block i&3)
-            if ((c & 1) == 0) FVK_MFMA1(o[0][i & 3], fr[i % FD], pf[1 - ODD][0][i >> 2]);
-            else FVK_MFMA1(o[1][i & 3], fr[i % FD], pf[1 - ODD][1][i >> 2]);
-            if ((c & 1) && i + FD < 16) fr[i % FD] = frag_v(stp, 4 * (1 - ODD) + ((i + FD) >> 2), (i + FD) & 3);
-            const int qb = c >> 4, kk = (c >> 2) & 3, j0 = 2 * (c & 3);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int jj = j0 + e, r = (kk & 1) * 8 + jj;
-                const float sv = qb == 0 ? s[0][kk >> 1][r] : s[1][kk >> 1][r];
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c2, qb == 0 ? -mc0 : -mc1));
-                if (qb == 0) psA[e] += p; else psB[e] += p;
-                pf[ODD][qb][kk][jj] = (bf16_t)p;
+        for (int c = 0; c < 64; ++c) {
+            const int i = c >> 1;  // fragment: i < 16: V^T (k-step i>>2, d-block i&3); else K (d-step (i-16)>>1, key block (i-16)&1)
+            if (i < 16) {
+                if ((c & 1) == 0) FVK_MFMA1(o[0][i & 3], fr[i % FD], pf[EVEN][0][i >> 2]);
+                else FVK_MFMA1(o[1][i & 3], fr[i % FD], pf[EVEN][1][i >> 2]);
+            } else {
+                const int ks = (i - 16) >> 1, kb = (i - 16) & 1;
+                if (ks == 0) {
+                    if ((c & 1) == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s[EVEN][0][kb]) : "v"(fr[i % FD]), "a"(qf[0][ks]));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(s[EVEN][1][kb]) : "v"(fr[i % FD]), "a"(qf[1][ks]));
+                } else {
+                    if ((c & 1) == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[EVEN][0][kb]) : "v"(fr[i % FD]), "a"(qf[0][ks]));
+                    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[EVEN][1][kb]) : "v"(fr[i % FD]), "a"(qf[1][ks]));
+                }
             }
-            // keep the chunk's work IN the chunk (a use here, before the scheduling barrier)
-            if ((c & 3) == 3) asm volatile("" : "+v"(pf[ODD][qb][kk]));
-            if (qb == 0) asm volatile("" : "+v"(psA[0]), "+v"(psA[1])); else asm volatile("" : "+v"(psB[0]), "+v"(psB[1]));
-            if (SCHED > 0) __builtin_amdgcn_sched_barrier(0);
+            if (c & 1) {
+                const int nx = i + FD;
+                if (nx < 32) fr[i % FD] = nx < 16 ? frag_v(j, 4 * EVEN + (nx >> 2), nx & 3) : frag_k(j + 1, (nx - 16) >> 1, 2 * EVEN + ((nx - 16) & 1));
+            }
+            if (EVEN == 0 && (c & 3) == 1 && !(ABL & 1)) issue_piece(c >> 2, j);
+            if (!(ABL & 4)) {   // the softmax of score c of the lane's 64: q block c>>5, P fragment (c>>3)&3, value c&7
+                const int qb = c >> 5, kk = (c >> 3) & 3, jj = c & 7, r = (kk & 1) * 8 + jj;
+                const float sv = qb == 0 ? s[CUR][0][kk >> 1][r] : s[CUR][1][kk >> 1][r];
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c2, qb == 0 ? -mc0 : -mc1));
+                if (qb == 0) psA[c & 1] += p; else psB[c & 1] += p;
+                pf[CUR][qb][kk][jj] = (bf16_t)p;
+                // keep the chunk's work IN the chunk (a use here, before the scheduling barrier)
+                if (jj == 7) asm volatile("" : "+v"(pf[CUR][qb][kk]));
+                if (qb == 0) asm volatile("" : "+v"(psA[0]), "+v"(psA[1])); else asm volatile("" : "+v"(psB[0]), "+v"(psB[1]));
+            }
+            if (PIN) __builtin_amdgcn_sched_barrier(0);
         }
         l_run[0] += psA[0] + psA[1];
         l_run[1] += psB[0] + psB[1];
@@ -314,7 +293,7 @@ struct W64 {
 #undef FVK_MFMA1
 };
 
-template <int SCHED>
+template <bool PIN, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -388,40 +367,53 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
         __builtin_amdgcn_s_barrier();           \
         __builtin_amdgcn_sched_barrier(0);      \
     }
-    // ---- prologue: K(0), V^T(0) -> slot 0 ---------------------------------------------------------------------------------------------
+    // ---- prologue: K(0), V^T(0) -> slot 0, K(1) -> slot 1; Q·K^T(0), the reference + softmax(0), Q·K^T(1) --------------------------------
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w.k_rsrc, (lds_void*)(smem + w.pdst + i * 4096), 16, w.kv0,
                                                  __builtin_amdgcn_readfirstlane(i * w.k_pstride), 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(w.k_rsrc, (lds_void*)(smem + K_TILE + w.pdst + i * 4096), 16, w.kv0,
+                                                 __builtin_amdgcn_readfirstlane(i * w.k_pstride + (n > 1 ? w.k_tile_bytes : 0u)), 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w.v_rsrc, (lds_void*)(smem + V_BASE + w.pdst + i * 4096), 16, w.vv0,
                                                  __builtin_amdgcn_readfirstlane(i * w.v_pstride), 0, 0);
     }
     WAIT_ALL()
     BAR()
     const int v0 = v_last < 64 ? v_last : 64, v1 = v_last > 64 ? v_last - 64 : 0;  // valid keys of the last stage's two sub-tiles
-    // iteration 0 (issues K(1)); then pairs (2j+1, 2j+2) for j = 0 .. n-2, the last even iteration masked; then the last odd iteration, masked
-    if (n == 1) w.iter<0, true, true, SCHED>(0, v0, hi); else w.iter<0, true, false, SCHED>(0, 64, hi);
+    w.qk_plain<0>(0, 0);
+    if (n == 1) w.mask_keys<0>(v0, hi);
+    // the fixed reference: exact row max of the first sub-tile (it has at least one valid key)
+    w.m_run[0] = w.row_max<0, 0>();
+    w.m_run[1] = w.row_max<0, 1>();
+    w.l_run[0] = w.exp_pack<0, 0>(w.m_run[0] * w.c2);
+    w.l_run[1] = w.exp_pack<0, 1>(w.m_run[1] * w.c2);
+    w.qk_plain<1>(0, 1);
+    // ---- pairs j = 0 .. n-2: iterations t = 2j+1 and 2j+2 behind ONE barrier; the last pair masks sub-tile 2n-2 ------------------------------
     for (int j = 0; j + 2 < n; ++j) {  // straight-line body: a conditional inside would make the register assignment of the two paths meet with copies
-        WAIT8()
-        BAR()
-        w.iter<1, false, false, SCHED>(j, 64, hi);          // t = 2j+1: Q·K^T on stage j (second half), P·V(2j); issues V^T(j+1)
-        WAIT8()
-        BAR()
-        w.iter<0, false, false, SCHED>(j + 1, 64, hi);      // t = 2j+2: Q·K^T on stage j+1 (first half), P·V(2j+1); issues K(j+2)
+        if (!(ABL & 2)) {
+            WAIT_ALL()  // this wave's pieces of set j-1 (issued a whole pair ago) have landed
+            BAR()       // every wave is past iteration 2j: the slots of K(j) and V^T(j-1) are free, set j-1 is visible
+        }
+        w.iter<0, false, PIN, ABL>(j, 64, hi);
+        w.iter<1, false, PIN, ABL>(j, 64, hi);
     }
-    if (n >= 2) {  // the last pair: its even iteration is the first half of the last stage (masked)
-        WAIT8()
+    if (n >= 2) {
+        WAIT_ALL()
         BAR()
-        w.iter<1, false, false, SCHED>(n - 2, 64, hi);
-        WAIT8()
-        BAR()
-        w.iter<0, false, true, SCHED>(n - 1, v0, hi);
+        w.iter<0, false, PIN>(n - 2, 64, hi);
+        w.iter<1, true, PIN>(n - 2, v0, hi);
     }
-    WAIT8()
+    // ---- tail: P·V(2n-2), softmax of sub-tile 2n-1 (second half of the last stage, masked), P·V(2n-1) --------------------------------------
+    WAIT_ALL()  // V^T(n-1) (and the harmless re-reads of stage 0) landed
     BAR()
-    w.iter<1, false, true, SCHED>(n - 1, v1, hi);              // t = 2n-1
-    // ---- tail: P·V(2n-1) ---------------------------------------------------------------------------------------------------------------
-    w.pv_plain<1>(n - 1, 1);
+    w.pv_plain<0>(n - 1, 0);
+    if (v1 > 0) {  // workgroup-uniform
+        w.fence_s<1>();
+        w.mask_keys<1>(v1, hi);
+        w.l_run[0] += w.exp_pack<1, 0>(w.m_run[0] * w.c2);
+        w.l_run[1] += w.exp_pack<1, 1>(w.m_run[1] * w.c2);
+        w.pv_plain<1>(n - 1, 1);
+    }
     w.fence_o();  // the last MFMAs' results before the epilogue's v_accvgpr_read
     WAIT_ALL()  // the harmless re-reads of stage 0 have landed (the exact pass below re-uses the ring; afterwards the LDS can be re-assigned)
     {   // fixed-reference range check: a row sum that is NaN, infinite or >= 2^90 sends the WHOLE workgroup through the exact pass
@@ -454,12 +446,12 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int SCHED>
+template <bool PIN, int ABL = 0>
 int launch_w64(const fvk_attn_args* a, hipStream_t s) {
     static FvkLdsConfigured configured;
-    if (int rc = fvk_config_lds(configured, (const void*)attn_w64_kernel<SCHED>, LDS_BYTES, "fvk_attn_dense_bf16 (w64)")) return rc;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_w64_kernel<PIN, ABL>, LDS_BYTES, "fvk_attn_dense_bf16 (w64)")) return rc;
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
-    hipLaunchKernelGGL((attn_w64_kernel<SCHED>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a);
+    hipLaunchKernelGGL((attn_w64_kernel<PIN, ABL>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -469,8 +461,17 @@ int launch_w64(const fvk_attn_args* a, hipStream_t s) {
 // variant (measurement build): 1 = phase 2 without the scheduling barriers (the compiler's own placement of the softmax around the MFMAs)
 int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s) {
 #if FVK_VARIANTS
-    if (variant == 1) return launch_w64<0>(a, s);
+    switch (variant) {
+        case 1: return launch_w64<false>(a, s);
+        // timing ablations (attn_impl 210 + bits: 1 no DMA in the loop, 2 no barrier / wait in the loop, 4 no softmax VALU in the loop)
+        case 11: return launch_w64<true, 1>(a, s);
+        case 12: return launch_w64<true, 2>(a, s);
+        case 13: return launch_w64<true, 3>(a, s);
+        case 14: return launch_w64<true, 4>(a, s);
+        case 17: return launch_w64<true, 7>(a, s);
+        default: break;
+    }
 #endif
     (void)variant;
-    return launch_w64<1>(a, s);
+    return launch_w64<true>(a, s);
 }

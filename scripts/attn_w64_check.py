@@ -49,7 +49,7 @@ S, H, D = 32760, 12, 128
 q, k, v = (torch.randn(1, S, H, D, device="cuda").bfloat16() for _ in range(3))
 vt = ops.v_transpose(v); o = torch.empty_like(q)
 fl = 4.0 * S * S * H * D
-impls = [int(x) for x in sys.argv[1:]] or [0, 200, 201]
+impls = [int(x) for x in sys.argv[1:]] or [0, 200, 201, 0, 200]
 res = {i: [] for i in impls}
 for r in range(5):
     for i in impls:
