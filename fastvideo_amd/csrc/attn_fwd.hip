@@ -516,16 +516,19 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
         ModeArgs ma{};
         return launch<4, MODE_DENSE, 384>(a, ma, (hipStream_t)stream);
     }
-    const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
-    // full-length query blocks: 0 = the 128-key-tile ping-pong kernel (attn_pp2.hip, shipped); 1 = this file's 4-wave kernel;
-    // >= 2 = the 64-key-tile ping-pong kernel (attn_pp.hip) variant impl-1 (measurement only)
+    const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);  // constant 0 in the product library
+    // full-length query blocks: 0 = attn_w64.hip (shipped since round 3: 4 waves x 64 query rows, one wave per SIMD — every K / V^T fragment
+    // read from LDS feeds two MFMAs); measurement build: 1 = this file's 4-wave kernel, 2..98 = attn_pp.hip (64-key tiles), 99 = attn_pp2.hip
+    // (the 8-wave ping-pong kernel shipped in rounds 1-2, still the kernel behind fvk_attn_tile_lists_bf16), 100.. its probe / schedule
+    // variants and timing ablations (attn_pp2.hip: fvk_attn_pp2_launch(impl - 99)), 200.. attn_w64 variants
+    if (a->Sq >= 256) {
 #if FVK_VARIANTS
-    if (impl >= 200 && impl < 300 && a->Sq >= 256) return fvk_attn_w64_launch(a, impl - 200, (hipStream_t)stream);  // 4 waves x 64 rows
+        if (impl >= 200 && impl < 300) return fvk_attn_w64_launch(a, impl - 200, (hipStream_t)stream);
+        if (impl >= 99) return fvk_attn_pp2_launch(a, impl - 99, (hipStream_t)stream);
+        if (impl >= 2) return fvk_attn_pp_launch(a, impl - 1, (hipStream_t)stream);
 #endif
-    if ((impl == 0 || impl >= 100) && a->Sq >= 256) return fvk_attn_pp2_launch(a, impl >= 100 ? impl - 99 : 0, (hipStream_t)stream);
-#if FVK_VARIANTS
-    if (impl >= 2 && impl < 100 && a->Sq >= 256) return fvk_attn_pp_launch(a, impl - 1, (hipStream_t)stream);
-#endif
+        if (impl == 0) return fvk_attn_w64_launch(a, 0, (hipStream_t)stream);
+    }
     ModeArgs ma{};
     return launch<4, MODE_DENSE>(a, ma, (hipStream_t)stream);
 }

@@ -293,7 +293,7 @@ struct W64 {
 #undef FVK_MFMA1
 };
 
-template <bool PIN, int ABL = 0>
+template <bool PIN, int ABL = 0, bool PLAIN_IDS = false>
 __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -303,9 +303,13 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int nqb = (a.Sq + BMQ - 1) / BMQ;
-    const int q_first = (blockIdx.x % nqb) * BMQ;
-    const int h = (blockIdx.x / nqb) % a.H;
-    const int b = blockIdx.x / (nqb * a.H);
+    // XCD-aware deal: hardware workgroup id x lands on XCD x % 8 (its own L2); XCD c gets the CONTIGUOUS logical ids [c*q + min(c, r), ...), i.e.
+    // consecutive query blocks of the same head, which stream the same K / V^T
+    const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+    const int bid = PLAIN_IDS ? (int)blockIdx.x : xcd * xq + (xcd < xr ? xcd : xr) + (int)(blockIdx.x >> 3);
+    const int q_first = (bid % nqb) * BMQ;
+    const int h = (bid / nqb) % a.H;
+    const int b = bid / (nqb * a.H);
     const int n = (a.Skv + KT - 1) / KT;          // stages
     const int v_last = a.Skv - (n - 1) * KT;      // valid keys of the last stage, 1..128
 
@@ -416,42 +420,41 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
     }
     w.fence_o();  // the last MFMAs' results before the epilogue's v_accvgpr_read
     WAIT_ALL()  // the harmless re-reads of stage 0 have landed (the exact pass below re-uses the ring; afterwards the LDS can be re-assigned)
-    {   // fixed-reference range check: a row sum that is NaN, infinite or >= 2^90 sends the WHOLE workgroup through the exact pass
-        const bool bad = !(xhalf_sum64(w.l_run[0]) < L_LIMIT) || !(xhalf_sum64(w.l_run[1]) < L_LIMIT);
-        if (__syncthreads_or(bad)) w.exact_pass(v_last, hi);
-    }  // the harmless re-reads of stage 0 have landed before this workgroup's LDS can be re-assigned
-#undef WAIT_ALL
-#undef WAIT8
-#undef BAR
-
-    // ---- epilogue -------------------------------------------------------------------------------------------------------------------
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const float l_tot = xhalf_sum64(w.l_run[qb]);
-        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-        if (q_ok[qb]) {
-            bf16_t* orow = op + (long)qrow[qb] * a.o_ss;
-#pragma unroll
-            for (int d = 0; d < 4; ++d)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    bf16x4 v4;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(w.o[qb][d][g * 4 + e] * inv);
-                    *reinterpret_cast<bf16x4*>(orow + d * 32 + g * 8 + hi * 4) = v4;
-                }
-            if (a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow[qb]] = w.m_run[qb] * w.c2 + log2f(l_tot);
-        }
+    // ---- epilogue: normalise and store; a row whose fixed-reference sum left the safe range (NaN, infinite or >= 2^90) is redone by the
+    // exact pass and stored again — per ROW, so that a row's result never depends on which other rows share its wave or workgroup (the
+    // sequence-parallel paths rely on that: a different partition groups the rows differently).  The whole workgroup takes part in the
+    // exact pass (staging, barriers); only the flagged rows are overwritten.
+    bool redo[2] = {false, false};
+#define FVK_STORE_ROWS(ONLY_REDO)                                                                                    \
+    _Pragma("unroll") for (int qb = 0; qb < 2; ++qb) {                                                               \
+        const float l_tot = xhalf_sum64(w.l_run[qb]);                                                                \
+        const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;                                                          \
+        if (!(ONLY_REDO)) redo[qb] = !(l_tot < L_LIMIT);                                                             \
+        if (q_ok[qb] && (!(ONLY_REDO) || redo[qb])) {                                                                \
+            bf16_t* orow = op + (long)qrow[qb] * a.o_ss;                                                             \
+            _Pragma("unroll") for (int d = 0; d < 4; ++d) _Pragma("unroll") for (int g = 0; g < 4; ++g) {           \
+                bf16x4 v4;                                                                                           \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(w.o[qb][d][g * 4 + e] * inv);        \
+                *reinterpret_cast<bf16x4*>(orow + d * 32 + g * 8 + hi * 4) = v4;                                     \
+            }                                                                                                        \
+            if (a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow[qb]] = w.m_run[qb] * w.c2 + log2f(l_tot);  \
+        }                                                                                                            \
     }
+    FVK_STORE_ROWS(false)
+    if (__syncthreads_or(redo[0] || redo[1])) {
+        w.exact_pass(v_last, hi);
+        FVK_STORE_ROWS(true)
+    }
+#undef FVK_STORE_ROWS
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <bool PIN, int ABL = 0>
+template <bool PIN, int ABL = 0, bool PLAIN_IDS = false>
 int launch_w64(const fvk_attn_args* a, hipStream_t s) {
     static FvkLdsConfigured configured;
-    if (int rc = fvk_config_lds(configured, (const void*)attn_w64_kernel<PIN, ABL>, LDS_BYTES, "fvk_attn_dense_bf16 (w64)")) return rc;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_w64_kernel<PIN, ABL, PLAIN_IDS>, LDS_BYTES, "fvk_attn_dense_bf16 (w64)")) return rc;
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
-    hipLaunchKernelGGL((attn_w64_kernel<PIN, ABL>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a);
+    hipLaunchKernelGGL((attn_w64_kernel<PIN, ABL, PLAIN_IDS>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -463,6 +466,7 @@ int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s) {
 #if FVK_VARIANTS
     switch (variant) {
         case 1: return launch_w64<false>(a, s);
+        case 2: return launch_w64<true, 0, true>(a, s);  // hardware workgroup order (A/B of the XCD-contiguous deal)
         // timing ablations (attn_impl 210 + bits: 1 no DMA in the loop, 2 no barrier / wait in the loop, 4 no softmax VALU in the loop)
         case 11: return launch_w64<true, 1>(a, s);
         case 12: return launch_w64<true, 2>(a, s);

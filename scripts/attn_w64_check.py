@@ -30,8 +30,8 @@ for (B, H, Sq, Skv, spike) in [(1, 2, 256, 128, 0), (1, 2, 256, 64, 0), (1, 1, 2
         k[0, 100, 0] = q[0, 5, 0] * 20      # growth far beyond any fixed-reference range
     ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
     qd, kd, vd = q.cuda(), k.cuda(), v.cuda()
-    o0, l0 = run(0, qd, kd, vd)
-    o1, l1 = run(200, qd, kd, vd)
+    o0, l0 = run(99, qd, kd, vd)
+    o1, l1 = run(0, qd, kd, vd)
     e0 = (o0.float().cpu() - ref).abs()
     e1 = (o1.float().cpu() - ref).abs()
     d = (o1.float() - o0.float()).abs().max().item()
@@ -41,7 +41,7 @@ for (B, H, Sq, Skv, spike) in [(1, 2, 256, 128, 0), (1, 2, 256, 64, 0), (1, 1, 2
     print(f"B{B} H{H} Sq{Sq} Skv{Skv} spike{spike}: w64 max {e1.max().item():.3g} mean {e1.mean().item():.3g} | pp2 max {e0.max().item():.3g} mean {e0.mean().item():.3g} | "
           f"w64-pp2 max {d:.3g} lse diff {dl:.3g} {'ok' if good else 'FAIL'}", flush=True)
 # repeatability
-o_a, _ = run(200, qd, kd, vd); o_b, _ = run(200, qd, kd, vd)
+o_a, _ = run(0, qd, kd, vd); o_b, _ = run(0, qd, kd, vd)
 print("repeatable:", bool(torch.equal(o_a, o_b)))
 print("ALL OK" if ok else "SOME FAILED")
 # timing at the cfg2 shape
@@ -49,7 +49,7 @@ S, H, D = 32760, 12, 128
 q, k, v = (torch.randn(1, S, H, D, device="cuda").bfloat16() for _ in range(3))
 vt = ops.v_transpose(v); o = torch.empty_like(q)
 fl = 4.0 * S * S * H * D
-impls = [int(x) for x in sys.argv[1:]] or [0, 200, 201, 0, 200]
+impls = [int(x) for x in sys.argv[1:]] or [99, 0, 99, 0]
 res = {i: [] for i in impls}
 for r in range(5):
     for i in impls:

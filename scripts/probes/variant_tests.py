@@ -167,10 +167,11 @@ def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
     close(outs[0][0], _lin_ref(x, w, b), what=f"gemm_ph {Mb}x{N}x{K}")
 
 
-@pytest.mark.parametrize("impl", [0, 1, 2, 3])
+@pytest.mark.parametrize("impl", [0, 1, 2, 3, 99, 201])
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 700), (2, 3, 512, 130), (1, 1, 256, 64), (1, 2, 1030, 1999)])
 def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
-    """attn_impl 0/2/3 = 8-wave ping-pong kernel (three DMA placements), 1 = 4-wave kernel; ragged Sq / Skv tails, 1..32 KV tiles."""
+    """attn_impl 0 = attn_w64 (shipped), 201 = the same without its scheduling barriers, 99 = attn_pp2, 2 / 3 = attn_pp (64-key tiles, two
+    DMA placements), 1 = the 4-wave kernel; ragged Sq / Skv tails, 1..32 KV tiles."""
     tunables("attn_impl", impl)
     q, k, v = rnd((B, Sq, H, 128), 1), rnd((B, Skv, H, 128), 2), rnd((B, Skv, H, 128), 3)
     ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
@@ -179,7 +180,7 @@ def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
 
 
 def test_attn_pp2_schedules_are_bit_identical(ops, tunables):
-    """The schedule variants of the 128-key-tile kernel (attn_pp2.hip: attn_impl 0 = shipped one-barrier / leading-group in-stream DMA;
+    """The schedule variants of the 128-key-tile kernel (attn_pp2.hip: attn_impl 99 = its final one-barrier / leading-group in-stream DMA schedule;
     103 = round 1's two-barrier schedule; 111 = V^T pieces inside the trailing matrix segment; 105 / 107 = one barrier with the trailing /
     leading group issuing ahead of the segment) move DMA issue and barriers only: same arithmetic in the same order, so the outputs must
     be bit-identical — also with a late rescale spike and ragged tails, and across repeated launches (a slot reused too early or a
@@ -189,17 +190,22 @@ def test_attn_pp2_schedules_are_bit_identical(ops, tunables):
     k[0, 2500, 1] = q[0, 700, 1] * 6
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
     outs = {}
-    for impl in (0, 103, 105, 107, 111, 0):
+    for impl in (99, 103, 105, 107, 111, 99):
         tunables("attn_impl", impl)
         outs.setdefault(impl, []).append(ops.attn_dense(qd, kd, vd, layout="bshd").cpu())
     ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
-    _attn_check(outs[0][0], ref, "attn_pp2 shipped schedule")
+    _attn_check(outs[99][0], ref, "attn_pp2 final schedule")
     for impl, lst in outs.items():
         for o in lst:
-            assert torch.equal(o, outs[0][0]), f"attn_impl {impl} differs from the shipped schedule"
+            assert torch.equal(o, outs[99][0]), f"attn_impl {impl} differs from attn_pp2's final schedule"
+    # the shipped dense kernel (attn_w64: fixed softmax reference, different rounding points) agrees with it to rounding
+    tunables("attn_impl", 0)
+    o64 = ops.attn_dense(qd, kd, vd, layout="bshd").cpu()
+    _attn_check(o64, ref, "attn_w64 (shipped)")
+    assert (o64.float() - outs[99][0].float()).abs().max().item() < 2e-2
 
 
-@pytest.mark.parametrize("impl", [0, 2, 3])
+@pytest.mark.parametrize("impl", [0, 2, 3, 99])
 def test_attn_pp_rescale_branch_and_repeatability(ops, tunables, impl):
     """Spiked keys force the running-max rescale in late tiles of the ping-pong kernel; 3 launches must agree bit-for-bit
     (a race between the staggered wave groups or an early LDS read would show up as run-to-run differences)."""
