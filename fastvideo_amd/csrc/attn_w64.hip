@@ -253,6 +253,9 @@ struct W64 {
 #pragma unroll
         for (int i = 0; i < FD; ++i) fr[i] = frag_v(j, 4 * EVEN + (i >> 2), i & 3);
         float psA[2] = {0.f, 0.f}, psB[2] = {0.f, 0.f};
+        // pipeline prologue of the softmax: exponential of score 0, exponent of score 1
+        float p_nx = __builtin_amdgcn_exp2f(__builtin_fmaf(s[CUR][0][0][0], c2, -mc0));
+        float e_nx = __builtin_fmaf(s[CUR][0][0][1], c2, -mc0);
 #pragma unroll
         for (int c = 0; c < 64; ++c) {
             const int i = c >> 1;  // fragment: i < 16: V^T (k-step i>>2, d-block i&3); else K (d-step (i-16)>>1, key block (i-16)&1)
@@ -269,20 +272,31 @@ struct W64 {
                     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s[EVEN][1][kb]) : "v"(fr[i % FD]), "a"(qf[1][ks]));
                 }
             }
+            if (PIN) __builtin_amdgcn_sched_barrier(0);  // the MFMA FIRST: everything below runs in its shadow (hoisted above it, it would delay the issue)
             if (c & 1) {
                 const int nx = i + FD;
                 if (nx < 32) fr[i % FD] = nx < 16 ? frag_v(j, 4 * EVEN + (nx >> 2), nx & 3) : frag_k(j + 1, (nx - 16) >> 1, 2 * EVEN + ((nx - 16) & 1));
             }
             if (EVEN == 0 && (c & 3) == 1 && !(ABL & 1)) issue_piece(c >> 2, j);
-            if (!(ABL & 4)) {   // the softmax of score c of the lane's 64: q block c>>5, P fragment (c>>3)&3, value c&7
-                const int qb = c >> 5, kk = (c >> 3) & 3, jj = c & 7, r = (kk & 1) * 8 + jj;
-                const float sv = qb == 0 ? s[CUR][0][kk >> 1][r] : s[CUR][1][kk >> 1][r];
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sv, c2, qb == 0 ? -mc0 : -mc1));
-                if (qb == 0) psA[c & 1] += p; else psB[c & 1] += p;
-                pf[CUR][qb][kk][jj] = (bf16_t)p;
+            if (!(ABL & 4)) {
+                // the softmax, software-pipelined over the chunks so that the three VALU instructions of a chunk are INDEPENDENT (one wave per
+                // SIMD: nothing else hides the latency of fma -> exp -> add on one score): chunk c finishes score c (row sum, bf16 pack),
+                // takes the exponential of score c+1 and forms the exponent of score c+2.  Score x of the lane's 64: q block x>>5, P fragment
+                // (x>>3)&3, value x&7.
+                {
+                    const int qb = c >> 5, kk = (c >> 3) & 3, jj = c & 7;
+                    if (qb == 0) psA[c & 1] += p_nx; else psB[c & 1] += p_nx;
+                    pf[CUR][qb][kk][jj] = (bf16_t)p_nx;
+                    if (jj == 7) asm volatile("" : "+v"(pf[CUR][qb][kk]));
+                }
+                if (c + 1 < 64) p_nx = __builtin_amdgcn_exp2f(e_nx);
+                if (c + 2 < 64) {
+                    const int x = c + 2, qb = x >> 5, kk = (x >> 3) & 3, r = (kk & 1) * 8 + (x & 7);
+                    e_nx = __builtin_fmaf(qb == 0 ? s[CUR][0][kk >> 1][r] : s[CUR][1][kk >> 1][r], c2, qb == 0 ? -mc0 : -mc1);
+                }
                 // keep the chunk's work IN the chunk (a use here, before the scheduling barrier)
-                if (jj == 7) asm volatile("" : "+v"(pf[CUR][qb][kk]));
-                if (qb == 0) asm volatile("" : "+v"(psA[0]), "+v"(psA[1])); else asm volatile("" : "+v"(psB[0]), "+v"(psB[1]));
+                asm volatile("" : "+v"(p_nx), "+v"(e_nx));
+                if ((c >> 5) == 0) asm volatile("" : "+v"(psA[0]), "+v"(psA[1])); else asm volatile("" : "+v"(psB[0]), "+v"(psB[1]));
             }
             if (PIN) __builtin_amdgcn_sched_barrier(0);
         }
@@ -461,11 +475,12 @@ int launch_w64(const fvk_attn_args* a, hipStream_t s) {
 
 }  // namespace
 
-// variant (measurement build): 1 = phase 2 without the scheduling barriers (the compiler's own placement of the softmax around the MFMAs)
+// variant (measurement build): 2 = hardware workgroup order, 11.. = timing ablations.  (A variant WITHOUT the scheduling barriers was tried and
+// removed: free to move the softmax's reads of S next to the asm MFMAs that write it — whose latency the compiler does not know — it
+// produced wrong rows at some shapes.)
 int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s) {
 #if FVK_VARIANTS
     switch (variant) {
-        case 1: return launch_w64<false>(a, s);
         case 2: return launch_w64<true, 0, true>(a, s);  // hardware workgroup order (A/B of the XCD-contiguous deal)
         // timing ablations (attn_impl 210 + bits: 1 no DMA in the loop, 2 no barrier / wait in the loop, 4 no softmax VALU in the loop)
         case 11: return launch_w64<true, 1>(a, s);

@@ -167,10 +167,10 @@ def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
     close(outs[0][0], _lin_ref(x, w, b), what=f"gemm_ph {Mb}x{N}x{K}")
 
 
-@pytest.mark.parametrize("impl", [0, 1, 2, 3, 99, 201])
+@pytest.mark.parametrize("impl", [0, 1, 2, 3, 99, 202])
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 700), (2, 3, 512, 130), (1, 1, 256, 64), (1, 2, 1030, 1999)])
 def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
-    """attn_impl 0 = attn_w64 (shipped), 201 = the same without its scheduling barriers, 99 = attn_pp2, 2 / 3 = attn_pp (64-key tiles, two
+    """attn_impl 0 = attn_w64 (shipped), 202 = the same in hardware workgroup order, 99 = attn_pp2, 2 / 3 = attn_pp (64-key tiles, two
     DMA placements), 1 = the 4-wave kernel; ragged Sq / Skv tails, 1..32 KV tiles."""
     tunables("attn_impl", impl)
     q, k, v = rnd((B, Sq, H, 128), 1), rnd((B, Skv, H, 128), 2), rnd((B, Skv, H, 128), 3)
