@@ -243,7 +243,7 @@ struct W64 {
     // ABL (measurement build; results are wrong, timing is what is measured): bit 0 no DMA pieces in the loop, bit 2 no softmax VALU in the loop
     template <int EVEN, bool MASK, bool PIN, int ABL = 0>
     __device__ __forceinline__ void iter(int j, int valid, int hi) {
-        constexpr int CUR = 1 - EVEN, FD = 4;
+        constexpr int CUR = 1 - EVEN, FD = 6;
         if (MASK) {
             fence_s<CUR>();  // the previous iteration's last Q·K^T MFMAs wrote these registers a few instructions ago
             mask_keys<CUR>(valid, hi);
