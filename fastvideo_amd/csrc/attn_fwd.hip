@@ -22,6 +22,7 @@
 
 int fvk_attn_pp_launch(const fvk_attn_args* a, int variant, hipStream_t s);  // attn_pp.hip
 int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s); // attn_w64.hip
+int fvk_attn_w64_split_launch(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, hipStream_t s);
 int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s);   // attn_pp2.hip
 struct fvk_pp2_lists {  // attn_pp2.hip: 256-row workgroups over shared KV block lists
     const int32_t* q2k_idx; const int32_t* q2k_num; const int32_t* kv_block_sizes; const int32_t* q_rows_valid;
@@ -531,6 +532,16 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
     }
     ModeArgs ma{};
     return launch<4, MODE_DENSE>(a, ma, (hipStream_t)stream);
+}
+
+extern "C" int fvk_attn_dense_split_bf16(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, void* stream) {
+    int rc = check_common(a, "fvk_attn_dense_split_bf16");
+    if (rc) return rc;
+    FVK_CHECK((a->qk_dim == 0 || a->qk_dim == 128) && a->Sq >= 256, FVK_ERR_ARG,
+              "fvk_attn_dense_split_bf16: head_dim 128 and Sq >= 256 only (Sq=%d, qk_dim=%d)", a->Sq, a->qk_dim);
+    FVK_CHECK(n_split >= 2 && n_split <= 64 && o_part && lse_part, FVK_ERR_ARG, "fvk_attn_dense_split_bf16: n_split=%d (2..64) / null workspace", n_split);
+    FVK_CHECK((long)((a->Sq + 255) / 256) * a->H * a->B * n_split < 0x7fffffffL, FVK_ERR_ARG, "fvk_attn_dense_split_bf16: grid too large");
+    return fvk_attn_w64_split_launch(a, n_split, o_part, lse_part, (hipStream_t)stream);
 }
 
 extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,

@@ -307,8 +307,12 @@ struct W64 {
 #undef FVK_MFMA1
 };
 
-template <bool PIN, int ABL = 0, bool PLAIN_IDS = false>
-__global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
+// SPLIT (fvk_attn_dense_split_bf16): the key axis is cut into `n_split` runs of whole 128-key stages and every (query block, head, batch,
+// run) is its own workgroup — for grids too small to fill 256 CUs (sequence-parallel ranks: 192 query-block workgroups at SP = 8).  A
+// run's result is written UN-merged: normalised O as fp32 rows into o_part[run][b][h][row][128] and its base-2 LSE into
+// lse_part[run][b][h][row]; attn_merge_splits_kernel combines the runs (a run with no keys writes LSE = -inf and is ignored).
+template <bool PIN, int ABL = 0, bool PLAIN_IDS = false, bool SPLIT = false>
+__global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n_split, float* o_part, float* lse_part) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BMQ = 256;
@@ -323,14 +327,24 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
     const int bid = PLAIN_IDS ? (int)blockIdx.x : xcd * xq + (xcd < xr ? xcd : xr) + (int)(blockIdx.x >> 3);
     const int q_first = (bid % nqb) * BMQ;
     const int h = (bid / nqb) % a.H;
-    const int b = bid / (nqb * a.H);
-    const int n = (a.Skv + KT - 1) / KT;          // stages
-    const int v_last = a.Skv - (n - 1) * KT;      // valid keys of the last stage, 1..128
+    const int b = (bid / (nqb * a.H)) % a.B;
+    const int run = SPLIT ? bid / (nqb * a.H * a.B) : 0;
+    // this workgroup's keys: stages [st0, st1) of the (b, h) slice; Skv_w = its key count (the last stage of the last run may be ragged)
+    const int n_all = (a.Skv + KT - 1) / KT;
+    const int st0 = SPLIT ? (int)((long)n_all * run / n_split) : 0, st1 = SPLIT ? (int)((long)n_all * (run + 1) / n_split) : n_all;
+    const int n = st1 - st0;                      // stages of this workgroup (SPLIT: may be 0 when there are fewer stages than runs)
+    const int Skv_w = (st1 * KT < a.Skv ? st1 * KT : a.Skv) - st0 * KT;
+    const int v_last = Skv_w - (n - 1) * KT;      // valid keys of the last stage, 1..128
 
     const bf16_t* qp = (const bf16_t*)a.q + (long)b * a.q_bs + (long)h * a.q_hs;
-    const bf16_t* kp = (const bf16_t*)a.k + (long)b * a.k_bs + (long)h * a.k_hs;
-    const bf16_t* vtp = (const bf16_t*)a.vt + ((long)b * a.H + h) * 128L * a.Skv_pad;
+    const bf16_t* kp = (const bf16_t*)a.k + (long)b * a.k_bs + (long)h * a.k_hs + (long)st0 * KT * a.k_ss;
+    const bf16_t* vtp = (const bf16_t*)a.vt + ((long)b * a.H + h) * 128L * a.Skv_pad + (long)st0 * KT;
     bf16_t* op = (bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs;
+    if (SPLIT && n <= 0) {  // an empty run: LSE = -inf (weight 0 in the merge); workgroup-uniform
+        const int r = q_first + tid;
+        if (r < a.Sq) lse_part[(((long)run * a.B + b) * a.H + h) * a.Sq + r] = -INFINITY;
+        return;
+    }
 
     W64 w;
     w.smem = smem;
@@ -354,8 +368,8 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
     }
     // LDS image of both tiles: row r, 16-B chunk c at r*256 + ((c ^ (r&15)) << 4); the hardware writes lane-linearly, so each lane fetches
     // the SOURCE chunk that belongs at its linear position.  Key rows >= Skv are outside the descriptor's range -> zeros.
-    w.k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (unsigned)((((long)a.Skv - 1) * a.k_ss + 128) * 2), 0x00020000);
-    w.v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vtp, 0, (unsigned)(256L * a.Skv_pad), 0x00020000);
+    w.k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (unsigned)((((long)Skv_w - 1) * a.k_ss + 128) * 2), 0x00020000);
+    w.v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vtp, 0, (unsigned)(256L * a.Skv_pad - 2L * st0 * KT), 0x00020000);
     const int r0 = 4 * wave + (lane >> 4);
     const unsigned sw0 = (unsigned)(((lane & 15) ^ (r0 & 15)) << 4);
     w.kv0 = (unsigned)(((long)r0 * a.k_ss) * 2) + sw0;
@@ -445,13 +459,24 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a) {
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;                                                          \
         if (!(ONLY_REDO)) redo[qb] = !(l_tot < L_LIMIT);                                                             \
         if (q_ok[qb] && (!(ONLY_REDO) || redo[qb])) {                                                                \
-            bf16_t* orow = op + (long)qrow[qb] * a.o_ss;                                                             \
-            _Pragma("unroll") for (int d = 0; d < 4; ++d) _Pragma("unroll") for (int g = 0; g < 4; ++g) {           \
-                bf16x4 v4;                                                                                           \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(w.o[qb][d][g * 4 + e] * inv);        \
-                *reinterpret_cast<bf16x4*>(orow + d * 32 + g * 8 + hi * 4) = v4;                                     \
+            if (SPLIT) {                                                                                             \
+                const long prow = (((long)run * a.B + b) * a.H + h) * a.Sq + qrow[qb];                               \
+                float* orow = o_part + prow * 128;                                                                   \
+                _Pragma("unroll") for (int d = 0; d < 4; ++d) _Pragma("unroll") for (int g = 0; g < 4; ++g) {       \
+                    f32x4 v4;                                                                                        \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) v4[e] = w.o[qb][d][g * 4 + e] * inv;              \
+                    *reinterpret_cast<f32x4*>(orow + d * 32 + g * 8 + hi * 4) = v4;                                  \
+                }                                                                                                    \
+                if (hi == 0) lse_part[prow] = w.m_run[qb] * w.c2 + log2f(l_tot);                                     \
+            } else {                                                                                                 \
+                bf16_t* orow = op + (long)qrow[qb] * a.o_ss;                                                         \
+                _Pragma("unroll") for (int d = 0; d < 4; ++d) _Pragma("unroll") for (int g = 0; g < 4; ++g) {       \
+                    bf16x4 v4;                                                                                       \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(w.o[qb][d][g * 4 + e] * inv);    \
+                    *reinterpret_cast<bf16x4*>(orow + d * 32 + g * 8 + hi * 4) = v4;                                 \
+                }                                                                                                    \
+                if (a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow[qb]] = w.m_run[qb] * w.c2 + log2f(l_tot); \
             }                                                                                                        \
-            if (a.lse && hi == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow[qb]] = w.m_run[qb] * w.c2 + log2f(l_tot);  \
         }                                                                                                            \
     }
     FVK_STORE_ROWS(false)
@@ -468,9 +493,38 @@ int launch_w64(const fvk_attn_args* a, hipStream_t s) {
     static FvkLdsConfigured configured;
     if (int rc = fvk_config_lds(configured, (const void*)attn_w64_kernel<PIN, ABL, PLAIN_IDS>, LDS_BYTES, "fvk_attn_dense_bf16 (w64)")) return rc;
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
-    hipLaunchKernelGGL((attn_w64_kernel<PIN, ABL, PLAIN_IDS>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a);
+    hipLaunchKernelGGL((attn_w64_kernel<PIN, ABL, PLAIN_IDS>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, 1, (float*)nullptr, (float*)nullptr);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
+}
+
+
+// out[b, row, h, :] = sum_r 2^(lse_r - max) * o_part[r] / sum_r 2^(lse_r - max): one wave per (b, h, row), 2 columns per lane; HBM-bound
+// (reads n_split * 512 B, writes 256 B per row).
+__global__ __launch_bounds__(256) void attn_merge_splits_kernel(fvk_attn_args a, int n_split, const float* o_part, const float* lse_part) {
+    const long row_id = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B * H * Sq
+    const long rows = (long)a.B * a.H * a.Sq;
+    if (row_id >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const int r = (int)(row_id % a.Sq), h = (int)((row_id / a.Sq) % a.H), b = (int)(row_id / ((long)a.Sq * a.H));
+    float mx = -INFINITY;
+    for (int s_ = 0; s_ < n_split; ++s_) mx = fmaxf(mx, lse_part[(long)s_ * rows + row_id]);
+    float acc0 = 0.f, acc1 = 0.f, wsum = 0.f;
+    for (int s_ = 0; s_ < n_split; ++s_) {
+        const float wgt = exp2f(lse_part[(long)s_ * rows + row_id] - mx);  // an empty run: 2^(-inf) = 0
+        if (wgt > 0.f) {
+            const float2 v = *reinterpret_cast<const float2*>(o_part + ((long)s_ * rows + row_id) * 128 + lane * 2);
+            acc0 += wgt * v.x;
+            acc1 += wgt * v.y;
+            wsum += wgt;
+        }
+    }
+    const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+    bf16x2 o2;
+    o2[0] = (bf16_t)(acc0 * inv);
+    o2[1] = (bf16_t)(acc1 * inv);
+    *reinterpret_cast<bf16x2*>((bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs + (long)r * a.o_ss + lane * 2) = o2;
+    if (a.lse && lane == 0) a.lse[row_id] = mx + log2f(wsum);
 }
 
 }  // namespace
@@ -493,4 +547,17 @@ int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s) {
 #endif
     (void)variant;
     return launch_w64<true>(a, s);
+}
+
+// split-KV form (called by fvk_attn_dense_split_bf16, attn_fwd.hip, after its argument checks)
+int fvk_attn_w64_split_launch(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, hipStream_t s) {
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_w64_kernel<true, 0, false, true>, LDS_BYTES, "fvk_attn_dense_split_bf16")) return rc;
+    const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B * n_split;
+    hipLaunchKernelGGL((attn_w64_kernel<true, 0, false, true>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, n_split, o_part, lse_part);
+    FVK_LAUNCH_CHECK();
+    const long rows = (long)a->B * a->H * a->Sq;
+    hipLaunchKernelGGL(attn_merge_splits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a, n_split, (const float*)o_part, (const float*)lse_part);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
 }

@@ -329,9 +329,30 @@ def _vt_of(v, layout):
     return v_transpose(v if layout == "bshd" else v.transpose(1, 2))
 
 
-def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, return_lse=False):
+N_CUS = 256  # MI355X
+
+
+def attn_key_splits(n_query_blocks: int, n_stages: int) -> int:
+    """How many key runs fvk_attn_dense_split_bf16 should cut: 1 (no split) when the 256-row workgroups already fill the chip; otherwise the
+    smallest run count (<= 8, <= the 128-key stages) whose grid fills whole rounds of the 256 CUs best.  192 workgroups (SP = 8 on 12 heads)
+    -> 4 runs = 768 = three full rounds; 384 (SP = 4) -> 2."""
+    eff = lambda wg: wg / (N_CUS * -(-wg // N_CUS))
+    best, best_eff = 1, eff(n_query_blocks)
+    if best_eff >= 0.9 or n_stages < 16:
+        return 1
+    for s in range(2, 9):
+        if s * 4 > n_stages:
+            break
+        e = eff(n_query_blocks * s)
+        if e > best_eff + 0.04:
+            best, best_eff = s, e
+    return best
+
+
+def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, return_lse=False, key_splits=None):
     """Dense non-causal attention.  Pass v (same layout as k) or a precomputed vt = v_transpose(v).
-    return_lse: also the base-2 log-sum-exp of the scaled scores per query row, fp32 [B, H, Sq] (full-length kernels only: Sq >= 256)."""
+    return_lse: also the base-2 log-sum-exp of the scaled scores per query row, fp32 [B, H, Sq] (full-length kernels only: Sq >= 256).
+    key_splits: None = automatic (attn_key_splits: split-KV + merge for grids that do not fill the chip), 1 = never, n = that many runs."""
     scale = q.shape[-1]**-0.5 if scale is None else scale
     if vt is None:
         vt = _vt_of(v, layout)
@@ -342,7 +363,17 @@ def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, retur
         Sq = q.shape[1] if layout == "bshd" else q.shape[2]
         lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     a = _attn_args(q, k, vt, o, scale, layout, lse)
-    _lib.call("fvk_attn_dense_bf16", C.byref(a), _stream())
+    if key_splits is None:
+        key_splits = 1
+        if a.Sq >= 256 and q.shape[-1] == 128:
+            key_splits = attn_key_splits(-(-a.Sq // 256) * a.H * a.B, -(-a.Skv // 128))
+    if key_splits > 1:
+        rows = a.B * a.H * a.Sq
+        o_part = torch.empty((key_splits, rows, 128), dtype=torch.float32, device=q.device)
+        lse_part = torch.empty((key_splits, rows), dtype=torch.float32, device=q.device)
+        _lib.call("fvk_attn_dense_split_bf16", C.byref(a), int(key_splits), _p(o_part), _p(lse_part), _stream())
+    else:
+        _lib.call("fvk_attn_dense_bf16", C.byref(a), _stream())
     return (o, lse) if return_lse else o
 
 

@@ -175,6 +175,14 @@ typedef struct {
 
 /* dense: ref fastvideo/attention/backends/sdpa.py:122-147 / flash_attn.py:247-345 (the path replaced). */
 int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream);
+/* The same attention with the KEY axis cut into n_split runs of whole 128-key stages, each (query block, head, batch, run) its own workgroup,
+ * and a merge pass: for grids too small to fill the 256 CUs — the per-rank shapes of sequence parallelism (SP = 8 on Wan2.1-1.3B: 3 heads x
+ * 64 query blocks = 192 workgroups of 256 rows; 4 runs make 768 = three full rounds).  Workspace (device, overwritten): o_part fp32
+ * [n_split, B, H, Sq, 128] (each run's normalised output), lse_part fp32 [n_split, B, H, Sq] (its base-2 log-sum-exp); the merge is
+ * o = sum_r 2^(lse_r - max) o_r / sum_r 2^(lse_r - max), a->lse (optional) receives the merged LSE.  Sq >= 256, head_dim 128.
+ * (No reference counterpart: flash-attn's split-KV decode path is the same idea; fastvideo/attention/backends/flash_attn.py calls it through
+ * flash_attn_func.) */
+int fvk_attn_dense_split_bf16(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, void* stream);
 
 /* block-sparse (VSA sparse branch; sliding-tile windows on arbitrary canvases): query block i (q_block = 64 or 128 rows) attends KV
  * blocks q2k_idx[b,h,i,0..q2k_num[b,h,i]) (64 keys each, of which the first kv_block_sizes[j] are valid).

@@ -50,13 +50,16 @@ for P in (1, 2, 4, 8):
     r["norm_rope(+pack)"] = t(lambda: ops.rmsnorm_rope([qkv[:, :d], qkv[:, d:2 * d]], [nw, nw], cos, sin, head_dim=D, seq_len=S))
     r["v_transpose"] = t(lambda: ops.v_transpose(vall))
     vt = ops.v_transpose(vall)
-    r["self-attention"] = t(lambda: ops.attn_dense(qb, kall[:, :S], vt=vt, layout="bshd"))
+    r["self-attention"] = t(lambda: ops.attn_dense(qb, kall[:, :S], vt=vt, layout="bshd"))   # automatic key split for small grids
+    unsplit = t(lambda: ops.attn_dense(qb, kall[:, :S], vt=vt, layout="bshd", key_splits=1))
     r["gemm o / cq / co (x3)"] = 3 * t(lambda: ops.gemm(x, W["o"], b["o"]))
     r["cross-attention"] = t(lambda: ops.attn_dense(cq, ck, cv, layout="bshd"))
     r["gemm ffn-in + gelu"] = t(lambda: ops.gemm(x, W["f1"], b["f1"], epilogue=ops.EPI_GELU_TANH))
     r["gemm ffn-out + gated residual"] = t(lambda: ops.gemm(ff, W["f2"], b["f2"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=mod))
     tot = sum(r.values())
-    out[f"P{P}"] = dict(layout=f"G{G}xU{U}", Sl=Sl, attn_workgroups=((G * Sl + 255) // 256) * hg, layer_us=round(tot, 1), forward_ms_30_layers=round(tot * 30 / 1e3, 2),
+    nqb = ((G * Sl + 255) // 256) * hg
+    out[f"P{P}"] = dict(layout=f"G{G}xU{U}", Sl=Sl, attn_workgroups=nqb, attn_key_splits=ops.attn_key_splits(nqb, (S + 127) // 128),
+                        self_attention_unsplit_us=round(unsplit, 1), layer_us=round(tot, 1), forward_ms_30_layers=round(tot * 30 / 1e3, 2),
                         per_op_us={k_: round(v_, 1) for k_, v_ in r.items()})
 base = out["P1"]["layer_us"]
 for P in (2, 4, 8):

@@ -62,6 +62,19 @@ def test_argument_checks_of_the_newer_entries(lib):
         lib.call("fvk_vsa_combine_scatter_bf16", p, p, None, p, None, 1, 64, 1, 128, 64, 0, 128, 128, 0, 128, 128, 0, 128, 128, None)
     with pytest.raises(RuntimeError, match="strides must keep 16-byte alignment"):
         lib.call("fvk_vsa_combine_scatter_bf16", p, p, None, p, p, 1, 64, 1, 128, 64, 0, 128, 128, 0, 130, 128, 0, 128, 128, None)
+    # round-3 entries: split-KV attention (workspace and run count checked before any launch), 4-slot exchange packing
+    from fastvideo_amd._lib import AttnArgs
+    aa = AttnArgs()
+    aa.q = aa.k = aa.vt = aa.o = p.value
+    aa.B, aa.H, aa.Sq, aa.Skv, aa.Skv_pad = 1, 1, 256, 256, 256
+    aa.q_ss = aa.k_ss = aa.o_ss = 128
+    aa.scale = 0.1
+    with pytest.raises(RuntimeError, match="n_split"):
+        lib.call("fvk_attn_dense_split_bf16", C.byref(aa), 1, p, p, None)
+    with pytest.raises(RuntimeError, match="null workspace"):
+        lib.call("fvk_attn_dense_split_bf16", C.byref(aa), 4, None, p, None)
+    with pytest.raises(RuntimeError, match="null gate"):
+        lib.call("fvk_qkvg_norm_rope_pack_bf16", p, p, p, None, None, None, None, None, p, 4, 128, 128, 4, 0, 128, 1, 1, 1e-6, None)
     with pytest.raises(RuntimeError, match="unknown tunable"):
         lib.call("fvk_set_tunable", b"no_such_knob", 1)
     lib.call("fvk_set_tunable", b"vsa_impl", 0)

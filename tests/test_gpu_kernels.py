@@ -238,6 +238,26 @@ def test_attn_dense_softmax_rescale_branch(ops):
     _attn_check(out, ref, "rescale branch")
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv,splits", [(1, 3, 512, 4096, 4), (2, 2, 300, 2500, 3), (1, 1, 256, 1000, 8), (1, 2, 1030, 5000, 2), (1, 2, 256, 300, 5)])
+def test_attn_dense_key_splits(ops, B, H, Sq, Skv, splits):
+    """fvk_attn_dense_split_bf16: the key axis cut into runs of whole 128-key stages (one workgroup per run) + the LSE-weighted merge — the form
+    the small per-rank grids of sequence parallelism take.  Against the fp32 reference and the un-split kernel (same tolerance: the merge
+    adds one fp32 rescale per run), with ragged lengths, more runs than stages (empty runs), a spiked key in one run (that run's exact
+    pass) and the merged LSE."""
+    q, k, v = rnd((B, Sq, H, 128), 1), rnd((B, Skv, H, 128), 2), rnd((B, Skv, H, 128), 3)
+    k[0, Skv - 7, 0] = q[0, 5, 0] * 6   # growth of ~2^98 over the first sub-tile's maximum, in the last run
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o1, l1 = ops.attn_dense(qd, kd, vd, layout="bshd", return_lse=True, key_splits=1)
+    os_, ls = ops.attn_dense(qd, kd, vd, layout="bshd", return_lse=True, key_splits=splits)
+    _attn_check(os_, ref, f"split-KV x{splits} {B},{H},{Sq},{Skv}")
+    assert (os_.float() - o1.float()).abs().max().item() < 4e-2   # both are within the attention bound of the reference
+    assert torch.isfinite(ls).all() and (ls - l1).abs().max().item() < 1e-3
+    # the automatic choice leaves a grid that fills the chip alone and cuts one that does not
+    assert ops.attn_key_splits(1536, 256) == 1 and ops.attn_key_splits(192, 256) == 4 and ops.attn_key_splits(384, 256) == 2
+    assert ops.attn_key_splits(192, 8) == 1   # too few stages to be worth a merge pass
+
+
 def test_attn_block_sparse(ops):
     B, H, nq, nk = 1, 2, 5, 7
     q, k, v = rnd((B, H, nq * 64, 128), 1), rnd((B, H, nk * 64, 128), 2), rnd((B, H, nk * 64, 128), 3)
