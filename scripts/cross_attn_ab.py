@@ -1,11 +1,11 @@
-"""Cross-attention shape (Sq = 32 760 queries, 512 text keys, 12 heads): 8-wave 256-row kernel (attn_impl 0) vs 4-wave 128-row kernel (1)."""
+"""Cross-attention shape (Sq = 32 760 queries, 512 text keys, 12 heads): 8-wave 256-row kernel attn_w64 (attn_impl 0), attn_pp2 (99), 4-wave 128-row kernel (1); L = CROSS_L keys."""
 import os as _os
 _os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fastvideo_amd import ops
-S, L, H, D = 32760, 512, 12, 128
+S, L, H, D = 32760, int(os.environ.get("CROSS_L", "512")), 12, 128
 g = torch.Generator(device="cuda").manual_seed(0)
 q = torch.randn((1, S, H, D), generator=g, device="cuda").bfloat16()
 k, v = (torch.randn((1, L, H, D), generator=g, device="cuda").bfloat16() for _ in range(2))
@@ -13,7 +13,7 @@ vt = ops.v_transpose(v); o = torch.empty_like(q)
 fl = 4.0 * S * L * H * D
 res = {}
 for r in range(5):
-    for i in (0, 1):
+    for i in (0, 99, 1):
         ops.set_tunable("attn_impl", i)
         ops.attn_dense(q, k, vt=vt, out=o); torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
