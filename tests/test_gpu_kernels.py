@@ -238,6 +238,27 @@ def test_attn_dense_softmax_rescale_branch(ops):
     _attn_check(out, ref, "rescale branch")
 
 
+@pytest.mark.parametrize("B,H,Sq,Skv,spike", [(1, 2, 700, 3100, 0), (2, 3, 512, 3073, 0), (1, 1, 300, 4000, 1), (1, 2, 1030, 3200, 2), (1, 12, 256, 8192, 0)])
+def test_attn_dense_long_keys_w64(ops, B, H, Sq, Skv, spike):
+    """Key axes of 3072 and more take attn_w64 (4 waves x 64 rows, fixed softmax reference): ragged Sq / Skv tails (masked last stage, one
+    valid key in the last stage), odd stage counts, a spiked key far beyond the first sub-tile's maximum (growth ~2^98: the row's exact
+    recompute) and one beyond any fp32 range (x20: every row of that head), repeatability, and the LSE."""
+    q, k, v = rnd((B, Sq, H, 128), Sq), rnd((B, Skv, H, 128), Skv), rnd((B, Skv, H, 128), 3)
+    if spike >= 1:
+        k[0, Skv - 100, 0] = q[0, 7, 0] * 6
+    if spike == 2:
+        k[0, 1500, 1] = q[0, 300, 1] * 20
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse = ops.attn_dense(qd, kd, vd, layout="bshd", return_lse=True, key_splits=1)
+    _attn_check(o, ref, f"attn_w64 {B},{H},{Sq},{Skv} spike {spike}")
+    s2 = (q.float().transpose(1, 2) @ k.float().transpose(1, 2).transpose(-1, -2)) * (128**-0.5 * 1.4426950408889634)
+    lse_ref = torch.logsumexp(s2 * 0.6931471805599453, -1) * 1.4426950408889634
+    assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
+    o2 = ops.attn_dense(qd, kd, vd, layout="bshd", key_splits=1)
+    assert torch.equal(o, o2)
+
+
 @pytest.mark.parametrize("B,H,Sq,Skv,splits", [(1, 3, 512, 4096, 4), (2, 2, 300, 2500, 3), (1, 1, 256, 1000, 8), (1, 2, 1030, 5000, 2), (1, 2, 256, 300, 5)])
 def test_attn_dense_key_splits(ops, B, H, Sq, Skv, splits):
     """fvk_attn_dense_split_bf16: the key axis cut into runs of whole 128-key stages (one workgroup per run) + the LSE-weighted merge — the form
