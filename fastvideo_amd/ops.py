@@ -333,15 +333,17 @@ N_CUS = 256  # MI355X
 
 
 def attn_key_splits(n_query_blocks: int, n_stages: int) -> int:
-    """How many key runs fvk_attn_dense_split_bf16 should cut: 1 (no split) when the 256-row workgroups already fill the chip; otherwise the
-    smallest run count (<= 8, <= the 128-key stages) whose grid fills whole rounds of the 256 CUs best.  192 workgroups (SP = 8 on 12 heads)
-    -> 4 runs = 768 = three full rounds; 384 (SP = 4) -> 2."""
+    """How many key runs fvk_attn_dense_split_bf16 should cut: 1 (no split) unless the 256-row workgroups leave more than a fifth of the
+    last round of 256 CUs empty AND every run keeps at least 32 stages (4096 keys) — a partly filled chip is clock-compensated (the power
+    the idle CUs do not draw goes into the busy ones' clock), so splitting pays only for clearly under-filled grids with long key axes:
+    measured +9 % at 384 workgroups (SP = 4 on 12 heads -> 2 runs), +1.3 % at 192 (SP = 8 -> 4 runs), and a LOSS at 432 workgroups x 72
+    stages (the 9x64x64 plumbing latent: 4 runs cost 12 % of the forward in merge traffic and per-run prologues)."""
     eff = lambda wg: wg / (N_CUS * -(-wg // N_CUS))
     best, best_eff = 1, eff(n_query_blocks)
-    if best_eff >= 0.9 or n_stages < 16:
+    if best_eff >= 0.8:
         return 1
     for s in range(2, 9):
-        if s * 4 > n_stages:
+        if s * 32 > n_stages:
             break
         e = eff(n_query_blocks * s)
         if e > best_eff + 0.04:

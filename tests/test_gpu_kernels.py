@@ -276,7 +276,7 @@ def test_attn_dense_key_splits(ops, B, H, Sq, Skv, splits):
     assert torch.isfinite(ls).all() and (ls - l1).abs().max().item() < 1e-3
     # the automatic choice leaves a grid that fills the chip alone and cuts one that does not
     assert ops.attn_key_splits(1536, 256) == 1 and ops.attn_key_splits(192, 256) == 4 and ops.attn_key_splits(384, 256) == 2
-    assert ops.attn_key_splits(192, 8) == 1   # too few stages to be worth a merge pass
+    assert ops.attn_key_splits(192, 8) == 1 and ops.attn_key_splits(432, 72) == 1   # too few stages / a grid that is full enough
 
 
 def test_attn_block_sparse(ops):
