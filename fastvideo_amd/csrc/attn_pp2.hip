@@ -16,6 +16,7 @@
 //   * The matrix segment is one software-pipelined fragment stream: each ds_read_b128 is issued 6 MFMAs ahead of its use
 //     (sched_group_barrier pins the interleave; left alone hipcc emits read-pair / wait / MFMA-pair).
 #include "fvk_common.h"
+#include "attn_lists.h"
 
 namespace {
 
@@ -29,12 +30,6 @@ constexpr int LDS_BYTES = RING * (K_TILE + V_TILE);  // 131 072
 }  // namespace
 // LIST mode (fvk_attn_tile_lists_bf16, attn_fwd.hip): every `q_stride` consecutive query rows share ONE list of 64-key KV blocks (the
 // sliding-tile window of their tile); a workgroup owns 256 of those rows and walks the list two blocks (= one 128-key tile) per step.
-struct fvk_pp2_lists {
-    const int32_t* q2k_idx; const int32_t* q2k_num; const int32_t* kv_block_sizes; const int32_t* q_rows_valid;
-    int max_kv, n_lists, q_stride, q_sub;  // q_sub = 256-row workgroups per list
-    const int32_t* o_rows;                 // optional [Sq]: query row r's output goes to row o_rows[r] of o (negative: dropped)
-    int plain_ids;                         // measurement: 1 = hardware workgroup order (no XCD-contiguous deal)
-};
 namespace {
 
 __device__ __forceinline__ float xhalf_max(float v) {

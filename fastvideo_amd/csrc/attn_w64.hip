@@ -31,6 +31,7 @@
 // Same operand orientation as the other kernels (S^T = K·Q^T: a softmax row is lane-local; O^T = V^T·P^T with P^T taken from the packed
 // S^T registers), same V^T input layout (fvk_v_transpose_bf16).
 #include "fvk_common.h"
+#include "attn_lists.h"
 
 namespace {
 
@@ -67,12 +68,33 @@ struct W64 {
     unsigned kv0, vv0, k_pstride, v_pstride, k_tile_bytes;
     int pdst, n;
     unsigned char* smem;
+    // LIST mode (fvk_attn_tile_lists_bf16): the workgroup's 64-key KV blocks, packed in LDS behind the ring as id | valid keys << 24, two per
+    // stage (an absent second block re-reads the first with 0 valid keys).  Sub-tile t IS list entry t.
+    const int32_t* lst;
+    unsigned k_blk_bytes, vvl;  // bytes between 64-key blocks of K; this lane's V^T source offset without the block part
+    bool vhalf;                 // this lane's 16-B chunk of a V^T piece row belongs to the stage's SECOND block
+    unsigned kblk0, kblk1, vvs; // this pair's set: K byte offsets of the two blocks of stage j+2 (SGPR), V^T lane offset of stage j+1
+    __device__ __forceinline__ int entry(int t) const { return lst[t < 2 * n ? t : 0]; }  // stages past the end re-read block 0 (harmless)
+    // the DMA operands of pair j: K(j+2) from entries 2j+4, 2j+5; V^T(j+1) from entries 2j+2, 2j+3
+    __device__ __forceinline__ void set_pair(int eK0, int eK1, int eV0, int eV1) {
+        kblk0 = (unsigned)(eK0 & 0xffffff) * k_blk_bytes;
+        kblk1 = (unsigned)(eK1 & 0xffffff) * k_blk_bytes;
+        vvs = vvl + (unsigned)((vhalf ? eV1 : eV0) & 0xffffff) * 128u;
+    }
 
     // piece I (0..7 = K(j+2), 8..15 = V^T(j+1)) of the set issued behind the barrier of pair j; stages past the end re-read stage 0 (harmless).
     // The per-piece and per-stage parts of the source address are wave-uniform: they ride in the SGPR offset, the lane part (kv0 / vv0) is ONE
     // arch VGPR per tensor for all pieces.
+    template <bool LIST>
     __device__ __forceinline__ void issue_piece(int I, int j) const {  // I is a compile-time constant after unrolling
-        if (I < 8) {
+        if (LIST) {  // K pieces 0-3 / 4-7 come from the stage's first / second block; a V^T piece row holds 64 keys of each (per-lane block)
+            if (I < 8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + (j & 1) * K_TILE + pdst + I * 4096), 16, kv0,
+                                                         __builtin_amdgcn_readfirstlane((I & 3) * k_pstride + (I < 4 ? kblk0 : kblk1)), 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + ((j + 1) & 1) * V_TILE + pdst + (I - 8) * 4096), 16, vvs,
+                                                         __builtin_amdgcn_readfirstlane((I - 8) * v_pstride), 0, 0);
+        } else if (I < 8) {
             const int t_ = j + 2 < n ? j + 2 : 0;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + (j & 1) * K_TILE + pdst + I * 4096), 16, kv0,
                                                      __builtin_amdgcn_readfirstlane(I * k_pstride + (unsigned)t_ * k_tile_bytes), 0, 0);
@@ -194,6 +216,7 @@ struct W64 {
     // The exact pass (rare: only when a row's fixed-reference sum left the safe range): plain online softmax over all keys with a running
     // max and O rescaled by the VALU, one stage at a time through ring slot 0 (load, wait, barrier, compute — no overlap).  Every wave of
     // the workgroup takes part.  Leaves o, m_run, l_run as the pipelined pass would have.
+    template <bool LIST>
     __device__ __forceinline__ void exact_pass(int v_last, int hi) {
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
@@ -209,12 +232,25 @@ struct W64 {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();  // every wave has finished reading slot 0
             __builtin_amdgcn_sched_barrier(0);
+            int e0 = 0, e1 = 0;
+            if (LIST) {
+                e0 = __builtin_amdgcn_readfirstlane(entry(2 * st));
+                e1 = __builtin_amdgcn_readfirstlane(entry(2 * st + 1));
+                set_pair(e0, e1, e0, e1);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + pdst + i * 4096), 16, kv0,
-                                                         __builtin_amdgcn_readfirstlane(i * k_pstride + (unsigned)st * k_tile_bytes), 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + pdst + i * 4096), 16, vv0,
-                                                         __builtin_amdgcn_readfirstlane(i * v_pstride + st * (KT * 2)), 0, 0);
+                if (LIST) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + pdst + i * 4096), 16, kv0,
+                                                             __builtin_amdgcn_readfirstlane((i & 3) * k_pstride + (i < 4 ? kblk0 : kblk1)), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + pdst + i * 4096), 16, vvs,
+                                                             __builtin_amdgcn_readfirstlane(i * v_pstride), 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + pdst + i * 4096), 16, kv0,
+                                                             __builtin_amdgcn_readfirstlane(i * k_pstride + (unsigned)st * k_tile_bytes), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + V_BASE + pdst + i * 4096), 16, vv0,
+                                                             __builtin_amdgcn_readfirstlane(i * v_pstride + st * (KT * 2)), 0, 0);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -223,9 +259,10 @@ struct W64 {
             const int valid = st == n - 1 ? v_last : KT;
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {  // (fully unrolled: a runtime index into foff[] would pin the whole register struct to scratch)
-                if (valid > 64 * hf) {
+                const int vh = LIST ? ((hf ? e1 : e0) >> 24) : (valid - 64 * hf < 64 ? valid - 64 * hf : 64);  // valid keys of this sub-tile
+                if (vh > 0) {
                     qk_plain<0>(0, hf);
-                    if (valid - 64 * hf < 64) mask_keys<0>(valid - 64 * hf, hi);
+                    if (vh < 64) mask_keys<0>(vh, hi);
                     softmax_exact<0, true>();
                     pv_plain<0>(0, hf);
                 }
@@ -241,10 +278,10 @@ struct W64 {
     // pieces of set j ({K(j+2), V^T(j+1)}: their slots were freed by the pair's barrier), one per 4 chunks.
     // MASK: keys >= valid of sub-tile t are masked (last stage).
     // ABL (measurement build; results are wrong, timing is what is measured): bit 0 no DMA pieces in the loop, bit 2 no softmax VALU in the loop
-    template <int EVEN, bool MASK, bool PIN, int ABL = 0>
+    template <int EVEN, bool MASK, bool PIN, int ABL = 0, bool LIST = false>
     __device__ __forceinline__ void iter(int j, int valid, int hi) {
         constexpr int CUR = 1 - EVEN, FD = 6;
-        if (MASK) {
+        if (LIST ? valid < 64 : MASK) {  // LIST: any block may be ragged (wave-uniform run-time test at the iteration's start)
             fence_s<CUR>();  // the previous iteration's last Q·K^T MFMAs wrote these registers a few instructions ago
             mask_keys<CUR>(valid, hi);
         }
@@ -277,7 +314,7 @@ struct W64 {
                 const int nx = i + FD;
                 if (nx < 32) fr[i % FD] = nx < 16 ? frag_v(j, 4 * EVEN + (nx >> 2), nx & 3) : frag_k(j + 1, (nx - 16) >> 1, 2 * EVEN + ((nx - 16) & 1));
             }
-            if (EVEN == 0 && (c & 3) == 1 && !(ABL & 1)) issue_piece(c >> 2, j);
+            if (EVEN == 0 && (c & 3) == 1 && !(ABL & 1)) issue_piece<LIST>(c >> 2, j);
             if (!(ABL & 4)) {
                 // the softmax, software-pipelined over the chunks so that the three VALU instructions of a chunk are INDEPENDENT (one wave per
                 // SIMD: nothing else hides the latency of fma -> exp -> add on one score): chunk c finishes score c (row sum, bf16 pack),
@@ -311,8 +348,12 @@ struct W64 {
 // run) is its own workgroup — for grids too small to fill 256 CUs (sequence-parallel ranks: 192 query-block workgroups at SP = 8).  A
 // run's result is written UN-merged: normalised O as fp32 rows into o_part[run][b][h][row][128] and its base-2 LSE into
 // lse_part[run][b][h][row]; attn_merge_splits_kernel combines the runs (a run with no keys writes LSE = -inf and is ignored).
-template <bool PIN, int ABL = 0, bool PLAIN_IDS = false, bool SPLIT = false>
-__global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n_split, float* o_part, float* lse_part) {
+// LIST (fvk_attn_tile_lists_bf16): every `q_stride` consecutive query rows share ONE list of 64-key KV blocks (a sliding-tile window); a
+// workgroup owns 256 of those rows and sub-tile t of its key walk IS list entry t — K pieces add their block's row offset, a V^T piece row
+// takes 64 keys from each of the stage's two blocks (per-lane block choice), every sub-tile is masked by its own block size, output rows may
+// be scattered (o_rows).  The list is copied to LDS behind the ring once; entries are read a whole pair ahead.
+template <bool PIN, int ABL = 0, bool PLAIN_IDS = false, bool SPLIT = false, bool LIST = false>
+__global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n_split, float* o_part, float* lse_part, fvk_pp2_lists la) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BMQ = 256;
@@ -324,17 +365,39 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n
     // XCD-aware deal: hardware workgroup id x lands on XCD x % 8 (its own L2); XCD c gets the CONTIGUOUS logical ids [c*q + min(c, r), ...), i.e.
     // consecutive query blocks of the same head, which stream the same K / V^T
     const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
-    const int bid = PLAIN_IDS ? (int)blockIdx.x : xcd * xq + (xcd < xr ? xcd : xr) + (int)(blockIdx.x >> 3);
-    const int q_first = (bid % nqb) * BMQ;
-    const int h = (bid / nqb) % a.H;
-    const int b = (bid / (nqb * a.H)) % a.B;
+    const int bid = (PLAIN_IDS || (LIST && la.plain_ids)) ? (int)blockIdx.x : xcd * xq + (xcd < xr ? xcd : xr) + (int)(blockIdx.x >> 3);
+    int q_first, h, b, lst_num = 0;
+    int32_t* const lst = reinterpret_cast<int32_t*>(smem + LDS_BYTES);  // LIST: [stage][2] packed entries
+    if (LIST) {
+        const int per_head = la.n_lists * la.q_sub;
+        const int u = bid % per_head, sub_ = u % la.q_sub, li = u / la.q_sub;
+        h = (bid / per_head) % a.H;
+        b = bid / (per_head * a.H);
+        q_first = li * la.q_stride + sub_ * BMQ;
+        const long meta = ((long)b * a.H + h) * la.n_lists + li;
+        lst_num = la.q2k_num[meta];
+        if (la.q_rows_valid && sub_ * BMQ >= la.q_rows_valid[li]) lst_num = 0;  // only padding rows: nothing to do
+        const int32_t* src = la.q2k_idx + meta * la.max_kv;
+        for (int t = tid; t < (lst_num + 1) >> 1; t += 256) {
+            const int id0 = src[2 * t];
+            const bool two = 2 * t + 1 < lst_num;
+            const int id1 = two ? src[2 * t + 1] : id0;  // an absent second block re-reads the first, with no valid key
+            lst[2 * t] = id0 | (la.kv_block_sizes[id0] << 24);
+            lst[2 * t + 1] = id1 | ((two ? la.kv_block_sizes[id1] : 0) << 24);
+        }
+        __syncthreads();
+    } else {
+        q_first = (bid % nqb) * BMQ;
+        h = (bid / nqb) % a.H;
+        b = (bid / (nqb * a.H)) % a.B;
+    }
     const int run = SPLIT ? bid / (nqb * a.H * a.B) : 0;
     // this workgroup's keys: stages [st0, st1) of the (b, h) slice; Skv_w = its key count (the last stage of the last run may be ragged)
     const int n_all = (a.Skv + KT - 1) / KT;
     const int st0 = SPLIT ? (int)((long)n_all * run / n_split) : 0, st1 = SPLIT ? (int)((long)n_all * (run + 1) / n_split) : n_all;
-    const int n = st1 - st0;                      // stages of this workgroup (SPLIT: may be 0 when there are fewer stages than runs)
-    const int Skv_w = (st1 * KT < a.Skv ? st1 * KT : a.Skv) - st0 * KT;
-    const int v_last = Skv_w - (n - 1) * KT;      // valid keys of the last stage, 1..128
+    const int n = LIST ? (lst_num + 1) >> 1 : st1 - st0;  // stages of this workgroup (SPLIT / LIST: may be 0)
+    const int Skv_w = LIST ? a.Skv : (st1 * KT < a.Skv ? st1 * KT : a.Skv) - st0 * KT;
+    const int v_last = Skv_w - (n - 1) * KT;      // dense: valid keys of the last stage, 1..128 (LIST: unused — every entry has its own size)
 
     const bf16_t* qp = (const bf16_t*)a.q + (long)b * a.q_bs + (long)h * a.q_hs;
     const bf16_t* kp = (const bf16_t*)a.k + (long)b * a.k_bs + (long)h * a.k_hs + (long)st0 * KT * a.k_ss;
@@ -346,8 +409,23 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n
         return;
     }
 
+    if (LIST && n <= 0) {  // an empty list (workgroup-uniform): zero rows, LSE = -inf
+        for (int r = tid; r < BMQ; r += 256) {
+            const int qr = q_first + r;
+            if (qr >= a.Sq) break;
+            const int orow_i = la.o_rows ? la.o_rows[qr] : qr;
+            if (orow_i < 0) continue;
+            bf16_t* orow = op + (long)orow_i * a.o_ss;
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int c = 0; c < 16; ++c) st_bf16x8(orow + c * 8, z);
+            if (a.lse) a.lse[((long)b * a.H + h) * a.Sq + qr] = -INFINITY;
+        }
+        return;
+    }
+
     W64 w;
     w.smem = smem;
+    w.lst = lst;
     w.n = n;
     w.c2 = a.scale * 1.4426950408889634f;
     // Q fragments of the wave's two 32-row blocks (B operand of S^T = K·Q^T): row q0 + 32*blk + l31, d = 16*ks + 8*hi .. +8
@@ -377,6 +455,12 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n
     w.k_pstride = (unsigned)(16 * a.k_ss * 2);
     w.v_pstride = (unsigned)(16 * a.Skv_pad * 2);
     w.k_tile_bytes = (unsigned)(a.k_ss * 2 * KT);
+    w.k_blk_bytes = (unsigned)(a.k_ss * 2 * 64);
+    {   // LIST: this lane's source chunk of a V^T piece row picks the block (chunks 8-15 = the stage's second block), (chunk & 7) the 16 B inside it
+        const unsigned csrc = (unsigned)((lane & 15) ^ (r0 & 15));
+        w.vhalf = csrc >= 8;
+        w.vvl = (unsigned)(r0 * a.Skv_pad * 2) + ((csrc & 7) << 4);
+    }
     w.pdst = wave * 1024;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) w.foff[ks] = l31 * 256 + (((2 * ks + hi) ^ (l31 & 15)) << 4);
@@ -400,8 +484,30 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n
         __builtin_amdgcn_sched_barrier(0);      \
     }
     // ---- prologue: K(0), V^T(0) -> slot 0, K(1) -> slot 1; Q·K^T(0), the reference + softmax(0), Q·K^T(1) --------------------------------
+    // LIST: the entries of the stage whose second block is softmaxed first (A1), of stage j+1 (B0, B1) and of stage j+2 (C0, C1), wave-uniform;
+    // P0 / P1 = the entries of stage j+3, read from LDS a whole pair before they are needed
+    int eA1 = 0, eB0 = 0, eB1 = 0, eC0 = 0, eC1 = 0, eP0 = 0, eP1 = 0;
+    if (LIST) {
+        const int e00 = __builtin_amdgcn_readfirstlane(w.entry(0));
+        eA1 = __builtin_amdgcn_readfirstlane(w.entry(1));
+        eB0 = __builtin_amdgcn_readfirstlane(w.entry(2));
+        eB1 = __builtin_amdgcn_readfirstlane(w.entry(3));
+        eC0 = __builtin_amdgcn_readfirstlane(w.entry(4));
+        eC1 = __builtin_amdgcn_readfirstlane(w.entry(5));
+        eP0 = w.entry(6);
+        eP1 = w.entry(7);
+        w.set_pair(e00, eA1, e00, eA1);  // stage 0 as a "set": K(0) -> slot 0 (J = 0: pieces 0-7), V^T(0) -> slot 0 (J = -1: pieces 8-15)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8; ++i) {
+            w.issue_piece<true>(i, 0);
+            w.issue_piece<true>(8 + i, -1);
+        }
+        w.set_pair(eB0, eB1, 0, 0);      // K(1) -> slot 1 (J = 1)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w.issue_piece<true>(i, 1);
+    }
+#pragma unroll
+    for (int i = 0; i < 8 && !LIST; ++i) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w.k_rsrc, (lds_void*)(smem + w.pdst + i * 4096), 16, w.kv0,
                                                  __builtin_amdgcn_readfirstlane(i * w.k_pstride), 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(w.k_rsrc, (lds_void*)(smem + K_TILE + w.pdst + i * 4096), 16, w.kv0,
@@ -411,9 +517,13 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n
     }
     WAIT_ALL()
     BAR()
-    const int v0 = v_last < 64 ? v_last : 64, v1 = v_last > 64 ? v_last - 64 : 0;  // valid keys of the last stage's two sub-tiles
+    const int v0 = v_last < 64 ? v_last : 64;  // dense: valid keys of the last stage's two sub-tiles
+    int v1 = v_last > 64 ? v_last - 64 : 0;
     w.qk_plain<0>(0, 0);
-    if (n == 1) w.mask_keys<0>(v0, hi);
+    if (LIST) {
+        const int sz0 = __builtin_amdgcn_readfirstlane(w.entry(0)) >> 24;
+        if (sz0 < 64) w.mask_keys<0>(sz0, hi);
+    } else if (n == 1) w.mask_keys<0>(v0, hi);
     // the fixed reference: exact row max of the first sub-tile (it has at least one valid key)
     w.m_run[0] = w.row_max<0, 0>();
     w.m_run[1] = w.row_max<0, 1>();
@@ -421,20 +531,33 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n
     w.l_run[1] = w.exp_pack<0, 1>(w.m_run[1] * w.c2);
     w.qk_plain<1>(0, 1);
     // ---- pairs j = 0 .. n-2: iterations t = 2j+1 and 2j+2 behind ONE barrier; the last pair masks sub-tile 2n-2 ------------------------------
-    for (int j = 0; j + 2 < n; ++j) {  // straight-line body: a conditional inside would make the register assignment of the two paths meet with copies
+    for (int j = 0; j + (LIST ? 1 : 2) < n; ++j) {  // straight-line body: a conditional inside would make the register assignment of the two paths meet with copies
         if (!(ABL & 2)) {
             WAIT_ALL()  // this wave's pieces of set j-1 (issued a whole pair ago) have landed
             BAR()       // every wave is past iteration 2j: the slots of K(j) and V^T(j-1) are free, set j-1 is visible
         }
-        w.iter<0, false, PIN, ABL>(j, 64, hi);
-        w.iter<1, false, PIN, ABL>(j, 64, hi);
+        if (LIST) {
+            w.set_pair(eC0, eC1, eB0, eB1);                       // this pair's set: K(j+2), V^T(j+1)
+            const int a1 = eA1 >> 24, b0 = eB0 >> 24;             // valid keys of sub-tiles 2j+1 and 2j+2
+            eA1 = eB1; eB0 = eC0; eB1 = eC1;                      // the window moves one stage
+            eC0 = __builtin_amdgcn_readfirstlane(eP0);
+            eC1 = __builtin_amdgcn_readfirstlane(eP1);
+            eP0 = w.entry(2 * j + 8);                             // stage j+4: needed as C in the pair after next
+            eP1 = w.entry(2 * j + 9);
+            w.iter<0, false, PIN, ABL, true>(j, a1, hi);
+            w.iter<1, false, PIN, ABL, true>(j, b0, hi);
+        } else {
+            w.iter<0, false, PIN, ABL>(j, 64, hi);
+            w.iter<1, false, PIN, ABL>(j, 64, hi);
+        }
     }
-    if (n >= 2) {
+    if (!LIST && n >= 2) {
         WAIT_ALL()
         BAR()
         w.iter<0, false, PIN>(n - 2, 64, hi);
         w.iter<1, true, PIN>(n - 2, v0, hi);
     }
+    if (LIST) v1 = eA1 >> 24;  // the last stage's second block
     // ---- tail: P·V(2n-2), softmax of sub-tile 2n-1 (second half of the last stage, masked), P·V(2n-1) --------------------------------------
     WAIT_ALL()  // V^T(n-1) (and the harmless re-reads of stage 0) landed
     BAR()
@@ -468,8 +591,8 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n
                     *reinterpret_cast<f32x4*>(orow + d * 32 + g * 8 + hi * 4) = v4;                                  \
                 }                                                                                                    \
                 if (hi == 0) lse_part[prow] = w.m_run[qb] * w.c2 + log2f(l_tot);                                     \
-            } else {                                                                                                 \
-                bf16_t* orow = op + (long)qrow[qb] * a.o_ss;                                                         \
+            } else if (!LIST || !la.o_rows || la.o_rows[qrow[qb]] >= 0) { /* LIST: un-grouping folded into the store */    \
+                bf16_t* orow = op + (long)((LIST && la.o_rows) ? la.o_rows[qrow[qb]] : qrow[qb]) * a.o_ss;           \
                 _Pragma("unroll") for (int d = 0; d < 4; ++d) _Pragma("unroll") for (int g = 0; g < 4; ++g) {       \
                     bf16x4 v4;                                                                                       \
                     _Pragma("unroll") for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(w.o[qb][d][g * 4 + e] * inv);    \
@@ -481,7 +604,7 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n
     }
     FVK_STORE_ROWS(false)
     if (__syncthreads_or(redo[0] || redo[1])) {
-        w.exact_pass(v_last, hi);
+        w.exact_pass<LIST>(v_last, hi);
         FVK_STORE_ROWS(true)
     }
 #undef FVK_STORE_ROWS
@@ -493,7 +616,7 @@ int launch_w64(const fvk_attn_args* a, hipStream_t s) {
     static FvkLdsConfigured configured;
     if (int rc = fvk_config_lds(configured, (const void*)attn_w64_kernel<PIN, ABL, PLAIN_IDS>, LDS_BYTES, "fvk_attn_dense_bf16 (w64)")) return rc;
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
-    hipLaunchKernelGGL((attn_w64_kernel<PIN, ABL, PLAIN_IDS>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, 1, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL((attn_w64_kernel<PIN, ABL, PLAIN_IDS>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, 1, (float*)nullptr, (float*)nullptr, fvk_pp2_lists{});
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -554,10 +677,22 @@ int fvk_attn_w64_split_launch(const fvk_attn_args* a, int n_split, float* o_part
     static FvkLdsConfigured configured;
     if (int rc = fvk_config_lds(configured, (const void*)attn_w64_kernel<true, 0, false, true>, LDS_BYTES, "fvk_attn_dense_split_bf16")) return rc;
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B * n_split;
-    hipLaunchKernelGGL((attn_w64_kernel<true, 0, false, true>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, n_split, o_part, lse_part);
+    hipLaunchKernelGGL((attn_w64_kernel<true, 0, false, true>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, n_split, o_part, lse_part, fvk_pp2_lists{});
     FVK_LAUNCH_CHECK();
     const long rows = (long)a->B * a->H * a->Sq;
     hipLaunchKernelGGL(attn_merge_splits_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, *a, n_split, (const float*)o_part, (const float*)lse_part);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+// 256-row workgroups over shared KV block lists (called by fvk_attn_tile_lists_bf16, attn_fwd.hip, after its argument checks)
+int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s) {
+    constexpr int LDS_LIST = LDS_BYTES + 2048 * 8;  // + the packed list: up to 2048 stages = 4096 blocks
+    FVK_CHECK(la->max_kv <= 4096, FVK_ERR_ARG, "fvk_attn_tile_lists_bf16: lists of more than 4096 blocks (max_kv=%d) do not fit the LDS copy", la->max_kv);
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_w64_kernel<true, 0, false, false, true>, LDS_LIST, "fvk_attn_tile_lists_bf16")) return rc;
+    const long nblk = (long)la->n_lists * la->q_sub * a->H * a->B;
+    hipLaunchKernelGGL((attn_w64_kernel<true, 0, false, false, true>), dim3((unsigned)nblk), dim3(256), LDS_LIST, s, *a, 1, (float*)nullptr, (float*)nullptr, *la);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }

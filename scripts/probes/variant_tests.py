@@ -218,3 +218,31 @@ def test_attn_pp_rescale_branch_and_repeatability(ops, tunables, impl):
     outs = [ops.attn_dense(q.to(DEV), k.to(DEV), v.to(DEV), layout="bshd").cpu() for _ in range(3)]
     _attn_check(outs[0], ref, f"rescale branch impl {impl}")
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_attn_w64_list_mode_agrees_with_the_shipped_list_kernel(ops, tunables):
+    """attn_w64's list mode ("attn_impl" 72; not shipped: attn_fwd.hip says why) over window-class query groups of a ragged sliding-tile
+    grid — partial blocks, odd list lengths, scattered output rows — against the shipped attn_pp2 list mode: same lists, same masks, the
+    outputs differ only by where P is rounded."""
+    from fastvideo_amd import kernel_api
+    grid, H = (7, 10, 20), 2
+    h = kernel_api.sliding_tile_block_lists(grid, (2, 4, 8), (3, 1, 3))
+    gq = torch.Generator().manual_seed(3)
+    q = torch.randn((1, h["group_rows"], H, 128), generator=gq).bfloat16().to(DEV)
+    k, v = (torch.randn((1, h["S_pad"], H, 128), generator=gq).bfloat16().to(DEV) for _ in range(2))
+    ex = lambda t, n: t.to(DEV)[None, None].expand(1, H, *([-1] * n)).contiguous()
+    idx, num, bs = ex(h["group_q2k_idx"], 2), ex(h["group_q2k_num"], 1), h["block_sizes"].to(DEV)
+    tok = torch.full((h["group_rows"],), -1, dtype=torch.int32)
+    tok[h["group_dst"].long()] = h["group_src"]
+    n_tok = grid[0] * grid[1] * grid[2]
+    outs = {}
+    for impl in (0, 72):
+        tunables("attn_impl", impl)
+        outs[impl] = (ops.attn_tile_lists(q, k, v, idx, num, bs, 256, None, layout="bshd").cpu(),
+                      ops.attn_tile_lists(q, k, v, idx, num, bs, 256, None, layout="bshd", o_rows=tok.to(DEV), n_out_rows=n_tok).cpu())
+    real = (tok >= 0)
+    for a_, b_ in zip(outs[0], outs[72]):
+        assert torch.isfinite(b_.float()).all()
+    d = (outs[72][0][0, real].float() - outs[0][0][0, real].float()).abs()
+    assert d.max().item() < 2e-2 and d.mean().item() < 2e-4, (d.max().item(), d.mean().item())
+    assert torch.equal(outs[72][1][0, tok[real].long()], outs[72][0][0, real])   # the scattered form stores the same rows at their tokens
