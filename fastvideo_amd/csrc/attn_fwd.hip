@@ -26,7 +26,9 @@ int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s); // 
 int fvk_attn_w64_split_launch(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, hipStream_t s);
 int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s);   // attn_pp2.hip
 int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);
-int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);  // attn_w64.hip
+#if FVK_VARIANTS
+int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);  // attn_w64.hip, measurement build
+#endif
 int fvk_attn_vsa_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
                         hipStream_t s);  // attn_vsa.hip: 64-row lists, key-split, register-staged prefetch
 

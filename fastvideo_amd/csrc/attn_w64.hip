@@ -685,6 +685,7 @@ int fvk_attn_w64_split_launch(const fvk_attn_args* a, int n_split, float* o_part
     return FVK_OK;
 }
 
+#if FVK_VARIANTS  // measurement build only: attn_fwd.hip (fvk_attn_tile_lists_bf16) says why the list mode is not shipped
 // 256-row workgroups over shared KV block lists (called by fvk_attn_tile_lists_bf16, attn_fwd.hip, after its argument checks)
 int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s) {
     constexpr int LDS_LIST = LDS_BYTES + 2048 * 8;  // + the packed list: up to 2048 stages = 4096 blocks
@@ -696,3 +697,4 @@ int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, h
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
+#endif
