@@ -187,10 +187,12 @@ static int gemm_impl(const void* x, const void* w, const void* bias, void* out, 
                M, N, K, lda, ldc, rows_per_batch > 0 ? rows_per_batch : M, (M + BM - 1) / BM, (N + BN - 1) / BN,
                epi_scalar, x_bstride, w_bstride, out_bstride};
     hipStream_t s = (hipStream_t)stream;
-    // token-axis GEMMs go to the 256x256 LDS-DMA kernels: gemm_ph.hip (K-step 64, the default) or gemm_pp.hip (K % 64 != 0, or forced
+    // token-axis GEMMs go to the 256x256 LDS-DMA kernels: gemm_w1.hip (K % 128 == 0, the default), gemm_ph.hip (K % 64 == 0) or gemm_pp.hip (K % 64 != 0, or forced
     // with gemm_impl 2 / 3); this 128x128 kernel keeps the small / odd shapes (gemm_impl 1 forces it)
     const int impl = fvk::tunable(fvk::TUNE_GEMM_IMPL);  // constant 0 in the product library
     if (impl != 1 && fvk::gemm_pp_eligible(a)) {
+        // gemm_w1.hip (four 128 x 128 waves, 16x16x32 MFMAs) where K is a whole number of 128-element double steps; gemm_impl 4 forces gemm_ph
+        if ((impl == 0 || (impl & 7) == 5) && fvk::gemm_w1_eligible(a)) return fvk::gemm_w1_launch(a, epilogue, batch, s);
         if ((impl == 0 || (impl & 7) == 4) && fvk::gemm_ph_eligible(a)) return fvk::gemm_ph_launch(a, epilogue, batch, s);
         return fvk::gemm_pp_launch(a, epilogue, batch, s);
     }

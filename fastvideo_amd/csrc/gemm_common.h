@@ -34,6 +34,10 @@ int gemm_pp_fp8_launch(GemmArgs a, int epilogue, hipStream_t s);
 bool gemm_ph_eligible(const GemmArgs& a);
 int gemm_ph_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
 
+// gemm_w1.hip (gemm_ph's tile and unit FIFO with four 128 x 128 waves, one per SIMD; gemm_impl 5)
+bool gemm_w1_eligible(const GemmArgs& a);
+int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
+
 // Integer knobs for within-process A/B measurements (fvk_set_tunable).  They exist only in the MEASUREMENT build of the library
 // (scripts/probes/libfvk_probe.so, compiled with -DFVK_PROBE_BUILD by fastvideo_amd/_build.py: build_probe): there FVK_VARIANTS is 1,
 // the non-shipping kernels and schedules (attn_pp.hip, attn_vsa.hip, the attn_pp2 / gemm_ph / vae_conv3 variants, ablation probes) are

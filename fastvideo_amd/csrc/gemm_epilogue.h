@@ -23,8 +23,9 @@ __device__ __forceinline__ float gelu_tanh_fast(float x) {
 // The caller guarantees that no wave still reads or DMA-writes the LDS ring (drained + barrier) before calling.
 // PREF (gated-residual epilogue): all 16 residual vectors of the lane are requested BEFORE the accumulators are packed and bounced
 // (one exposed HBM latency per tile instead of four), and the gate row is loaded once when the wave's 128 rows share a batch.
-template <int EPI, bool FP8, bool PREF = false>
-__device__ __forceinline__ void gemm_tile_epilogue(const GemmArgs& a, f32x16 (&acc)[2][4], unsigned char* smem, int wave, int lane, int m0, int n0) {
+// MI16: the accumulator is f32x4 acc[4][8] of v_mfma_f32_16x16x32_bf16 tiles (gemm_w1.hip): acc[nb][mb][e] = D[n = nb*16 + 4(lane>>4) + e][m = mb*16 + (lane&15)].
+template <int EPI, bool FP8, bool PREF = false, bool MI16 = false, typename Acc = f32x16[2][4]>
+__device__ __forceinline__ void gemm_tile_epilogue(const GemmArgs& a, Acc& acc, unsigned char* smem, int wave, int lane, int m0, int n0) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave & 1, wn = wave >> 1;
     constexpr bool kPref = PREF && EPI == FVK_EPI_RESIDUAL_GATE;
@@ -51,6 +52,26 @@ __device__ __forceinline__ void gemm_tile_epilogue(const GemmArgs& a, f32x16 (&a
     }
     unsigned char* st = smem + wave * EPI_WAVE;
     const int ncol0 = n0 + wn * 64;
+    if constexpr (MI16) {
+        static_assert(!FP8, "the 16x16x32 accumulator layout is a bf16-GEMM path");
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            const int nl = nb * 16 + 4 * (lane >> 4);
+            float b4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias && ncol0 + nl < a.N) {
+                const bf16x4 bv = *reinterpret_cast<const bf16x4*>(a.bias + ncol0 + nl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b4[e] = (float)bv[e];
+            }
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb) {
+                bf16x4 y;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = (bf16_t)(acc[nb][mb][e] + b4[e]);
+                *reinterpret_cast<bf16x4*>(st + (mb * 16 + (lane & 15)) * EPI_PITCH + nl * 2) = y;
+            }
+        }
+    } else
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll

@@ -1,0 +1,324 @@
+// bf16 GEMM for the token-axis projections, gfx950 only — "one wave per SIMD" kernel: the shipped bf16 path for K % 128 == 0
+// (gemm_impl 0; gemm_impl 228 forces gemm_ph.hip, 5 + 8 * VAR a schedule variant of this file; scripts/gemm_ab.py).
+//   out[M,N] = epilogue( x[M,K] · w[N,K]^T + bias )      (same contract and rounding points as gemm_ph.hip)
+//
+// Same 256(M) x 256(N) workgroup tile, K-step 64, 128-B swizzled LDS rows, unit FIFO and epilogue as gemm_ph.hip.  Two things change:
+//   * the wave tile: FOUR waves of 128 x 128 (one per SIMD, the whole 512-entry register file each: 256 accumulator AGPRs + 128
+//     fragment VGPRs) instead of eight waves of 128 x 64.  A K-tile then costs every SIMD 32 fragment reads for 2048 MFMA cycles
+//     (gemm_ph: 2 x 24), and nothing alternates on a SIMD: the MFMA stream is continuous and the fragment reads / LDS-DMA pieces of the
+//     NEXT phases are interleaved into it by hand;
+//   * the MFMA shape: v_mfma_f32_16x16x32_bf16 (K = 32 per instruction, 4 accumulator registers) instead of 32x32x16 (K = 16, 16
+//     registers).  Same FLOP per cycle, but half the accumulator traffic per FLOP — and MI355X is power-bound: a registers-only MFMA loop
+//     sustains 2.40 PFLOP/s in the 16x16x32 shape against 2.13 in 32x32x16 (scripts/probes/mfma_rate.cpp, profiles/r03_mfma_shapes.md).
+//     On the same schedule the shape alone is worth +6..8 % here (VAR 3 -> 7).  The summation order inside an instruction differs, so
+//     this kernel agrees with gemm_ph.hip to rounding, not byte for byte (VAR 0..3, the 32x32x16 variants, are byte-identical to it).
+// Measured (same box, interleaved, TFLOP/s, gemm_ph -> this kernel | vendor library plain epilogue): QKV [32760,4608,1536] 1205 -> 1284 | 1116,
+// out-proj [32760,1536,1536] 1149 -> 1224 | 1307, FFN-in [32760,8960,1536] 1157 -> 1188 | 1336, FFN-out [32760,1536,8960] 1357 -> 1448 | 1540,
+// 8192^3 1392 -> 1559 | 1560, 14B FFN-out [75600,5120,13824] 1268 -> 1411 | 1530.
+//
+// A K-tile is four phases (one 64 x 64 quadrant of the wave tile x K = 64: 32 MFMAs 16x16x32, or 16 MFMAs 32x32x16):
+//     phase 4t+0: X0 x W0    4t+1: X0 x W1    4t+2: X1 x W1    4t+3: X1 x W0          (X0 / X1 = the wave's first / second 64 m, W0 / W1 likewise in n)
+// Units in the order their fragments are read:  U(4t) = W0(t), U(4t+1) = W1(t), U(4t+2) = X1(t), U(4t+3) = X0(t+1).   During phase p a wave
+//   * runs MFMA(p) from registers,
+//   * reads unit U(p+1) (8 fragments = the unit's whole K = 64) into the register set that fell free — X0 / X1 have a set each, the two
+//     W sets swap roles every K-tile, hence the loop body of two K-tiles,
+//   * stages one unit by LDS-DMA (4 pieces per wave) into a slot whose reads retired before the last barrier.
+// Shipped schedule (VAR bit 1): ONE barrier per two phases.  Phase p stages U(p+7) into the slot of U(p-1).  WAR: U(p-1) was read in phase
+// p-2, i.e. in front of the barrier closing the previous phase pair (reads are retired with lgkmcnt(0) there).  RAW: U(p+7) is read in
+// phase p+6; every wave waits for its own pieces at the barrier closing the pair before (vmcnt(16): the two younger pairs' pieces stay in
+// flight, about 2000-3000 cycles of flight).  Without VAR bit 1: a barrier per phase, phase p stages U(p+8), vmcnt(24).
+#include "gemm_common.h"
+#include "gemm_epilogue.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int ROWB = TK * 2;     // 128 B per LDS row
+constexpr int XREG = TM * ROWB;  // 32 KiB: the x rows of a buffer; the w rows follow
+constexpr int BUF = 2 * XREG;    // 64 KiB
+constexpr int LDS_BYTES = fvk::EPI_LDS_BYTES;
+static_assert(LDS_BYTES >= 2 * BUF, "epilogue staging must cover both buffers");
+
+using fvk::GemmArgs;
+
+#define W1_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+#define W1_MFMA16(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+
+template <int EPI, int VAR>
+__global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef __attribute__((address_space(3))) void lds_void;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;  // wave tile: rows wm*128.., cols wn*128..
+
+    a.x += blockIdx.y * a.x_bstride;
+    a.w += blockIdx.y * a.w_bstride;
+    a.out += blockIdx.y * a.out_bstride;
+    // ---- tile id: XCD-contiguous (block b runs on XCD b % 8), then groups of 8 m-tiles swept along n (as gemm_ph.hip) --------
+    const int ntiles = a.ntm * a.ntn;
+    int tile_id;
+    {
+        const int nwg = ntiles, bid = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    constexpr int GM = 8;
+    const int per_group = GM * a.ntn;
+    const int gid = tile_id / per_group;
+    const int first_m = gid * GM;
+    const int gsz = (a.ntm - first_m) < GM ? (a.ntm - first_m) : GM;
+    const int in_g = tile_id - gid * per_group;
+    const int pid_m = first_m + in_g % gsz, pid_n = in_g / gsz;
+    const int m0 = pid_m * TM, n0 = pid_n * TN;
+
+    // ---- LDS-DMA staging: every wave stages 32 consecutive rows (4 pieces of 8 rows x 128 B) of each unit -----------------------
+    //   X0: rows (wave>>1)*128 + (wave&1)*32    X1: + 64        W0 / W1: the same rows of the w panel
+    const int row0 = (wave >> 1) * 128 + (wave & 1) * 32;
+    int xvalid = a.M - m0, wvalid = a.N - n0;
+    xvalid = xvalid > 256 ? 256 : xvalid;
+    wvalid = wvalid > 256 ? 256 : wvalid;
+    const long xld = a.lda * 2, wld = (long)a.K * 2;  // row pitch in bytes
+    const unsigned char* xbase = (const unsigned char*)a.x + (long)m0 * xld;
+    const unsigned char* wbase = (const unsigned char*)a.w + (long)n0 * wld;
+    // one descriptor per unit kind, based at the wave's first row of that kind; rows past the operand's valid rows read as zeros
+    auto mk = [](const unsigned char* base, long ld, int r0, int valid, int K) {
+        const long nrec = valid > r0 ? ((long)(valid - r0) - 1) * ld + (long)K * 2 : 0;
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)r0 * ld), 0, (int)nrec, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t r_x0 = mk(xbase, xld, row0, xvalid, a.K);
+    const __amdgpu_buffer_rsrc_t r_x1 = mk(xbase, xld, row0 + 64, xvalid, a.K);
+    const __amdgpu_buffer_rsrc_t r_w0 = mk(wbase, wld, row0, wvalid, a.K);
+    const __amdgpu_buffer_rsrc_t r_w1 = mk(wbase, wld, row0 + 64, wvalid, a.K);
+    // lane -> (row r = lane>>3 of the piece, LDS chunk position lane&7); piece i holds rows 8i + r.  LDS chunk position c' of tile
+    // row R holds source chunk c' ^ ((R >> 1) & 7); row0 is a multiple of 32, so (R >> 1) & 7 = 4(i & 1) + (r >> 1).
+    int xv[4], wv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = lane >> 3;
+        const int c = (lane & 7) ^ (4 * (i & 1) + (r >> 1));
+        xv[i] = (int)((long)(8 * i + r) * xld) + c * 16;
+        wv[i] = (int)((long)(8 * i + r) * wld) + c * 16;
+    }
+    const int d_x0 = row0 * ROWB, d_x1 = (row0 + 64) * ROWB;
+    const int d_w0 = XREG + row0 * ROWB, d_w1 = XREG + (row0 + 64) * ROWB;
+    const int nt = a.K / TK;
+
+    // kinds: 0 = X0, 1 = W0, 2 = W1, 3 = X1.  One piece (PC) of unit KIND of K-tile TILE; tiles past the end re-read tile 0 (never consumed)
+#define W1_STAGE(KIND, TILE, PC)                                                                                      \
+    {                                                                                                                 \
+        const int t_ = (TILE);                                                                                        \
+        const int so_ = __builtin_amdgcn_readfirstlane(t_ < nt ? t_ * ROWB : 0);                                      \
+        unsigned char* d_ = smem + (t_ & 1) * BUF + ((KIND) == 0 ? d_x0 : (KIND) == 1 ? d_w0 : (KIND) == 2 ? d_w1 : d_x1) + (PC) * 1024; \
+        if ((KIND) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x0, (lds_void*)(d_), 16, xv[PC], so_, 0, 0);      \
+        else if ((KIND) == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w0, (lds_void*)(d_), 16, wv[PC], so_, 0, 0); \
+        else if ((KIND) == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w1, (lds_void*)(d_), 16, wv[PC], so_, 0, 0); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x1, (lds_void*)(d_), 16, xv[PC], so_, 0, 0);                  \
+    }
+#define W1_STAGE_UNIT(KIND, TILE) W1_STAGE(KIND, TILE, 0) W1_STAGE(KIND, TILE, 1) W1_STAGE(KIND, TILE, 2) W1_STAGE(KIND, TILE, 3)
+
+    // ---- fragment read offsets (bytes within a buffer).  32x32x16 fragments: row R = l31, k16-step ks, half hi -> chunk (2ks + hi);
+    // 16x16x32 fragments (MI16): row R = lane & 15, k32-step ks, quarter q = lane >> 4 -> chunk (4ks + q).  LDS chunk = chunk ^ ((R>>1)&7);
+    // a ds_read_b128 is served 16 lanes a cycle over 64 banks: 16 consecutive rows of one chunk are conflict-free in both shapes.
+    constexpr bool MI16 = (VAR & 4) != 0;
+    constexpr int NKS = MI16 ? 2 : 4, NBLK = MI16 ? 4 : 2, BLKR = MI16 ? 16 : 32;  // k-steps per K-tile, row blocks per unit, rows per block
+    int xo[4], wo[4];
+    {
+        const int rl = MI16 ? (lane & 15) : l31;
+        const int sw = (rl >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int co = ((MI16 ? 4 * ks + (lane >> 4) : 2 * ks + hi) ^ sw) << 4;
+            xo[ks] = (wm * 128 + rl) * ROWB + co;
+            wo[ks] = XREG + (wn * 128 + rl) * ROWB + co;
+        }
+    }
+
+    f32x16 acc[MI16 ? 1 : 4][MI16 ? 1 : 4];   // 32x32x16: [nb][mb]
+    f32x4 acc16[MI16 ? 8 : 1][MI16 ? 8 : 1];  // 16x16x32: [nb][mb]
+    if (MI16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc16[i & (MI16 ? 7 : 0)][j & (MI16 ? 7 : 0)][r] = 0.f;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i & (MI16 ? 0 : 3)][j & (MI16 ? 0 : 3)][r] = 0.f;
+    }
+
+    bf16x8 XA[8], XB[8], WA[8], WB[8];  // fragment sets, in the order a phase consumes them: [ks * NBLK + block]
+
+    // fragment J (0..7: block J % NBLK, k-step J / NBLK) of a unit: IS_X selects the x / w rows, ROW0 (0 / 64) the unit's first row in the wave tile
+#define W1_READ1(DST, BUFP, IS_X, ROW0, J) \
+    DST[J] = *reinterpret_cast<const bf16x8*>((BUFP) + ((IS_X) ? xo[(J) / NBLK] : wo[(J) / NBLK]) + ((ROW0) + ((J) % NBLK) * BLKR) * ROWB);
+#define W1_PHASE_END(P)                                                 \
+    if (!(VAR & 2)) {                                                   \
+        asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        __builtin_amdgcn_s_barrier();                                   \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    } else if ((P) & 1) {                                               \
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");    \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        __builtin_amdgcn_s_barrier();                                   \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    }
+    // One 64 x 64 quadrant x K = 64: 16 MFMAs 32x32x16 (ks outer, then 2 x 2 blocks) or 32 MFMAs 16x16x32 (ks outer, then 4 x 4 blocks, the
+    // w fragment held over 4 MFMAs), with the unit read and the unit stage between them at 16 SLOTS.  VAR bit 0: the 8 fragment reads fill
+    // slots 0..7 and the 4 pieces slots 8, 10, 12, 14 (else a read in every odd slot, a piece in every fourth); VAR bit 1: one barrier
+    // per TWO phases (phase p stages U(p+7) and the wait is vmcnt(16)).  P = phase number within the K-tile; NQ / MQ = the quadrant.
+#define W1_PHASE(P, XS, WS, NQ, MQ, RDST, RBUF, RIS_X, ROW0)                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < (MI16 ? 32 : 16); ++i_) {                                   \
+        if (MI16) {                                                                                     \
+            const int ks_ = i_ >> 4, nb_ = (i_ >> 2) & 3, mb_ = i_ & 3;                                 \
+            W1_MFMA16(acc16[((NQ) * 4 + nb_) & (MI16 ? 7 : 0)][((MQ) * 4 + mb_) & (MI16 ? 7 : 0)], WS[ks_ * 4 + nb_], XS[ks_ * 4 + mb_]); \
+        } else {                                                                                        \
+            const int ks_ = i_ >> 2, nb_ = (i_ >> 1) & 1, mb_ = i_ & 1;                                 \
+            W1_MFMA(acc[((NQ) * 2 + nb_) & (MI16 ? 0 : 3)][((MQ) * 2 + mb_) & (MI16 ? 0 : 3)], WS[(ks_ * 2 + nb_) & 7], XS[(ks_ * 2 + mb_) & 7]); \
+        }                                                                                               \
+        constexpr int sk_ = (VAR & 2) ? ((P) == 0 ? 0 : (P) == 1 ? 1 : (P) == 2 ? 2 : 3) : ((P) == 0 ? 1 : (P) == 1 ? 2 : (P) == 2 ? 3 : 0); \
+        const int st_ = t + (PT) + 2 + ((!(VAR & 2) && (P) == 3) ? 1 : 0);                              \
+        if (!MI16 || (i_ & 1)) {                                                                        \
+            const int sl_ = MI16 ? i_ >> 1 : i_;                                                        \
+            if (VAR & 1) {                                                                              \
+                if (sl_ < 8) { W1_READ1(RDST, RBUF, RIS_X, ROW0, sl_ & 7) }                             \
+                else if ((sl_ & 1) == 0) W1_STAGE(sk_, st_, ((sl_ - 8) >> 1) & 3)                       \
+            } else {                                                                                    \
+                if ((sl_ & 3) == 0) W1_STAGE(sk_, st_, sl_ >> 2)                                        \
+                if (sl_ & 1) { W1_READ1(RDST, RBUF, RIS_X, ROW0, sl_ >> 1) }                            \
+            }                                                                                           \
+        }                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    }                                                                                                   \
+    W1_PHASE_END(P)
+
+    // ---- prologue: both K-tiles' units staged in read order, X0(0) and W0(0) landed and read, X0(2) staged ("phase -1") --------
+    W1_STAGE_UNIT(0, 0) W1_STAGE_UNIT(1, 0) W1_STAGE_UNIT(2, 0) W1_STAGE_UNIT(3, 0)
+    W1_STAGE_UNIT(0, 1) W1_STAGE_UNIT(1, 1) W1_STAGE_UNIT(2, 1) W1_STAGE_UNIT(3, 1)
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { W1_READ1(XA, smem, true, 0, j) }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { W1_READ1(WA, smem, false, 0, j) }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(VAR & 2)) {
+        W1_STAGE_UNIT(0, 2)
+        W1_PHASE_END(1)
+    } else {  // phase 0 stages X0(2) itself; U(1), U(2) (read in phases 0, 1) must have landed: all but the 16 youngest pieces
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    for (int t = 0; t < nt; t += 2) {  // nt is even (gemm_w1_eligible)
+        const unsigned char* b0 = smem + (t & 1) * BUF;  // K-tiles t, t+2
+        const unsigned char* b1 = smem + ((t + 1) & 1) * BUF;
+        // K-tile t: W0 in WA, W1 in WB.   stage (VAR bit 1 clear): phases 0..3 stage W0(t+2), W1(t+2), X1(t+2), X0(t+3); (set): X0(t+2), W0(t+2), W1(t+2), X1(t+2)
+#define PT 0
+        W1_PHASE(0, XA, WA, 0, 0, WB, b0, false, 64)  // X0 x W0; read W1(t)
+        W1_PHASE(1, XA, WB, 1, 0, XB, b0, true, 64)   // X0 x W1; read X1(t)
+        W1_PHASE(2, XB, WB, 1, 1, XA, b1, true, 0)    // X1 x W1; read X0(t+1)
+        W1_PHASE(3, XB, WA, 0, 1, WB, b1, false, 0)   // X1 x W0; read W0(t+1)
+#undef PT
+#define PT 1
+        // K-tile t+1: W0 in WB, W1 in WA
+        W1_PHASE(0, XA, WB, 0, 0, WA, b1, false, 64)  // read W1(t+1)
+        W1_PHASE(1, XA, WA, 1, 0, XB, b1, true, 64)   // read X1(t+1)
+        W1_PHASE(2, XB, WA, 1, 1, XA, b0, true, 0)    // read X0(t+2)
+        W1_PHASE(3, XB, WB, 0, 1, WA, b0, false, 0)   // read W0(t+2)
+#undef PT
+    }
+#undef W1_STAGE
+#undef W1_STAGE_UNIT
+#undef W1_READ1
+#undef W1_PHASE
+#undef W1_PHASE_END
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail re-reads must have landed before the buffers are reused
+    __builtin_amdgcn_s_barrier();
+    // the accumulators were written by asm MFMAs: the compiler knows no hazard distance to its own reads of them
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+    // the shared epilogue works on 128(m) x 64(n) wave tiles numbered wm + 2 * (64-column group): this wave is two of them
+    if constexpr (MI16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc16[i][j]));
+        fvk::gemm_tile_epilogue<EPI, false, true, true>(a, reinterpret_cast<f32x4(&)[4][8]>(acc16[0]), smem, wm + 2 * (2 * wn), lane, m0, n0);
+        fvk::gemm_tile_epilogue<EPI, false, true, true>(a, reinterpret_cast<f32x4(&)[4][8]>(acc16[4]), smem, wm + 2 * (2 * wn + 1), lane, m0, n0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[i][j]));
+        fvk::gemm_tile_epilogue<EPI, false, true>(a, reinterpret_cast<f32x16(&)[2][4]>(acc[0]), smem, wm + 2 * (2 * wn), lane, m0, n0);
+        fvk::gemm_tile_epilogue<EPI, false, true>(a, reinterpret_cast<f32x16(&)[2][4]>(acc[2]), smem, wm + 2 * (2 * wn + 1), lane, m0, n0);
+    }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+template <int EPI, int VAR>
+int launch(const GemmArgs& a, int batch, hipStream_t s) {
+    static FvkLdsConfigured configured;
+    if (int rc = fvk_config_lds(configured, (const void*)gemm_w1_kernel<EPI, VAR>, LDS_BYTES, "fvk_gemm_bf16 (w1)")) return rc;
+    hipLaunchKernelGGL((gemm_w1_kernel<EPI, VAR>), dim3(a.ntm * a.ntn, batch), dim3(256), LDS_BYTES, s, a);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+}  // namespace
+
+namespace fvk {
+
+bool gemm_w1_eligible(const GemmArgs& a) {
+    // on top of gemm_ph_eligible: an even number of 64-element K-steps (the loop body is two K-tiles)
+    return gemm_ph_eligible(a) && a.K % (2 * TK) == 0;
+}
+
+template <int VAR>
+int launch_var(const GemmArgs& a, int epilogue, int batch, hipStream_t s) {
+    switch (epilogue) {
+        case FVK_EPI_NONE: return launch<FVK_EPI_NONE, VAR>(a, batch, s);
+        case FVK_EPI_GELU_TANH: return launch<FVK_EPI_GELU_TANH, VAR>(a, batch, s);
+        case FVK_EPI_SILU: return launch<FVK_EPI_SILU, VAR>(a, batch, s);
+        case FVK_EPI_DIV: return launch<FVK_EPI_DIV, VAR>(a, batch, s);
+        default: return launch<FVK_EPI_RESIDUAL_GATE, VAR>(a, batch, s);
+    }
+}
+
+int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
+    a.ntm = (a.M + TM - 1) / TM;
+    a.ntn = (a.N + TN - 1) / TN;
+    // shipped configuration = VAR 7 (16x16x32 MFMAs, early fragment reads, one barrier per two phases); gemm_impl = 5 + 8 * VAR selects
+    // a measurement variant (5 = VAR 0: 32x32x16 MFMAs — byte-identical to gemm_ph.hip)
+    const int impl = fvk::tunable(fvk::TUNE_GEMM_IMPL);
+#if FVK_VARIANTS
+    switch ((impl & 7) == 5 ? impl >> 3 : 7) {
+        case 0: return launch_var<0>(a, epilogue, batch, s);
+        case 1: return launch_var<1>(a, epilogue, batch, s);
+        case 2: return launch_var<2>(a, epilogue, batch, s);
+        case 3: return launch_var<3>(a, epilogue, batch, s);
+        case 4: return launch_var<4>(a, epilogue, batch, s);
+        case 5: return launch_var<5>(a, epilogue, batch, s);
+        case 6: return launch_var<6>(a, epilogue, batch, s);
+        default: break;
+    }
+#endif
+    (void)impl;
+    return launch_var<7>(a, epilogue, batch, s);
+}
+
+}  // namespace fvk

@@ -7,7 +7,9 @@ import torch
 from fastvideo_amd import ops
 impls = [int(x) for x in sys.argv[1:]] or [0, 2]
 S, d, F = 32760, 1536, 8960
-for name, M, N, K in (("qkv", S, 3 * d, d), ("ffn_in", S, F, d), ("ffn_out", S, d, F), ("8k", 8192, 8192, 8192)):
+S14, d14, F14 = 75600, 5120, 13824
+for name, M, N, K in (("qkv", S, 3 * d, d), ("out", S, d, d), ("ffn_in", S, F, d), ("ffn_out", S, d, F), ("8k", 8192, 8192, 8192),
+                      ("14b_qkv", S14, 3 * d14, d14), ("14b_ffn_in", S14, F14, d14), ("14b_ffn_out", S14, d14, F14)):
     a = torch.randn(M, K, device="cuda").bfloat16(); w = (torch.randn(N, K, device="cuda") * K**-0.5).bfloat16()
     out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     res = {i: [] for i in impls}
@@ -21,4 +23,13 @@ for name, M, N, K in (("qkv", S, 3 * d, d), ("ffn_in", S, F, d), ("ffn_out", S, 
             e.record(); torch.cuda.synchronize()
             res[i].append(s.elapsed_time(e) / 5)
     ops.set_tunable("gemm_impl", 0)
-    print(name, json.dumps({f"impl{i}_tflops": round(2.0 * M * N * K / sorted(v)[1] / 1e9, 1) for i, v in res.items()}))
+    tl = []  # the vendor library through torch (x @ w^T, plain epilogue)
+    for r in range(3):
+        torch.matmul(a, w.t(), out=out); torch.cuda.synchronize()
+        s_, e_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s_.record()
+        for _ in range(5): torch.matmul(a, w.t(), out=out)
+        e_.record(); torch.cuda.synchronize()
+        tl.append(s_.elapsed_time(e_) / 5)
+    res["_torch"] = tl
+    print(name, json.dumps({f"impl{i}_tflops".replace("impl_torch", "torch"): round(2.0 * M * N * K / sorted(v)[1] / 1e9, 1) for i, v in res.items()}))

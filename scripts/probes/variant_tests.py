@@ -124,18 +124,21 @@ def tunables(ops):
 
 
 def test_gemm_kernels_agree(ops, tunables):
-    """The two GEMM kernels accumulate 16-k MFMA steps in the same order: identical outputs except for the GELU formulation."""
+    """gemm_ph (gemm_impl 228 = its shipped schedule) and the 128x128 kernel accumulate 16-k MFMA steps in the same order: identical outputs
+    except for the GELU formulation; the shipped gemm_w1 (32-k MFMA steps) agrees to rounding."""
     M, N, K, B = 600, 768, 256, 2
     x, w, b = rnd((M, K), 1), rnd((N, K), 2, K**-0.5), rnd((N, ), 3)
     res, gate = rnd((M, N), 4, 2.0), rnd((B, N), 5, 0.5, torch.float32)
     outs = {}
-    for impl in (0, 1):
+    for impl in (228, 1, 0):
         tunables("gemm_impl", impl)
         outs[impl] = [ops.gemm(x.to(DEV), w.to(DEV), b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
                                gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None).cpu()
                       for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_RESIDUAL_GATE, ops.EPI_GELU_TANH)]
     for i in range(3):
-        assert torch.equal(outs[0][i], outs[1][i]), f"epilogue #{i}: kernels disagree"
+        assert torch.equal(outs[228][i], outs[1][i]), f"epilogue #{i}: kernels disagree"
+        close(outs[0][i], outs[228][i], atol=3e-2, rtol=2e-2, what=f"gemm_w1 vs gemm_ph, epilogue #{i}")
+    outs[0] = outs[228]
     close(outs[0][3], outs[1][3], atol=1e-2, rtol=1e-2, what="gelu formulations")
     y = _lin_ref(x, w, b)
     close(outs[0][3], W.gelu_tanh(y), what="gelu (pp)")
@@ -154,17 +157,29 @@ def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
     res, gate = rnd((Mb, N), 4, 2.0), rnd((B, N), 5, 0.5, torch.float32)
     xd = rnd((Mb, 2 * K), 1).to(DEV)[:, K // 2:K // 2 + K]  # row stride 2K
     outs = {}
-    for impl in (0, 2, 1252):  # shipped gemm_ph | gemm_pp | gemm_ph persistent
+    for impl in (228, 2, 1252, 5, 13, 21, 29, 0, 61):  # gemm_ph shipped | gemm_pp | gemm_ph persistent | gemm_w1 with 32x32x16 MFMAs | shipped gemm_w1
         tunables("gemm_impl", impl)
         outs[impl] = [ops.gemm(xd, w.to(DEV), b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
                                gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None).cpu()
                       for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_GELU_TANH, ops.EPI_RESIDUAL_GATE)]
         xb, wb = rnd((2, 150, K), 7), rnd((2, 140, K), 8)
         outs[impl].append(ops.gemm_batched(xb.to(DEV), wb.to(DEV), ops.EPI_DIV, 11.0).cpu())
-    for impl in (2, 1252):
-        for i, (a_, b_) in enumerate(zip(outs[0], outs[impl])):
+    for impl in (2, 1252, 5, 13, 21, 29):
+        for i, (a_, b_) in enumerate(zip(outs[228], outs[impl])):
             assert torch.equal(a_, b_), f"impl {impl}, output #{i}"
+    for i, (a_, b_) in enumerate(zip(outs[0], outs[61])):
+        assert torch.equal(a_, b_), f"shipped gemm_w1 is variant 61, output #{i}"
+    outs[0] = outs[228]
     close(outs[0][0], _lin_ref(x, w, b), what=f"gemm_ph {Mb}x{N}x{K}")
+    # gemm_w1 with 16x16x32 MFMAs (K = 32 per instruction): another summation order inside the MFMA, so equal only to rounding
+    for impl in (37, 45, 53, 61):
+        tunables("gemm_impl", impl)
+        got = [ops.gemm(xd, w.to(DEV), b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
+                        gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None).cpu()
+               for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_GELU_TANH, ops.EPI_RESIDUAL_GATE)]
+        for i, (a_, b_) in enumerate(zip(outs[0], got)):
+            close(b_, a_, atol=3e-2, rtol=2e-2, what=f"impl {impl}, output #{i}")
+        assert (got[0].float() - outs[0][0].float()).abs().mean() < 1e-3
 
 
 @pytest.mark.parametrize("impl", [0, 1, 2, 3, 99, 202])
