@@ -147,23 +147,23 @@ def cpu_baseline(cfg, latent_shape, S, L_text, kind="auto"):
 
 
 def attention_traffic_from_profiles():
-    """HBM-side bytes per launch of the dominant kernel from the newest committed PMC pass (profiles/*pmc_attn_w64*.json, written by
+    """HBM-side bytes per launch of the dominant kernel from the newest committed PMC pass (profiles/*pmc_attn_w16*.json, written by
     scripts/pmc_traffic.sh from `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE` passes with the gfx950 x2 FETCH correction; counters cannot be
     collected inside the timed run).  A pass only counts if it recorded the sha256 of the kernel source it measured and that still matches
     the source in the tree: a stale number is reported as null, never silently."""
     import glob
     import hashlib
-    src = os.path.join(ROOT, "fastvideo_amd", "csrc", "attn_w64.hip")
+    src = os.path.join(ROOT, "fastvideo_amd", "csrc", "attn_w16.hip")
     cur = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
     best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attn_w64*.json"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_attn_w16*.json"))):
         try:
             j = json.load(open(f))
         except Exception:  # noqa: BLE001
             continue
         if j.get("kernel_source_sha256") == cur and j.get("traffic_bytes_per_launch"):
             best = (j["traffic_bytes_per_launch"], os.path.basename(f), j.get("GRBM_GUI_ACTIVE_sum"))
-    return best if best else (None, "no PMC pass for the current attn_w64.hip (run scripts/pmc_traffic.sh)", None)
+    return best if best else (None, "no PMC pass for the current attn_w16.hip (run scripts/pmc_traffic.sh)", None)
 
 
 def vae_cpu_baseline(latent_shape, budget_frames=2):
@@ -389,7 +389,7 @@ def main():
     if args.attention == "dense":
         # launches may differ in head count (pipelined SP exchange: two head chunks per layer): total FLOPs / total time
         flops_launch = sum(4.0 * sq_ * skv_ * h_ * cfg.head_dim for _, _, sq_, skv_, h_ in events) / len(events)
-        kname = "attn_w64_kernel (dense self-attention: 4 waves x 64 query rows, one wave per SIMD, 64-key sub-tiles software-pipelined in the wave)"
+        kname = "attn_w16_kernel (dense self-attention: 4 waves x 64 query rows, one wave per SIMD, 16x16x32 MFMAs, 64-key sub-tiles software-pipelined in the wave)"
     else:
         # sparse modes: the algorithmic work is the selected fraction of the dense score matrix (VSA: top-k of the 64-token blocks
         # + the coarse branch, negligible; STA: the window's share of key tokens); the timed region is the whole attention

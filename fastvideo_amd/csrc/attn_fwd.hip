@@ -22,12 +22,14 @@
 #include "attn_lists.h"
 
 int fvk_attn_pp_launch(const fvk_attn_args* a, int variant, hipStream_t s);  // attn_pp.hip
-int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s); // attn_w64.hip
-int fvk_attn_w64_split_launch(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, hipStream_t s);
+int fvk_attn_w16_launch(const fvk_attn_args* a, int variant, hipStream_t s); // attn_w16.hip
+int fvk_attn_w16_split_launch(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, hipStream_t s);
 int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s);   // attn_pp2.hip
 int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);
-#if FVK_VARIANTS
-int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);  // attn_w64.hip, measurement build
+#if FVK_VARIANTS  // scripts/probes/attn_w64.hip (the 32x32x16 predecessor of attn_w16.hip), measurement build
+int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s);
+int fvk_attn_w64_split_launch(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, hipStream_t s);
+int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);
 #endif
 int fvk_attn_vsa_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
                         hipStream_t s);  // attn_vsa.hip: 64-row lists, key-split, register-staged prefetch
@@ -516,12 +518,14 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
         return launch<4, MODE_DENSE, 384>(a, ma, (hipStream_t)stream);
     }
     const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);  // constant 0 in the product library
-    // full-length query blocks: 0 = attn_w64.hip (shipped since round 3: 4 waves x 64 query rows, one wave per SIMD — every K / V^T fragment
-    // read from LDS feeds two MFMAs); measurement build: 1 = this file's 4-wave kernel, 2..98 = attn_pp.hip (64-key tiles), 99 = attn_pp2.hip
-    // (the 8-wave ping-pong kernel shipped in rounds 1-2, still the kernel behind fvk_attn_tile_lists_bf16), 100.. its probe / schedule
-    // variants and timing ablations (attn_pp2.hip: fvk_attn_pp2_launch(impl - 99)), 200.. attn_w64 variants
+    // full-length query blocks: 0 = attn_w16.hip (shipped since round 3: 4 waves x 64 query rows, one wave per SIMD, 16x16x32 MFMAs — every
+    // K / V^T fragment read from LDS feeds four MFMAs); measurement build: 1 = this file's 4-wave kernel, 2..98 = attn_pp.hip (64-key tiles),
+    // 99 = attn_pp2.hip (the 8-wave ping-pong kernel shipped in rounds 1-2, still the kernel behind fvk_attn_tile_lists_bf16), 100.. its probe
+    // / schedule variants and timing ablations (attn_pp2.hip: fvk_attn_pp2_launch(impl - 99)), 200.. attn_w64 (attn_w16's 32x32x16
+    // predecessor) and its variants, 300.. attn_w16 variants
     if (a->Sq >= 256) {
 #if FVK_VARIANTS
+        if (impl >= 300 && impl < 400) return fvk_attn_w16_launch(a, impl - 300, (hipStream_t)stream);
         if (impl >= 200 && impl < 300) return fvk_attn_w64_launch(a, impl - 200, (hipStream_t)stream);
         if (impl >= 99) return fvk_attn_pp2_launch(a, impl - 99, (hipStream_t)stream);
         if (impl >= 2) return fvk_attn_pp_launch(a, impl - 1, (hipStream_t)stream);
@@ -529,7 +533,7 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
         // short key axes (the DiT's cross-attention: 512 text keys) stay on the 8-wave kernel: attn_w64's exposed first sub-tile and tail
         // cost more than its leaner stream saves below ~3 000 keys (same box, 32 760 x 12 queries: 512 keys 126 vs 154 us, 1024: 204 vs 220,
         // 2048: 360 vs 364, 4096: 680 vs 656)
-        if (impl == 0) return a->Skv < 3072 ? fvk_attn_pp2_launch(a, 0, (hipStream_t)stream) : fvk_attn_w64_launch(a, 0, (hipStream_t)stream);
+        if (impl == 0) return a->Skv < 3072 ? fvk_attn_pp2_launch(a, 0, (hipStream_t)stream) : fvk_attn_w16_launch(a, 0, (hipStream_t)stream);
     }
     ModeArgs ma{};
     return launch<4, MODE_DENSE>(a, ma, (hipStream_t)stream);
@@ -542,7 +546,10 @@ extern "C" int fvk_attn_dense_split_bf16(const fvk_attn_args* a, int n_split, fl
               "fvk_attn_dense_split_bf16: head_dim 128 and Sq >= 256 only (Sq=%d, qk_dim=%d)", a->Sq, a->qk_dim);
     FVK_CHECK(n_split >= 2 && n_split <= 64 && o_part && lse_part, FVK_ERR_ARG, "fvk_attn_dense_split_bf16: n_split=%d (2..64) / null workspace", n_split);
     FVK_CHECK((long)((a->Sq + 255) / 256) * a->H * a->B * n_split < 0x7fffffffL, FVK_ERR_ARG, "fvk_attn_dense_split_bf16: grid too large");
-    return fvk_attn_w64_split_launch(a, n_split, o_part, lse_part, (hipStream_t)stream);
+#if FVK_VARIANTS
+    if (fvk::tunable(fvk::TUNE_ATTN_IMPL) == 200) return fvk_attn_w64_split_launch(a, n_split, o_part, lse_part, (hipStream_t)stream);
+#endif
+    return fvk_attn_w16_split_launch(a, n_split, o_part, lse_part, (hipStream_t)stream);
 }
 
 extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,

@@ -1,5 +1,5 @@
 // KV block lists shared by a run of query rows (fvk_attn_tile_lists_bf16: sliding-tile windows in tile-major order): the argument block the
-// list modes of attn_pp2.hip (8-wave kernel, rounds 1-2) and attn_w64.hip (4 waves x 64 rows, round 3) take.
+// list modes of attn_pp2.hip (8-wave kernel, rounds 1-2) and scripts/probes/attn_w64.hip (4 waves x 64 rows, round 3, measurement build) take.
 #pragma once
 #include <stdint.h>
 

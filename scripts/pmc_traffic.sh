@@ -1,14 +1,14 @@
 #!/bin/bash
-# PMC passes for the dominant kernel of the contract bench (attn_w64_kernel at the cfg2 self-attention shape; KERNEL=attn_pp2 for the round-1/2 kernel), each in its OWN rocprofv3
+# PMC passes for the dominant kernel of the contract bench (attn_w16_kernel at the cfg2 self-attention shape; KERNEL=attn_pp2 for the round-1/2 kernel), each in its OWN rocprofv3
 # run with --kernel-trace only (never combined with other trace domains), as guides/MI355X_MICROARCH.md prescribes:
 #   FETCH_SIZE | WRITE_SIZE | GRBM_GUI_ACTIVE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 # Writes gpurun_out/pmc/<tag>/pmc_<kernel>.json (copy to profiles/<round>_pmc_<kernel>.json) with the gfx950 FETCH correction (x2 for wide
 # streaming reads), the effective clock (GRBM_GUI_ACTIVE per XCD / kernel duration) and the sha256 of the kernel source measured — bench.py
 # only reports `roofline.traffic` from a pass whose hash matches the source in the tree.
-# usage: scripts/pmc_traffic.sh <tag>            (KERNEL=attn_w64 | attn_pp2, default attn_w64 = the kernel fvk_attn_dense_bf16 ships)
+# usage: scripts/pmc_traffic.sh <tag>            (KERNEL=attn_w16 | attn_w64 | attn_pp2, default attn_w16 = the kernel fvk_attn_dense_bf16 ships)
 set -u
 TAG=${1:-r3}
-export KERNEL=${KERNEL:-attn_w64}
+export KERNEL=${KERNEL:-attn_w16}
 cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/pmc/$TAG
@@ -26,7 +26,7 @@ done
 python - "$OUT" <<'PY'
 import csv, glob, hashlib, json, os, sys, collections
 out = sys.argv[1]
-KERNEL = os.environ.get("KERNEL", "attn_w64")
+KERNEL = os.environ.get("KERNEL", "attn_w16")
 ctr = collections.defaultdict(list)
 dur = []
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):

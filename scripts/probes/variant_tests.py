@@ -182,11 +182,12 @@ def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
         assert (got[0].float() - outs[0][0].float()).abs().mean() < 1e-3
 
 
-@pytest.mark.parametrize("impl", [0, 1, 2, 3, 99, 202])
+@pytest.mark.parametrize("impl", [0, 1, 2, 3, 99, 200, 202, 300, 302])
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 700), (2, 3, 512, 130), (1, 1, 256, 64), (1, 2, 1030, 1999)])
 def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
-    """attn_impl 0 = attn_w64 (shipped), 202 = the same in hardware workgroup order, 99 = attn_pp2, 2 / 3 = attn_pp (64-key tiles, two
-    DMA placements), 1 = the 4-wave kernel; ragged Sq / Skv tails, 1..32 KV tiles."""
+    """attn_impl 0 = the shipped choice (attn_pp2 below 3072 keys, attn_w16 above), 300 = attn_w16 forced, 302 = the same in hardware workgroup
+    order, 200 / 202 = attn_w64 (its 32x32x16 predecessor), 99 = attn_pp2, 2 / 3 = attn_pp (64-key tiles, two DMA placements), 1 = the 4-wave
+    kernel; ragged Sq / Skv tails, 1..32 KV tiles."""
     tunables("attn_impl", impl)
     q, k, v = rnd((B, Sq, H, 128), 1), rnd((B, Skv, H, 128), 2), rnd((B, Skv, H, 128), 3)
     ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
@@ -213,14 +214,15 @@ def test_attn_pp2_schedules_are_bit_identical(ops, tunables):
     for impl, lst in outs.items():
         for o in lst:
             assert torch.equal(o, outs[99][0]), f"attn_impl {impl} differs from attn_pp2's final schedule"
-    # the shipped dense kernel (attn_w64: fixed softmax reference, different rounding points) agrees with it to rounding
-    tunables("attn_impl", 0)
-    o64 = ops.attn_dense(qd, kd, vd, layout="bshd").cpu()
-    _attn_check(o64, ref, "attn_w64 (shipped)")
-    assert (o64.float() - outs[99][0].float()).abs().max().item() < 2e-2
+    # attn_w16 (shipped above 3072 keys: fixed softmax reference, 32-k MFMA steps, row sums of the bf16 P) and attn_w64 agree with it to rounding
+    for impl in (300, 200):
+        tunables("attn_impl", impl)
+        o64 = ops.attn_dense(qd, kd, vd, layout="bshd").cpu()
+        _attn_check(o64, ref, f"attn_impl {impl}")
+        assert (o64.float() - outs[99][0].float()).abs().max().item() < 2e-2
 
 
-@pytest.mark.parametrize("impl", [0, 2, 3, 99])
+@pytest.mark.parametrize("impl", [0, 2, 3, 99, 200, 300])
 def test_attn_pp_rescale_branch_and_repeatability(ops, tunables, impl):
     """Spiked keys force the running-max rescale in late tiles of the ping-pong kernel; 3 launches must agree bit-for-bit
     (a race between the staggered wave groups or an early LDS read would show up as run-to-run differences)."""

@@ -239,8 +239,8 @@ def test_attn_dense_softmax_rescale_branch(ops):
 
 
 @pytest.mark.parametrize("B,H,Sq,Skv,spike", [(1, 2, 700, 3100, 0), (2, 3, 512, 3073, 0), (1, 1, 300, 4000, 1), (1, 2, 1030, 3200, 2), (1, 12, 256, 8192, 0)])
-def test_attn_dense_long_keys_w64(ops, B, H, Sq, Skv, spike):
-    """Key axes of 3072 and more take attn_w64 (4 waves x 64 rows, fixed softmax reference): ragged Sq / Skv tails (masked last stage, one
+def test_attn_dense_long_keys_w16(ops, B, H, Sq, Skv, spike):
+    """Key axes of 3072 and more take attn_w16 (4 waves x 64 rows, 16x16x32 MFMAs, fixed softmax reference, row sums from the matrix pipe): ragged Sq / Skv tails (masked last stage, one
     valid key in the last stage), odd stage counts, a spiked key far beyond the first sub-tile's maximum (growth ~2^98: the row's exact
     recompute) and one beyond any fp32 range (x20: every row of that head), repeatability, and the LSE."""
     q, k, v = rnd((B, Sq, H, 128), Sq), rnd((B, Skv, H, 128), Skv), rnd((B, Skv, H, 128), 3)
@@ -251,7 +251,7 @@ def test_attn_dense_long_keys_w64(ops, B, H, Sq, Skv, spike):
     ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
     o, lse = ops.attn_dense(qd, kd, vd, layout="bshd", return_lse=True, key_splits=1)
-    _attn_check(o, ref, f"attn_w64 {B},{H},{Sq},{Skv} spike {spike}")
+    _attn_check(o, ref, f"attn_w16 {B},{H},{Sq},{Skv} spike {spike}")
     s2 = (q.float().transpose(1, 2) @ k.float().transpose(1, 2).transpose(-1, -2)) * (128**-0.5 * 1.4426950408889634)
     lse_ref = torch.logsumexp(s2 * 0.6931471805599453, -1) * 1.4426950408889634
     assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
@@ -273,7 +273,10 @@ def test_attn_dense_key_splits(ops, B, H, Sq, Skv, splits):
     os_, ls = ops.attn_dense(qd, kd, vd, layout="bshd", return_lse=True, key_splits=splits)
     _attn_check(os_, ref, f"split-KV x{splits} {B},{H},{Sq},{Skv}")
     assert (os_.float() - o1.float()).abs().max().item() < 4e-2   # both are within the attention bound of the reference
-    assert torch.isfinite(ls).all() and (ls - l1).abs().max().item() < 1e-3
+    # the row sums are sums of the bf16-rounded probabilities — the values the numerator uses, so a run's O_r * 2^lse_r is exact and the merge is
+    # self-consistent — which leaves each reported LSE with P's rounding (~2^-9 relative on l, ~3e-3 in log2 units; measured <= 7.1e-3 between
+    # the split and the un-split walk of a spiked row)
+    assert torch.isfinite(ls).all() and (ls - l1).abs().max().item() < 1e-2
     # the automatic choice leaves a grid that fills the chip alone and cuts one that does not
     assert ops.attn_key_splits(1536, 256) == 1 and ops.attn_key_splits(192, 256) == 4 and ops.attn_key_splits(384, 256) == 2
     assert ops.attn_key_splits(192, 8) == 1 and ops.attn_key_splits(432, 72) == 1   # too few stages / a grid that is full enough
