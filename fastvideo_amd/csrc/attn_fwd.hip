@@ -530,10 +530,10 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
         if (impl >= 99) return fvk_attn_pp2_launch(a, impl - 99, (hipStream_t)stream);
         if (impl >= 2) return fvk_attn_pp_launch(a, impl - 1, (hipStream_t)stream);
 #endif
-        // short key axes (the DiT's cross-attention: 512 text keys) stay on the 8-wave kernel: attn_w64's exposed first sub-tile and tail
-        // cost more than its leaner stream saves below ~3 000 keys (same box, 32 760 x 12 queries: 512 keys 126 vs 154 us, 1024: 204 vs 220,
-        // 2048: 360 vs 364, 4096: 680 vs 656)
-        if (impl == 0) return a->Skv < 3072 ? fvk_attn_pp2_launch(a, 0, (hipStream_t)stream) : fvk_attn_w16_launch(a, 0, (hipStream_t)stream);
+        // short key axes (the DiT's cross-attention: 512 text keys) stay on the 8-wave kernel: attn_w16's exposed first sub-tile and tail
+        // cost more than its leaner stream saves below ~1 800 keys (same box, 32 760 x 12 queries, us attn_pp2 / attn_w16: 512 keys 130 / 153,
+        // 1024: 213 / 232, 1536: 295 / 303, 2048: 379 / 368, 3072: 541 / 511, 4096: 701 / 656; profiles/r03_attn_short_keys.log)
+        if (impl == 0) return a->Skv < 2048 ? fvk_attn_pp2_launch(a, 0, (hipStream_t)stream) : fvk_attn_w16_launch(a, 0, (hipStream_t)stream);
     }
     ModeArgs ma{};
     return launch<4, MODE_DENSE>(a, ma, (hipStream_t)stream);

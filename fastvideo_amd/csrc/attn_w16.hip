@@ -286,7 +286,12 @@ struct W16 {
             }
             __builtin_amdgcn_sched_barrier(0);  // the MFMA FIRST: everything below runs in its shadow
             if (qb == 3 && !is_ones && L + FD < 32) fr[L % FD] = load_frag(L + FD);
-            if (EVEN == 0 && (m & 7) == 1 && m < 128 && !(ABL & 1)) issue_piece(m >> 3, j);
+            if (!(ABL & 1)) {
+                if (ABL & 8) {  // A/B: the set spread over BOTH iterations — K(j+2) here in the odd one (one piece per 16 MFMAs), V^T(j+1) in the first half of the even one
+                    if (EVEN == 0 && (m & 15) == 1 && m < 128) issue_piece(m >> 4, j);
+                    if (EVEN == 1 && (m & 7) == 1 && m < 64) issue_piece(8 + (m >> 3), j);
+                } else if (EVEN == 0 && (m & 7) == 1 && m < 128) issue_piece(m >> 3, j);
+            }
             if (!(ABL & 4) && m < 128) {
                 const int c = m >> 1;  // the score this chunk pair works on
                 if ((m & 1) == 0) {
@@ -443,8 +448,8 @@ __global__ __launch_bounds__(256, 1) void attn_w16_kernel(fvk_attn_args a, int n
     if (n >= 2) {
         WAIT_ALL()
         BAR()
-        w.iter<0, false>(n - 2, 64, g);
-        w.iter<1, true>(n - 2, v0, g);
+        w.iter<0, false, ABL & 8>(n - 2, 64, g);
+        w.iter<1, true, ABL & 8>(n - 2, v0, g);
         w.flip_slots();
     }
     // ---- tail: P·V(2n-2), softmax of sub-tile 2n-1 (second half of the last stage, masked), P·V(2n-1) --------------------------------------
@@ -551,6 +556,7 @@ int fvk_attn_w16_launch(const fvk_attn_args* a, int variant, hipStream_t s) {
         case 12: return launch_w16<2>(a, s);
         case 14: return launch_w16<4>(a, s);
         case 17: return launch_w16<7>(a, s);
+        case 18: return launch_w16<8>(a, s);
         default: break;
     }
 #endif

@@ -1,4 +1,4 @@
-"""Cross-attention shape (Sq = 32 760 queries, 512 text keys, 12 heads): 8-wave 256-row kernel attn_w64 (attn_impl 0), attn_pp2 (99), 4-wave 128-row kernel (1); L = CROSS_L keys."""
+"""Short key axes (Sq = 32 760 queries, L = CROSS_L keys, 12 heads; the DiT cross-attention has 512): attn_w16 forced (attn_impl 300), attn_pp2 (99), the 4-wave 128-row kernel (1)."""
 import os as _os
 _os.environ.setdefault("FVK_PROBE_LIB", "1")  # A/B switches exist only in the measurement build (scripts/probes/libfvk_probe.so)
 import json, os, sys
@@ -13,7 +13,7 @@ vt = ops.v_transpose(v); o = torch.empty_like(q)
 fl = 4.0 * S * L * H * D
 res = {}
 for r in range(5):
-    for i in (0, 99, 1):
+    for i in (300, 99, 1):
         ops.set_tunable("attn_impl", i)
         ops.attn_dense(q, k, vt=vt, out=o); torch.cuda.synchronize()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

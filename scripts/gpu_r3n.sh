@@ -8,7 +8,7 @@ S, H, D = 32760, 12, 128
 q, k, v = (torch.randn(1, S, H, D, device="cuda").bfloat16() for _ in range(3))
 vt = ops.v_transpose(v); o = torch.empty_like(q)
 fl = 4.0 * S * S * H * D
-impls = [200, 300, 211, 311, 214, 314, 217, 317]
+impls = [300, 318, 311, 314, 317, 312]
 res = {i: [] for i in impls}
 for r in range(4):
     for i in impls:
@@ -25,3 +25,4 @@ for i in impls:
     print(json.dumps({"impl": i, "ms_med": round(ms[len(ms)//2], 4), "tflops_med": round(fl / ms[len(ms)//2] / 1e9, 1), "tflops_all": [round(fl / m / 1e9, 1) for m in res[i]]}))
 PY
 cat gpurun_out/r3n/ablate.log
+FVK_PROBE_LIB=1 timeout 300 python -m pytest scripts/probes/variant_tests.py -q -k "test_attn_dense_impls" 2>&1 | tail -2

@@ -182,10 +182,10 @@ def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
         assert (got[0].float() - outs[0][0].float()).abs().mean() < 1e-3
 
 
-@pytest.mark.parametrize("impl", [0, 1, 2, 3, 99, 200, 202, 300, 302])
+@pytest.mark.parametrize("impl", [0, 1, 2, 3, 99, 200, 202, 300, 302, 318])
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 700), (2, 3, 512, 130), (1, 1, 256, 64), (1, 2, 1030, 1999)])
 def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
-    """attn_impl 0 = the shipped choice (attn_pp2 below 3072 keys, attn_w16 above), 300 = attn_w16 forced, 302 = the same in hardware workgroup
+    """attn_impl 0 = the shipped choice (attn_pp2 below 2048 keys, attn_w16 above), 300 = attn_w16 forced, 302 = the same in hardware workgroup
     order, 200 / 202 = attn_w64 (its 32x32x16 predecessor), 99 = attn_pp2, 2 / 3 = attn_pp (64-key tiles, two DMA placements), 1 = the 4-wave
     kernel; ragged Sq / Skv tails, 1..32 KV tiles."""
     tunables("attn_impl", impl)
@@ -214,7 +214,7 @@ def test_attn_pp2_schedules_are_bit_identical(ops, tunables):
     for impl, lst in outs.items():
         for o in lst:
             assert torch.equal(o, outs[99][0]), f"attn_impl {impl} differs from attn_pp2's final schedule"
-    # attn_w16 (shipped above 3072 keys: fixed softmax reference, 32-k MFMA steps, row sums of the bf16 P) and attn_w64 agree with it to rounding
+    # attn_w16 (shipped above 2048 keys: fixed softmax reference, 32-k MFMA steps, row sums of the bf16 P) and attn_w64 agree with it to rounding
     for impl in (300, 200):
         tunables("attn_impl", impl)
         o64 = ops.attn_dense(qd, kd, vd, layout="bshd").cpu()
