@@ -12,9 +12,15 @@
 //     sustains 2.40 PFLOP/s in the 16x16x32 shape against 2.13 in 32x32x16 (scripts/probes/mfma_rate.cpp, profiles/r03_mfma_shapes.md).
 //     On the same schedule the shape alone is worth +6..8 % here (VAR 3 -> 7).  The summation order inside an instruction differs, so
 //     this kernel agrees with gemm_ph.hip to rounding, not byte for byte (VAR 0..3, the 32x32x16 variants, are byte-identical to it).
-// Measured (same box, interleaved, TFLOP/s, gemm_ph -> this kernel | vendor library plain epilogue): QKV [32760,4608,1536] 1205 -> 1284 | 1116,
-// out-proj [32760,1536,1536] 1149 -> 1224 | 1307, FFN-in [32760,8960,1536] 1157 -> 1188 | 1336, FFN-out [32760,1536,8960] 1357 -> 1448 | 1540,
-// 8192^3 1392 -> 1559 | 1560, 14B FFN-out [75600,5120,13824] 1268 -> 1411 | 1530.
+//   * (VAR bit 3, shipped) the tile walk: 256 PERSISTENT workgroups.  The unit FIFO does not stop at a tile boundary — the last two K-tiles of a
+//     tile's loop stage, and its last two phases read, the first units of the workgroup's next tile, so only a workgroup's first tile has a
+//     prologue (a cold 128-KiB burst per CU otherwise); the epilogue stores straight from the accumulators (w1_direct_epilogue: no LDS, so it
+//     cannot collide with the running stream); and the 256 tiles in flight are one run of consecutive tile ids, 32 per XCD — 40 operand
+//     panels from HBM per round instead of the 96 of eight unrelated XCD chunks (worth +10 % at the 14B shapes, which do not fit the MALL).
+// Measured (same box, interleaved, TFLOP/s, gemm_ph -> this kernel | vendor library plain epilogue; profiles/r03_gemm_w1_ab2.log):
+// QKV [32760,4608,1536] 1155 -> 1210 | 1136, out-proj [32760,1536,1536] 1079 -> 1153 | 1240, FFN-in [32760,8960,1536] 1104 -> 1284 | 1321,
+// FFN-out [32760,1536,8960] 1221 -> 1431 | 1514, 8192^3 1396 -> 1575 | 1535, 14B QKV [75600,15360,5120] 1299 -> 1447 | 1494,
+// 14B FFN-in [75600,13824,5120] 1294 -> 1455 | 1481, 14B FFN-out [75600,5120,13824] 1293 -> 1525 | 1507.
 //
 // A K-tile is four phases (one 64 x 64 quadrant of the wave tile x K = 64: 32 MFMAs 16x16x32, or 16 MFMAs 32x32x16):
 //     phase 4t+0: X0 x W0    4t+1: X0 x W1    4t+2: X1 x W1    4t+3: X1 x W0          (X0 / X1 = the wave's first / second 64 m, W0 / W1 likewise in n)
@@ -23,7 +29,7 @@
 //   * reads unit U(p+1) (8 fragments = the unit's whole K = 64) into the register set that fell free — X0 / X1 have a set each, the two
 //     W sets swap roles every K-tile, hence the loop body of two K-tiles,
 //   * stages one unit by LDS-DMA (4 pieces per wave) into a slot whose reads retired before the last barrier.
-// Shipped schedule (VAR bit 1): ONE barrier per two phases.  Phase p stages U(p+7) into the slot of U(p-1).  WAR: U(p-1) was read in phase
+// Schedule (VAR bit 1, shipped): ONE barrier per two phases.  Phase p stages U(p+7) into the slot of U(p-1).  WAR: U(p-1) was read in phase
 // p-2, i.e. in front of the barrier closing the previous phase pair (reads are retired with lgkmcnt(0) there).  RAW: U(p+7) is read in
 // phase p+6; every wave waits for its own pieces at the barrier closing the pair before (vmcnt(16): the two younger pairs' pieces stay in
 // flight, about 2000-3000 cycles of flight).  Without VAR bit 1: a barrier per phase, phase p stages U(p+8), vmcnt(24).
@@ -44,6 +50,107 @@ using fvk::GemmArgs;
 #define W1_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 #define W1_MFMA16(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 
+// Direct epilogue (VAR bit 3, 16x16x32 accumulators): no LDS bounce.  The w rows of a 32-row group are fed to the two MFMA tiles of the group
+// in the order that leaves lane (l15, g) with EIGHT consecutive output columns — tile 2P row 4g + e = column 32P + 8g + e, tile 2P + 1 the
+// columns + 4 — so a lane stores 16 B per (16-row m block, 32-column group): 64 contiguous bytes per output row and instruction.
+// Rounding points as everywhere: y = bf16(acc + bias), the epilogue on float(y), one more rounding.
+template <int EPI>
+__device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4 (&acc)[8][8], int m0, int n0, int wm, int wn, int lane) {
+    const int l15 = lane & 15, g = lane >> 4;
+    const int ncol = n0 + wn * 128 + 8 * g;  // + 32 P
+    const int mrow = m0 + wm * 128 + l15;    // + 16 mb
+    constexpr bool RG = EPI == FVK_EPI_RESIDUAL_GATE;
+    float b8[4][8];
+#pragma unroll
+    for (int P = 0; P < 4; ++P) {
+        const int n = ncol + 32 * P;
+        if (a.bias && n < a.N) {
+            const bf16x8 bv = ld_bf16x8(a.bias + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b8[P][e] = (float)bv[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) b8[P][e] = 0.f;
+        }
+    }
+    // gated residual: the residual vectors of four m blocks are requested at a time (16 x 16 B per lane in flight; the next tile's first
+    // fragments stay live in registers across the epilogue, so not all 32); the gate rows are loaded once when the wave's 128 rows share a batch
+    bf16x8 resv[RG ? 4 : 1][RG ? 4 : 1];
+    float gt0[RG ? 4 : 1][RG ? 8 : 1];
+    bool gate_uniform = false;
+    auto load_res = [&](int mb0) {
+#pragma unroll
+        for (int i = 0; i < (RG ? 4 : 0); ++i) {
+            int m = mrow + 16 * (mb0 + i);
+            m = m < a.M ? m : a.M - 1;  // clamped addresses: always inside the operand, masked at the store
+#pragma unroll
+            for (int P = 0; P < 4; ++P) {
+                const int n = ncol + 32 * P;
+                resv[i][P] = ld_bf16x8(a.residual + (long)m * a.ldc + (n < a.N ? n : 0));
+            }
+        }
+    };
+    if constexpr (RG) {
+        load_res(0);
+        const int mf = m0 + wm * 128, ml = (mf + 127 < a.M ? mf + 127 : a.M - 1);
+        gate_uniform = a.gate && (mf / a.rows_per_batch == ml / a.rows_per_batch);
+#pragma unroll
+        for (int P = 0; P < 4; ++P) {
+            const int n = ncol + 32 * P;
+            if (gate_uniform) {
+                const float* gp = a.gate + (long)(mf / a.rows_per_batch) * a.N + (n < a.N ? n : 0);
+                const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { gt0[P][e] = g0[e]; gt0[P][4 + e] = g1[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gt0[P][e] = 1.0f;
+            }
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+        const int m = mrow + 16 * mb;
+        if (RG && mb == 4) load_res(4);
+#pragma unroll
+        for (int P = 0; P < 4; ++P) {
+            const int n = ncol + 32 * P;
+            bf16x8 y;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                y[e] = (bf16_t)(acc[2 * P][mb][e] + b8[P][e]);
+                y[4 + e] = (bf16_t)(acc[2 * P + 1][mb][e] + b8[P][4 + e]);
+            }
+            if (m < a.M && n < a.N) {
+                if (EPI == FVK_EPI_GELU_TANH) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = (bf16_t)fvk::gelu_tanh_fast((float)y[e]);
+                } else if (EPI == FVK_EPI_SILU) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = (bf16_t)silu_f32((float)y[e]);
+                } else if (EPI == FVK_EPI_DIV) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fdiv_rn((float)y[e], a.epi_scalar);
+                } else if constexpr (RG) {
+                    float gt[8];
+                    if (gate_uniform || !a.gate) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) gt[e] = gt0[P][e];
+                    } else {
+                        const float* gp = a.gate + (long)(m / a.rows_per_batch) * a.N + n;
+                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { gt[e] = g0[e]; gt[4 + e] = g1[e]; }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fadd_rn((float)resv[mb & 3][P][e], __fmul_rn((float)y[e], gt[e]));
+                }
+                st_bf16x8(a.out + (long)m * a.ldc + n, y);
+            }
+        }
+    }
+}
+
 template <int EPI, int VAR>
 __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -58,50 +165,68 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     a.x += blockIdx.y * a.x_bstride;
     a.w += blockIdx.y * a.w_bstride;
     a.out += blockIdx.y * a.out_bstride;
+    constexpr bool MI16 = (VAR & 4) != 0;
+    constexpr bool DIRECT = MI16 && (VAR & 8) != 0;  // direct epilogue + persistent workgroups (each walks tiles vb, vb + gridDim.x, ...)
     // ---- tile id: XCD-contiguous (block b runs on XCD b % 8), then groups of 8 m-tiles swept along n (as gemm_ph.hip) --------
     const int ntiles = a.ntm * a.ntn;
-    int tile_id;
-    {
-        const int nwg = ntiles, bid = blockIdx.x;
+    // DIRECT: 256 persistent workgroups; in round rho workgroup b (XCD b & 7) takes tile 256 rho + 32 (b & 7) + (b >> 3): the 256 tiles in flight
+    // are ONE run of consecutive ids (8 m-tiles x 32 n-tiles: 40 operand panels from HBM per round instead of the 96 of eight unrelated XCD
+    // chunks), of which every XCD holds 32 consecutive ones (8 m x 4 n: 12 panels through its L2).  vb = the tile id.
+    int vb = DIRECT ? 32 * (int)(blockIdx.x & 7) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (DIRECT && vb >= ntiles) return;  // fewer tiles than workgroups (workgroup-uniform, before any barrier)
+    int m0, n0;
+    auto tile_coords = [&](int bid) {
+        const int nwg = ntiles;
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
-    constexpr int GM = 8;
-    const int per_group = GM * a.ntn;
-    const int gid = tile_id / per_group;
-    const int first_m = gid * GM;
-    const int gsz = (a.ntm - first_m) < GM ? (a.ntm - first_m) : GM;
-    const int in_g = tile_id - gid * per_group;
-    const int pid_m = first_m + in_g % gsz, pid_n = in_g / gsz;
-    const int m0 = pid_m * TM, n0 = pid_n * TN;
+        const int tile_id = DIRECT ? bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = 8;
+        const int per_group = GM * a.ntn;
+        const int gid = tile_id / per_group;
+        const int first_m = gid * GM;
+        const int gsz = (a.ntm - first_m) < GM ? (a.ntm - first_m) : GM;
+        const int in_g = tile_id - gid * per_group;
+        m0 = (first_m + in_g % gsz) * TM;
+        n0 = (in_g / gsz) * TN;
+    };
+    tile_coords(vb);
 
     // ---- LDS-DMA staging: every wave stages 32 consecutive rows (4 pieces of 8 rows x 128 B) of each unit -----------------------
     //   X0: rows (wave>>1)*128 + (wave&1)*32    X1: + 64        W0 / W1: the same rows of the w panel
     const int row0 = (wave >> 1) * 128 + (wave & 1) * 32;
-    int xvalid = a.M - m0, wvalid = a.N - n0;
-    xvalid = xvalid > 256 ? 256 : xvalid;
-    wvalid = wvalid > 256 ? 256 : wvalid;
     const long xld = a.lda * 2, wld = (long)a.K * 2;  // row pitch in bytes
-    const unsigned char* xbase = (const unsigned char*)a.x + (long)m0 * xld;
-    const unsigned char* wbase = (const unsigned char*)a.w + (long)n0 * wld;
     // one descriptor per unit kind, based at the wave's first row of that kind; rows past the operand's valid rows read as zeros
     auto mk = [](const unsigned char* base, long ld, int r0, int valid, int K) {
         const long nrec = valid > r0 ? ((long)(valid - r0) - 1) * ld + (long)K * 2 : 0;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)r0 * ld), 0, (int)nrec, 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t r_x0 = mk(xbase, xld, row0, xvalid, a.K);
-    const __amdgpu_buffer_rsrc_t r_x1 = mk(xbase, xld, row0 + 64, xvalid, a.K);
-    const __amdgpu_buffer_rsrc_t r_w0 = mk(wbase, wld, row0, wvalid, a.K);
-    const __amdgpu_buffer_rsrc_t r_w1 = mk(wbase, wld, row0 + 64, wvalid, a.K);
+    __amdgpu_buffer_rsrc_t r_x0, r_x1, r_w0, r_w1;      // the tile being staged
+    __amdgpu_buffer_rsrc_t rn_x0, rn_x1, rn_w0, rn_w1;  // DIRECT: the workgroup's NEXT tile (the staging stream runs on into it)
+    auto tile_descriptors = [&](int m0_, int n0_, __amdgpu_buffer_rsrc_t& x0_, __amdgpu_buffer_rsrc_t& x1_, __amdgpu_buffer_rsrc_t& w0_,
+                                __amdgpu_buffer_rsrc_t& w1_) {
+        int xvalid = a.M - m0_, wvalid = a.N - n0_;
+        xvalid = xvalid > 256 ? 256 : xvalid;
+        wvalid = wvalid > 256 ? 256 : wvalid;
+        const unsigned char* xbase = (const unsigned char*)a.x + (long)m0_ * xld;
+        const unsigned char* wbase = (const unsigned char*)a.w + (long)n0_ * wld;
+        x0_ = mk(xbase, xld, row0, xvalid, a.K);
+        x1_ = mk(xbase, xld, row0 + 64, xvalid, a.K);
+        w0_ = mk(wbase, wld, row0, wvalid, a.K);
+        w1_ = mk(wbase, wld, row0 + 64, wvalid, a.K);
+    };
+    tile_descriptors(m0, n0, r_x0, r_x1, r_w0, r_w1);
+    int kb = 0;  // DIRECT: byte offset added to a staged K-tile's source offset (-K-extent once the stream has moved on to the next tile)
     // lane -> (row r = lane>>3 of the piece, LDS chunk position lane&7); piece i holds rows 8i + r.  LDS chunk position c' of tile
     // row R holds source chunk c' ^ ((R >> 1) & 7); row0 is a multiple of 32, so (R >> 1) & 7 = 4(i & 1) + (r >> 1).
+    // DIRECT: the w rows use c' ^ (((R >> 1) & 1) | (((R >> 3) & 3) << 1)) = c' ^ (((r >> 1) & 1) | (i << 1)) instead: a w fragment then reads rows
+    // {0-3, 8-11, 16-19, 24-27} (+4) of a 32-row group (see w1_direct_epilogue), which that swizzle spreads over all 16 (parity, position) slots.
     int xv[4], wv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = lane >> 3;
         const int c = (lane & 7) ^ (4 * (i & 1) + (r >> 1));
+        const int cw = DIRECT ? (lane & 7) ^ (((r >> 1) & 1) | (i << 1)) : c;
         xv[i] = (int)((long)(8 * i + r) * xld) + c * 16;
-        wv[i] = (int)((long)(8 * i + r) * wld) + c * 16;
+        wv[i] = (int)((long)(8 * i + r) * wld) + cw * 16;
     }
     const int d_x0 = row0 * ROWB, d_x1 = (row0 + 64) * ROWB;
     const int d_w0 = XREG + row0 * ROWB, d_w1 = XREG + (row0 + 64) * ROWB;
@@ -111,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
 #define W1_STAGE(KIND, TILE, PC)                                                                                      \
     {                                                                                                                 \
         const int t_ = (TILE);                                                                                        \
-        const int so_ = __builtin_amdgcn_readfirstlane(t_ < nt ? t_ * ROWB : 0);                                      \
+        const int so_ = __builtin_amdgcn_readfirstlane(DIRECT ? t_ * ROWB + kb : (t_ < nt ? t_ * ROWB : 0));          \
         unsigned char* d_ = smem + (t_ & 1) * BUF + ((KIND) == 0 ? d_x0 : (KIND) == 1 ? d_w0 : (KIND) == 2 ? d_w1 : d_x1) + (PC) * 1024; \
         if ((KIND) == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_x0, (lds_void*)(d_), 16, xv[PC], so_, 0, 0);      \
         else if ((KIND) == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(r_w0, (lds_void*)(d_), 16, wv[PC], so_, 0, 0); \
@@ -123,7 +248,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     // ---- fragment read offsets (bytes within a buffer).  32x32x16 fragments: row R = l31, k16-step ks, half hi -> chunk (2ks + hi);
     // 16x16x32 fragments (MI16): row R = lane & 15, k32-step ks, quarter q = lane >> 4 -> chunk (4ks + q).  LDS chunk = chunk ^ ((R>>1)&7);
     // a ds_read_b128 is served 16 lanes a cycle over 64 banks: 16 consecutive rows of one chunk are conflict-free in both shapes.
-    constexpr bool MI16 = (VAR & 4) != 0;
     constexpr int NKS = MI16 ? 2 : 4, NBLK = MI16 ? 4 : 2, BLKR = MI16 ? 16 : 32;  // k-steps per K-tile, row blocks per unit, rows per block
     int xo[4], wo[4];
     {
@@ -134,6 +258,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
             const int co = ((MI16 ? 4 * ks + (lane >> 4) : 2 * ks + hi) ^ sw) << 4;
             xo[ks] = (wm * 128 + rl) * ROWB + co;
             wo[ks] = XREG + (wn * 128 + rl) * ROWB + co;
+            if (DIRECT) {  // lane row l15 of a w tile = row 8(l15 >> 2) + (l15 & 3) of its 32-row group (+4 for the group's second tile, in W1_READ1)
+                const int rho = 8 * (rl >> 2) + (rl & 3), sww = ((rl & 3) >> 1) | ((rl >> 2) << 1);
+                wo[ks] = XREG + (wn * 128 + rho) * ROWB + (((4 * ks + (lane >> 4)) ^ sww) << 4);
+            }
         }
     }
 
@@ -159,7 +287,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
 
     // fragment J (0..7: block J % NBLK, k-step J / NBLK) of a unit: IS_X selects the x / w rows, ROW0 (0 / 64) the unit's first row in the wave tile
 #define W1_READ1(DST, BUFP, IS_X, ROW0, J) \
-    DST[J] = *reinterpret_cast<const bf16x8*>((BUFP) + ((IS_X) ? xo[(J) / NBLK] : wo[(J) / NBLK]) + ((ROW0) + ((J) % NBLK) * BLKR) * ROWB);
+    DST[J] = *reinterpret_cast<const bf16x8*>((BUFP) + ((IS_X) ? xo[(J) / NBLK] : wo[(J) / NBLK]) + \
+                                              ((ROW0) + ((DIRECT && !(IS_X)) ? 32 * (((J) % NBLK) >> 1) + 4 * (((J) % NBLK) & 1) : ((J) % NBLK) * BLKR)) * ROWB);
 #define W1_PHASE_END(P)                                                 \
     if (!(VAR & 2)) {                                                   \
         asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");    \
@@ -204,6 +333,23 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     // ---- prologue: both K-tiles' units staged in read order, X0(0) and W0(0) landed and read, X0(2) staged ("phase -1") --------
     W1_STAGE_UNIT(0, 0) W1_STAGE_UNIT(1, 0) W1_STAGE_UNIT(2, 0) W1_STAGE_UNIT(3, 0)
     W1_STAGE_UNIT(0, 1) W1_STAGE_UNIT(1, 1) W1_STAGE_UNIT(2, 1) W1_STAGE_UNIT(3, 1)
+    bool first_tile = true;
+    while (true) {  // tile loop (DIRECT: persistent; otherwise one pass)
+    // DIRECT: the unit FIFO does not stop at a tile boundary — the last two K-tiles of a tile's loop stage (and its last two phases read) the
+    // first units of the workgroup's NEXT tile, so only the first tile has a prologue; what remains between two tiles is the epilogue itself
+    bool more = false;
+    int m0n = m0, n0n = n0;
+    if (DIRECT) {
+        more = vb + 256 < ntiles;  // workgroup-uniform
+        if (more) {
+            const int m0c = m0, n0c = n0;
+            tile_coords(vb + 256);
+            m0n = m0; n0n = n0;
+            m0 = m0c; n0 = n0c;
+        }
+        tile_descriptors(m0n, n0n, rn_x0, rn_x1, rn_w0, rn_w1);  // (no next tile: the stream re-reads this tile's first K-tiles, never consumed)
+    }
+    if (!DIRECT || first_tile) {
     asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
@@ -223,8 +369,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
+    }  // prologue (first tile)
+    first_tile = false;
 
     for (int t = 0; t < nt; t += 2) {  // nt is even (gemm_w1_eligible)
+        if (DIRECT && t == nt - 2) {  // from here on every staged unit belongs to the next tile (K-tiles nt, nt+1 = its K-tiles 0, 1)
+            r_x0 = rn_x0; r_x1 = rn_x1; r_w0 = rn_w0; r_w1 = rn_w1;
+            kb = -nt * ROWB;
+        }
         const unsigned char* b0 = smem + (t & 1) * BUF;  // K-tiles t, t+2
         const unsigned char* b1 = smem + ((t + 1) & 1) * BUF;
         // K-tile t: W0 in WA, W1 in WB.   stage (VAR bit 1 clear): phases 0..3 stage W0(t+2), W1(t+2), X1(t+2), X0(t+3); (set): X0(t+2), W0(t+2), W1(t+2), X1(t+2)
@@ -242,11 +394,29 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         W1_PHASE(3, XB, WB, 0, 1, WA, b0, false, 0)   // read W0(t+2)
 #undef PT
     }
-#undef W1_STAGE
-#undef W1_STAGE_UNIT
-#undef W1_READ1
-#undef W1_PHASE
-#undef W1_PHASE_END
+    if constexpr (DIRECT) {
+        // the accumulators were written by asm MFMAs: the compiler knows no hazard distance to its own reads of them
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc16[i][j]));
+        w1_direct_epilogue<EPI>(a, acc16, m0, n0, wm, wn, lane);
+        // everything this wave has in flight — the next tile's units and the epilogue's stores (they share vmcnt, and reads / writes need not
+        // retire in issue order) — before the counted waits of the next tile's loop, or before the workgroup ends with LDS writes outstanding
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!more) break;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+        vb += 256;
+        m0 = m0n; n0 = n0n;
+        kb = 0;  // (r_* already describe this tile)
+        continue;
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // tail re-reads must have landed before the buffers are reused
     __builtin_amdgcn_s_barrier();
     // the accumulators were written by asm MFMAs: the compiler knows no hazard distance to its own reads of them
@@ -267,14 +437,25 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         fvk::gemm_tile_epilogue<EPI, false, true>(a, reinterpret_cast<f32x16(&)[2][4]>(acc[0]), smem, wm + 2 * (2 * wn), lane, m0, n0);
         fvk::gemm_tile_epilogue<EPI, false, true>(a, reinterpret_cast<f32x16(&)[2][4]>(acc[2]), smem, wm + 2 * (2 * wn + 1), lane, m0, n0);
     }
+    break;
+    }  // tile loop
+#undef W1_STAGE
+#undef W1_STAGE_UNIT
+#undef W1_READ1
+#undef W1_PHASE
+#undef W1_PHASE_END
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
 template <int EPI, int VAR>
 int launch(const GemmArgs& a, int batch, hipStream_t s) {
     static FvkLdsConfigured configured;
-    if (int rc = fvk_config_lds(configured, (const void*)gemm_w1_kernel<EPI, VAR>, LDS_BYTES, "fvk_gemm_bf16 (w1)")) return rc;
-    hipLaunchKernelGGL((gemm_w1_kernel<EPI, VAR>), dim3(a.ntm * a.ntn, batch), dim3(256), LDS_BYTES, s, a);
+    constexpr bool DIRECT = (VAR & 12) == 12;
+    constexpr int lds = DIRECT ? 2 * BUF : LDS_BYTES;  // the direct epilogue needs no staging region
+    if (int rc = fvk_config_lds(configured, (const void*)gemm_w1_kernel<EPI, VAR>, lds, "fvk_gemm_bf16 (w1)")) return rc;
+    const int tiles = a.ntm * a.ntn;
+    const int grid = DIRECT ? 256 : tiles;  // DIRECT: persistent, one workgroup per CU (a workgroup without a tile returns at once)
+    hipLaunchKernelGGL((gemm_w1_kernel<EPI, VAR>), dim3(grid, batch), dim3(256), lds, s, a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -302,11 +483,12 @@ int launch_var(const GemmArgs& a, int epilogue, int batch, hipStream_t s) {
 int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
     a.ntm = (a.M + TM - 1) / TM;
     a.ntn = (a.N + TN - 1) / TN;
-    // shipped configuration = VAR 7 (16x16x32 MFMAs, early fragment reads, one barrier per two phases); gemm_impl = 5 + 8 * VAR selects
-    // a measurement variant (5 = VAR 0: 32x32x16 MFMAs — byte-identical to gemm_ph.hip)
+    // shipped configuration = VAR 15 (16x16x32 MFMAs, early fragment reads, one barrier per two phases, direct epilogue + persistent
+    // workgroups); gemm_impl = 5 + 8 * VAR selects a measurement variant (5 = VAR 0: 32x32x16 MFMAs — byte-identical to gemm_ph.hip;
+    // 61 = VAR 7: the shipped arithmetic with the LDS-bounce epilogue and one workgroup per tile — byte-identical to the shipped kernel)
     const int impl = fvk::tunable(fvk::TUNE_GEMM_IMPL);
 #if FVK_VARIANTS
-    switch ((impl & 7) == 5 ? impl >> 3 : 7) {
+    switch ((impl & 7) == 5 ? impl >> 3 : 15) {
         case 0: return launch_var<0>(a, epilogue, batch, s);
         case 1: return launch_var<1>(a, epilogue, batch, s);
         case 2: return launch_var<2>(a, epilogue, batch, s);
@@ -314,11 +496,12 @@ int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
         case 4: return launch_var<4>(a, epilogue, batch, s);
         case 5: return launch_var<5>(a, epilogue, batch, s);
         case 6: return launch_var<6>(a, epilogue, batch, s);
+        case 7: return launch_var<7>(a, epilogue, batch, s);
         default: break;
     }
 #endif
     (void)impl;
-    return launch_var<7>(a, epilogue, batch, s);
+    return launch_var<15>(a, epilogue, batch, s);
 }
 
 }  // namespace fvk
