@@ -26,8 +26,8 @@ int fvk_attn_w16_launch(const fvk_attn_args* a, int variant, hipStream_t s); // 
 int fvk_attn_w16_split_launch(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, hipStream_t s);
 int fvk_attn_pp2_launch(const fvk_attn_args* a, int probe, hipStream_t s);   // attn_pp2.hip
 int fvk_attn_pp2_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);
-#if FVK_VARIANTS  // scripts/probes/attn_w64.hip (the 32x32x16 predecessor of attn_w16.hip), measurement build
-int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s);
+int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s);  // attn_w64.hip (the same design on 32x32x16 MFMAs)
+#if FVK_VARIANTS  // measurement build
 int fvk_attn_w64_split_launch(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, hipStream_t s);
 int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s);
 #endif
@@ -506,9 +506,10 @@ int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
+static int attn_dense_impl(const fvk_attn_args* a, int kernel, void* stream) {
     int rc = check_common(a, "fvk_attn_dense_bf16");
     if (rc) return rc;
+    FVK_CHECK(kernel >= 0 && kernel <= 2, FVK_ERR_ARG, "fvk_attn_dense_kernel_bf16: kernel=%d (0 default, 1 attn_w16, 2 attn_w64)", kernel);
     // full-length query blocks go to the 8-wave ping-pong kernel (attn_pp.hip); "attn_impl" = 1 forces this 4-wave kernel,
     // 2 / 3 select the alternative DMA placements of the ping-pong kernel (measurement only)
     FVK_CHECK(a->qk_dim == 0 || a->qk_dim == 128 || a->qk_dim == 384, FVK_ERR_ARG, "fvk_attn_dense_bf16: qk_dim=%d unsupported (128 or 384)",
@@ -533,11 +534,23 @@ extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) {
         // short key axes (the DiT's cross-attention: 512 text keys) stay on the 8-wave kernel: attn_w16's exposed first sub-tile and tail
         // cost more than its leaner stream saves below ~1 800 keys (same box, 32 760 x 12 queries, us attn_pp2 / attn_w16: 512 keys 130 / 153,
         // 1024: 213 / 232, 1536: 295 / 303, 2048: 379 / 368, 3072: 541 / 511, 4096: 701 / 656; profiles/r03_attn_short_keys.log)
-        if (impl == 0) return a->Skv < 2048 ? fvk_attn_pp2_launch(a, 0, (hipStream_t)stream) : fvk_attn_w16_launch(a, 0, (hipStream_t)stream);
+        if (impl == 0) {
+            if (a->Skv < 2048) return fvk_attn_pp2_launch(a, 0, (hipStream_t)stream);
+            // long key axes: the one-wave-per-SIMD design, on 16x16x32 MFMAs (attn_w16.hip, the default) or 32x32x16 (attn_w64.hip).  The two
+            // agree to rounding.  attn_w16 needs ~6 % more matrix-pipe cycles and a fifth less energy per FLOP: launched back to back it
+            // settles at a higher clock and is 5 % faster, but between the GEMMs of a DiT block the clock does not always get there within
+            // one 5-ms launch and it can be 5 % slower (profiles/r03_attn_context.md) — the caller may time both in ITS context and choose
+            // (fvk_attn_dense_kernel_bf16; fastvideo_amd/wan_dit.py does, once, in its first forward).
+            return kernel == 2 ? fvk_attn_w64_launch(a, 0, (hipStream_t)stream) : fvk_attn_w16_launch(a, 0, (hipStream_t)stream);
+        }
     }
     ModeArgs ma{};
     return launch<4, MODE_DENSE>(a, ma, (hipStream_t)stream);
 }
+
+extern "C" int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream) { return attn_dense_impl(a, 0, stream); }
+
+extern "C" int fvk_attn_dense_kernel_bf16(const fvk_attn_args* a, int kernel, void* stream) { return attn_dense_impl(a, kernel, stream); }
 
 extern "C" int fvk_attn_dense_split_bf16(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, void* stream) {
     int rc = check_common(a, "fvk_attn_dense_split_bf16");

@@ -557,6 +557,7 @@ int fvk_attn_w16_launch(const fvk_attn_args* a, int variant, hipStream_t s) {
         case 14: return launch_w16<4>(a, s);
         case 17: return launch_w16<7>(a, s);
         case 18: return launch_w16<8>(a, s);
+        case 19: return launch_w16<16>(a, s);  // no exact recompute (timing probe: are rows being redone?)
         default: break;
     }
 #endif

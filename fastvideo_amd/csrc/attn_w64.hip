@@ -672,6 +672,7 @@ int fvk_attn_w64_launch(const fvk_attn_args* a, int variant, hipStream_t s) {
     return launch_w64<true>(a, s);
 }
 
+#if FVK_VARIANTS  // measurement build: the shipped split-KV form is attn_w16's
 // split-KV form (called by fvk_attn_dense_split_bf16, attn_fwd.hip, after its argument checks)
 int fvk_attn_w64_split_launch(const fvk_attn_args* a, int n_split, float* o_part, float* lse_part, hipStream_t s) {
     static FvkLdsConfigured configured;
@@ -685,7 +686,7 @@ int fvk_attn_w64_split_launch(const fvk_attn_args* a, int n_split, float* o_part
     return FVK_OK;
 }
 
-#if FVK_VARIANTS  // measurement build only: attn_fwd.hip (fvk_attn_tile_lists_bf16) says why the list mode is not shipped
+// measurement build only: attn_fwd.hip (fvk_attn_tile_lists_bf16) says why the list mode is not shipped
 // 256-row workgroups over shared KV block lists (called by fvk_attn_tile_lists_bf16, attn_fwd.hip, after its argument checks)
 int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, hipStream_t s) {
     constexpr int LDS_LIST = LDS_BYTES + 2048 * 8;  // + the packed list: up to 2048 stages = 4096 blocks

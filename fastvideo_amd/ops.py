@@ -351,10 +351,14 @@ def attn_key_splits(n_query_blocks: int, n_stages: int) -> int:
     return best
 
 
-def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, return_lse=False, key_splits=None):
+ATTN_KERNEL_DEFAULT, ATTN_KERNEL_W16, ATTN_KERNEL_W64 = 0, 1, 2  # fvk_attn_dense_kernel_bf16: the long-key kernel on 16x16x32 / 32x32x16 MFMAs
+
+
+def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, return_lse=False, key_splits=None, kernel=ATTN_KERNEL_DEFAULT):
     """Dense non-causal attention.  Pass v (same layout as k) or a precomputed vt = v_transpose(v).
     return_lse: also the base-2 log-sum-exp of the scaled scores per query row, fp32 [B, H, Sq] (full-length kernels only: Sq >= 256).
-    key_splits: None = automatic (attn_key_splits: split-KV + merge for grids that do not fill the chip), 1 = never, n = that many runs."""
+    key_splits: None = automatic (attn_key_splits: split-KV + merge for grids that do not fill the chip), 1 = never, n = that many runs.
+    kernel: which long-key kernel (ATTN_KERNEL_*; same result to rounding — see include/fvk_amd.h for when either is faster)."""
     scale = q.shape[-1]**-0.5 if scale is None else scale
     if vt is None:
         vt = _vt_of(v, layout)
@@ -374,8 +378,10 @@ def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, retur
         o_part = torch.empty((key_splits, rows, 128), dtype=torch.float32, device=q.device)
         lse_part = torch.empty((key_splits, rows), dtype=torch.float32, device=q.device)
         _lib.call("fvk_attn_dense_split_bf16", C.byref(a), int(key_splits), _p(o_part), _p(lse_part), _stream())
-    else:
+    elif kernel == ATTN_KERNEL_DEFAULT:
         _lib.call("fvk_attn_dense_bf16", C.byref(a), _stream())
+    else:
+        _lib.call("fvk_attn_dense_kernel_bf16", C.byref(a), int(kernel), _stream())
     return (o, lse) if return_lse else o
 
 

@@ -37,7 +37,7 @@ class WanTransformer3DModelHip:
 
     def __init__(self, state_dict: dict, num_heads: int, head_dim: int = 128, patch_size=(1, 2, 2), eps: float = 1e-6,
                  freq_dim: int = 256, attention: str = "dense", vsa_sparsity: float = 0.8, sta_window=(3, 3, 3),
-                 sta_tile=(6, 8, 8), sp_group=None, device="cuda", quantization: str | None = None):
+                 sta_tile=(6, 8, 8), sp_group=None, device="cuda", quantization: str | None = None, attn_autotune: bool = False):
         if head_dim != 128:
             raise ValueError("the gfx950 attention kernels are specialised for head_dim 128 (Wan2.1 / Wan2.2)")
         if attention not in ("dense", "vsa", "sta"):
@@ -67,6 +67,14 @@ class WanTransformer3DModelHip:
         self.vsa_fold = True  # single GPU: tile(q), tile(k), tile(gate), untile(out) folded into the neighbouring kernels (V keeps its gather)
         self.sta_fold = True  # single GPU: no gather passes at all (q / k scattered by the norm pass, V^T gathered, output scattered)
         self.attn_events = None  # set to a list to collect (start, end, Sq, Skv, heads) HIP-event pairs
+        # Dense self-attention on long key axes has two kernels that agree to rounding (fvk_attn_dense_kernel_bf16: attn_w16 / attn_w64); which
+        # is faster depends on the clock the device reaches between THIS model's other kernels (profiles/r03_attn_context.md).  attn_autotune:
+        # the first forward alternates them layer by layer, times every launch with HIP events, and keeps the faster one from then on (one
+        # synchronisation, once).  Off (default): the library default for every launch, bit-identical forwards from the first one on.
+        self.attn_kernel = ops.ATTN_KERNEL_DEFAULT
+        self.attn_autotune = bool(attn_autotune)
+        self.attn_tune_report = None
+        self._tune = None
         self.vsa_trace = None    # set to a list to collect every layer's VSA block mask (tests)
 
     # ------------------------------------------------------------------ weights
@@ -196,6 +204,21 @@ class WanTransformer3DModelHip:
             self._vsa_cache[key] = bufs
         return bufs
 
+    def _finish_attn_tune(self):
+        """Close the timing forward: the faster long-key kernel (median launch time, the first launch of each left out) is kept."""
+        ev, self._tune = self._tune, None
+        self.attn_autotune = False
+        if len(ev) < 6:  # too few long-key launches to compare (short sequences take the 8-wave kernel anyway)
+            return
+        torch.cuda.synchronize()
+        ms = {ops.ATTN_KERNEL_W16: [], ops.ATTN_KERNEL_W64: []}
+        for kern, e0, e1 in ev[2:]:
+            ms[kern].append(e0.elapsed_time(e1))
+        med = {kk: sorted(v)[len(v) // 2] for kk, v in ms.items()}
+        self.attn_kernel = min(med, key=med.get)
+        self.attn_tune_report = {"attn_w16_ms": round(med[ops.ATTN_KERNEL_W16], 4), "attn_w64_ms": round(med[ops.ATTN_KERNEL_W64], 4),
+                                 "launches_timed": len(ev) - 2, "kept": "attn_w16" if self.attn_kernel == ops.ATTN_KERNEL_W16 else "attn_w64"}
+
     def _attn_local(self, q, k, v, kv_len, grid, gate=None):
         if self.attn_events is None or self.attention == "dense":
             return self._attn_local_impl(q, k, v, kv_len, grid, gate)
@@ -212,14 +235,22 @@ class WanTransformer3DModelHip:
         q4, k4, v4 = q.unsqueeze(0), k[:kv_len].unsqueeze(0), v[:kv_len].unsqueeze(0)
         if self.attention == "dense":
             vt = ops.v_transpose(v4)
-            if self.attn_events is None:
-                return ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd")[0]
-            # bench.py roofline leg: HIP events on the launch stream around the dominant kernel only
+            kern, tune = self.attn_kernel, self._tune
+            if tune is not None and q4.shape[1] >= 256 and k4.shape[1] >= 2048:
+                kern = (ops.ATTN_KERNEL_W16, ops.ATTN_KERNEL_W64)[len(tune) % 2]
+            elif tune is not None:
+                tune = None
+            if self.attn_events is None and tune is None:
+                return ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd", kernel=kern)[0]
+            # bench.py roofline leg / the in-place kernel choice: HIP events on the launch stream around the dominant kernel only
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            o = ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd")[0]
+            o = ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd", kernel=kern)[0]
             e1.record()
-            self.attn_events.append((e0, e1, q4.shape[1], k4.shape[1], q4.shape[2]))
+            if self.attn_events is not None:
+                self.attn_events.append((e0, e1, q4.shape[1], k4.shape[1], q4.shape[2]))
+            if tune is not None:
+                tune.append((kern, e0, e1))
             return o
         if self.attention == "vsa":
             # ref: VideoSparseAttentionImpl.preprocess_qkv / forward / postprocess_output (video_sparse_attn.py:254-342)
@@ -420,6 +451,8 @@ class WanTransformer3DModelHip:
         sp = self.sp
         P, rank = sp.lay.P, sp.lay.rank
         cos, sin = rope.get_rotary_pos_embed(grid, D, device=dev)
+        if self.attn_autotune and self.attention == "dense" and P == 1:
+            self._tune = []  # this forward times the two long-key attention kernels in place (see __init__)
 
         # patch embedding (Conv3d k=s=patch == GEMM over patch rows), then shard the token axis
         x = ops.gemm(ops.patchify(hidden_states.to(BF16), self.patch).view(B * S, -1), w["pe_w"], w["pe_b"]).view(B, S, d)
@@ -544,6 +577,8 @@ class WanTransformer3DModelHip:
             trace["norm_out"] = x.clone()
         y = ops.gemm(x.reshape(B * S, d), w["proj_out.w"], w["proj_out.b"])
         c_out = y.shape[-1] // (pt * ph * pw)
+        if self._tune is not None:
+            self._finish_attn_tune()
         return ops.unpatchify(y.view(B, S, -1), (B, c_out, T, Hh, W), self.patch)
 
     __call__ = forward

@@ -173,8 +173,16 @@ typedef struct {
                    ref: WanAttentionBlock.forward, fastvideo/models/vaes/wanvae.py:479-507) */
 } fvk_attn_args;
 
-/* dense: ref fastvideo/attention/backends/sdpa.py:122-147 / flash_attn.py:247-345 (the path replaced). */
+/* dense: ref fastvideo/attention/backends/sdpa.py:122-147 / flash_attn.py:247-345 (the path replaced).
+ * lse of the long-key kernel (Skv >= 2048): the row sum is the sum of the bf16-rounded probabilities (the values the numerator uses), i.e.
+ * accurate to ~2^-9 relative (3e-3 in log2 units), not to fp32 rounding. */
 int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream);
+/* The same call with the long-key kernel named: kernel 0 = the default (1), 1 = attn_w16 (16x16x32 MFMAs: less energy per FLOP, ~6 % more
+ * matrix-pipe cycles), 2 = attn_w64 (32x32x16 MFMAs).  Same result to rounding (different summation order inside the MFMA; kernel 2 sums the
+ * fp32 probabilities for lse).  Which is faster depends on the clock the device reaches in the CALLER'S launch sequence: back to back kernel 1
+ * is ~5 % faster, between the GEMMs of a DiT block it is anywhere from 5 % faster to 5 % slower (profiles/r03_attn_context.md); a caller that
+ * cares times both in place once.  Key axes below 2048 ignore the choice (8-wave kernel). */
+int fvk_attn_dense_kernel_bf16(const fvk_attn_args* a, int kernel, void* stream);
 /* The same attention with the KEY axis cut into n_split runs of whole 128-key stages, each (query block, head, batch, run) its own workgroup,
  * and a merge pass: for grids too small to fill the 256 CUs — the per-rank shapes of sequence parallelism (SP = 8 on Wan2.1-1.3B: 3 heads x
  * 64 query blocks = 192 workgroups of 256 rows; 4 runs make 768 = three full rounds).  Workspace (device, overwritten): o_part fp32

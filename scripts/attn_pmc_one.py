@@ -1,4 +1,4 @@
-"""One attention kernel variant at the cfg2 shape for PMC passes: ATTN_IMPL=<attn_impl> (0 = attn_w16, the shipped kernel; 200 = attn_w64; 99 = attn_pp2), N_LAUNCH launches."""
+"""One attention kernel variant at the cfg2 shape for PMC passes: ATTN_IMPL=<attn_impl> (0 = the shipped default attn_w16; 200 = attn_w64; 99 = attn_pp2), N_LAUNCH launches."""
 import os as _os
 _os.environ.setdefault("FVK_PROBE_LIB", "1")
 import os, sys

@@ -16,7 +16,7 @@ mkdir -p "$OUT"
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  ATTN_IMPL=$([ "$KERNEL" = attn_pp2 ] && echo 99 || echo 0) N_LAUNCH=3 timeout ${PASS_TIMEOUT:-120} rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/p$i" -o pmc -- python scripts/attn_pmc_one.py > "$OUT/p$i.log" 2>&1 < /dev/null
+  ATTN_IMPL=$([ "$KERNEL" = attn_pp2 ] && echo 99 || ([ "$KERNEL" = attn_w64 ] && echo 200 || echo 0)) N_LAUNCH=3 timeout ${PASS_TIMEOUT:-120} rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/p$i" -o pmc -- python scripts/attn_pmc_one.py > "$OUT/p$i.log" 2>&1 < /dev/null
   rc=$?
   echo "pass $i ($SET) rc=$rc"
   # a pass that faults or hangs (seen once: "Memory access fault" inside rocprofv3's own start-up on a box whose GPU then hung every later

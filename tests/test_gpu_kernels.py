@@ -259,6 +259,27 @@ def test_attn_dense_long_keys_w16(ops, B, H, Sq, Skv, spike):
     assert torch.equal(o, o2)
 
 
+def test_attn_dense_kernel_choice(ops):
+    """fvk_attn_dense_kernel_bf16: the long-key kernel on 16x16x32 (1, the default) or 32x32x16 MFMAs (2) — both within the attention bound of
+    the fp32 reference and within rounding of each other, with a spiked key (each one's exact recompute) and a ragged tail; below 2048 keys
+    the choice is ignored (8-wave kernel: bit-identical outputs); an unknown kernel id is refused."""
+    B, H, Sq, Skv = 1, 3, 700, 2600
+    q, k, v = rnd((B, Sq, H, 128), 1), rnd((B, Skv, H, 128), 2), rnd((B, Skv, H, 128), 3)
+    k[0, 2500, 1] = q[0, 300, 1] * 6
+    ref = W.attention_fp32_ref(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), 128**-0.5).transpose(1, 2)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    outs = {kk: ops.attn_dense(qd, kd, vd, layout="bshd", kernel=kk, return_lse=True) for kk in (0, 1, 2)}
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])   # 0 = the default = 1
+    for kk in (1, 2):
+        _attn_check(outs[kk][0], ref, f"long-key kernel {kk}")
+    assert (outs[1][0].float() - outs[2][0].float()).abs().max().item() < 2e-2
+    assert (outs[1][1] - outs[2][1]).abs().max().item() < 1e-2   # lse: sums of bf16 vs fp32 probabilities
+    short = [ops.attn_dense(qd, kd[:, :1500], vd[:, :1500], layout="bshd", kernel=kk) for kk in (0, 1, 2)]
+    assert torch.equal(short[0], short[1]) and torch.equal(short[0], short[2])
+    with pytest.raises(RuntimeError, match="kernel=3"):
+        ops.attn_dense(qd, kd, vd, layout="bshd", kernel=3)
+
+
 @pytest.mark.parametrize("B,H,Sq,Skv,splits", [(1, 3, 512, 4096, 4), (2, 2, 300, 2500, 3), (1, 1, 256, 1000, 8), (1, 2, 1030, 5000, 2), (1, 2, 256, 300, 5)])
 def test_attn_dense_key_splits(ops, B, H, Sq, Skv, splits):
     """fvk_attn_dense_split_bf16: the key axis cut into runs of whole 128-key stages (one workgroup per run) + the LSE-weighted merge — the form

@@ -200,3 +200,35 @@ def test_loader_builds_the_same_model_from_safetensors(tiny, tmp_path, golden_di
             y2 = WanTransformer3DModelHip(tiny["state_dict"], num_heads=tiny["config"]["num_heads"], quantization="fp8")(
                 c["latent"].cuda(), c["ctx"].cuda(), c["timestep"].cuda())
             assert torch.equal(y, y2) and not torch.equal(y, ref)
+
+
+def test_attention_kernel_choice_in_place():
+    """attn_autotune: the first forward alternates the two long-key dense attention kernels (attn_w16 / attn_w64: the same arithmetic to
+    rounding) layer by layer, times every launch, and keeps the faster; every later forward is bit-identical to the next; the result stays
+    within rounding of the model that never tunes (library default for every launch)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from fastvideo_amd import ops, wan_config as WC
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    cfg = WC.WanConfig("tune-test", 2, 128, 512, 8)
+    sd = WC.random_state_dict(cfg, seed=3, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(5)
+    latent = torch.randn((1, 16, 4, 48, 64), generator=g, device="cuda").bfloat16()   # 4 x 24 x 32 = 3072 tokens: the long-key kernels
+    ctx = torch.randn((1, 512, cfg.text_dim), generator=g, device="cuda").bfloat16()
+    ts = torch.tensor([400.0], device="cuda")
+    plain = WanTransformer3DModelHip(sd, cfg.num_heads, cfg.head_dim, cfg.patch_size, cfg.eps, cfg.freq_dim)
+    y_off = plain(latent, ctx, ts)
+    assert plain.attn_tune_report is None and plain.attn_kernel == ops.ATTN_KERNEL_DEFAULT and torch.equal(plain(latent, ctx, ts), y_off)
+    model = WanTransformer3DModelHip(sd, cfg.num_heads, cfg.head_dim, cfg.patch_size, cfg.eps, cfg.freq_dim, attn_autotune=True)
+    y1 = model(latent, ctx, ts)
+    rep = model.attn_tune_report
+    assert rep and rep["kept"] in ("attn_w16", "attn_w64") and rep["launches_timed"] == cfg.num_layers - 2 and rep["attn_w16_ms"] > 0 < rep["attn_w64_ms"]
+    assert model.attn_kernel in (ops.ATTN_KERNEL_W16, ops.ATTN_KERNEL_W64) and model._tune is None and not model.attn_autotune
+    y2, y3 = model(latent, ctx, ts), model(latent, ctx, ts)
+    assert torch.equal(y2, y3)
+    for y, what in ((y1, "timing forward"), (y2, "after the choice")):
+        d = (y.float() - y_off.float()).abs()
+        assert d.max().item() < 0.1 * y_off.float().abs().max().item() and d.mean().item() < 1e-2 * y_off.float().abs().mean().item(), \
+            f"{what}: max {d.max().item():.4g} mean {d.mean().item():.4g}"
+    if rep["kept"] == "attn_w16":
+        assert torch.equal(y2, y_off)   # the default kernel
