@@ -37,6 +37,8 @@ int gemm_ph_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
 // gemm_w1.hip (gemm_ph's tile and unit FIFO with four 128 x 128 waves, one per SIMD; gemm_impl 5)
 bool gemm_w1_eligible(const GemmArgs& a);
 int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
+bool gemm_w1_fp8_eligible(const GemmArgs& a);
+int gemm_w1_fp8_launch(GemmArgs a, int epilogue, hipStream_t s);  // fvk_gemm_fp8 on the same kernel (16x16x128 MX-fp8 MFMAs)
 
 // Integer knobs for within-process A/B measurements (fvk_set_tunable).  They exist only in the MEASUREMENT build of the library
 // (scripts/probes/libfvk_probe.so, compiled with -DFVK_PROBE_BUILD by fastvideo_amd/_build.py: build_probe): there FVK_VARIANTS is 1,

@@ -49,12 +49,23 @@ using fvk::GemmArgs;
 
 #define W1_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 #define W1_MFMA16(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+typedef int w1_v8i __attribute__((ext_vector_type(8)));
+typedef int w1_v4i __attribute__((ext_vector_type(4)));
+// fp8: the two 16-B halves of each operand's 32-B fragment; unit block scales (E8M0 0x7F = 1.0)
+#define W1_MFMA_FP8(ACC, A0, A1, B0, B1)                                                                                           \
+    {                                                                                                                              \
+        const w1_v4i a0_ = __builtin_bit_cast(w1_v4i, A0), a1_ = __builtin_bit_cast(w1_v4i, A1);                                   \
+        const w1_v4i b0_ = __builtin_bit_cast(w1_v4i, B0), b1_ = __builtin_bit_cast(w1_v4i, B1);                                   \
+        const w1_v8i wa_ = {a0_[0], a0_[1], a0_[2], a0_[3], a1_[0], a1_[1], a1_[2], a1_[3]};                                       \
+        const w1_v8i xa_ = {b0_[0], b0_[1], b0_[2], b0_[3], b1_[0], b1_[1], b1_[2], b1_[3]};                                       \
+        ACC = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa_, xa_, ACC, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);                 \
+    }
 
 // Direct epilogue (VAR bit 3, 16x16x32 accumulators): no LDS bounce.  The w rows of a 32-row group are fed to the two MFMA tiles of the group
 // in the order that leaves lane (l15, g) with EIGHT consecutive output columns — tile 2P row 4g + e = column 32P + 8g + e, tile 2P + 1 the
 // columns + 4 — so a lane stores 16 B per (16-row m block, 32-column group): 64 contiguous bytes per output row and instruction.
 // Rounding points as everywhere: y = bf16(acc + bias), the epilogue on float(y), one more rounding.
-template <int EPI>
+template <int EPI, bool FP8 = false>
 __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4 (&acc)[8][8], int m0, int n0, int wm, int wn, int lane) {
     const int l15 = lane & 15, g = lane >> 4;
     const int ncol = n0 + wn * 128 + 8 * g;  // + 32 P
@@ -72,6 +83,16 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
 #pragma unroll
             for (int e = 0; e < 8; ++e) b8[P][e] = 0.f;
         }
+    }
+    float sb8[FP8 ? 4 : 1][FP8 ? 8 : 1];  // fp8: the weight scales of the lane's 32 columns
+    if constexpr (FP8) {
+#pragma unroll
+        for (int P = 0; P < 4; ++P)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int n = ncol + 32 * P + e;
+                sb8[P][e] = a.scale_b_rowwise ? (n < a.N ? a.scale_b[n] : 0.f) : a.scale_b[0];
+            }
     }
     // gated residual: the residual vectors of four m blocks are requested at a time (16 x 16 B per lane in flight; the next tile's first
     // fragments stay live in registers across the epilogue, so not all 32); the gate rows are loaded once when the wave's 128 rows share a batch
@@ -116,10 +137,21 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
         for (int P = 0; P < 4; ++P) {
             const int n = ncol + 32 * P;
             bf16x8 y;
+            if (FP8) {
+                // ref: torch._scaled_mm(x_fp8, w_fp8.t(), scale_a, scale_b, out_dtype=bf16) then `out + bias` in bf16
+                // (fastvideo/layers/quantization/fp8_config.py:141-152): two roundings
+                const float sa = a.scale_a_rowwise ? (m < a.M ? a.scale_a[m] : 0.f) : a.scale_a[0];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                y[e] = (bf16_t)(acc[2 * P][mb][e] + b8[P][e]);
-                y[4 + e] = (bf16_t)(acc[2 * P + 1][mb][e] + b8[P][4 + e]);
+                for (int e = 0; e < 8; ++e) {
+                    const float y0 = (float)(bf16_t)((e < 4 ? acc[2 * P][mb][e] : acc[2 * P + 1][mb][e - 4]) * (sa * sb8[P][e]));
+                    y[e] = a.bias ? (bf16_t)(y0 + b8[P][e]) : (bf16_t)y0;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = (bf16_t)(acc[2 * P][mb][e] + b8[P][e]);
+                    y[4 + e] = (bf16_t)(acc[2 * P + 1][mb][e] + b8[P][4 + e]);
+                }
             }
             if (m < a.M && n < a.N) {
                 if (EPI == FVK_EPI_GELU_TANH) {
@@ -151,7 +183,10 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
     }
 }
 
-template <int EPI, int VAR>
+// FP8 (fvk_gemm_fp8, VAR 15 only): x and w are OCP e4m3 bytes; an LDS row is still 128 B = 128 k, a K-tile is ONE k-step of
+// v_mfma_scale_f32_16x16x128_f8f6f4 (unit block scales; 2x the bf16 MFMA rate), a fragment is 32 B per lane = two 16-B chunk reads, and the
+// dequantisation scales are applied in the epilogue (gemm_pp.hip's FP8 contract).
+template <int EPI, int VAR, bool FP8 = false>
 __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -193,10 +228,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     // ---- LDS-DMA staging: every wave stages 32 consecutive rows (4 pieces of 8 rows x 128 B) of each unit -----------------------
     //   X0: rows (wave>>1)*128 + (wave&1)*32    X1: + 64        W0 / W1: the same rows of the w panel
     const int row0 = (wave >> 1) * 128 + (wave & 1) * 32;
-    const long xld = a.lda * 2, wld = (long)a.K * 2;  // row pitch in bytes
+    constexpr int ES = FP8 ? 1 : 2;  // bytes per operand element
+    static_assert(!FP8 || (VAR & 12) == 12, "the fp8 path exists in the shipped (direct, persistent) configuration only");
+    const long xld = a.lda * ES, wld = (long)a.K * ES;  // row pitch in bytes
     // one descriptor per unit kind, based at the wave's first row of that kind; rows past the operand's valid rows read as zeros
     auto mk = [](const unsigned char* base, long ld, int r0, int valid, int K) {
-        const long nrec = valid > r0 ? ((long)(valid - r0) - 1) * ld + (long)K * 2 : 0;
+        const long nrec = valid > r0 ? ((long)(valid - r0) - 1) * ld + (long)K * ES : 0;
         return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (long)r0 * ld), 0, (int)nrec, 0x00020000);
     };
     __amdgpu_buffer_rsrc_t r_x0, r_x1, r_w0, r_w1;      // the tile being staged
@@ -230,7 +267,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     }
     const int d_x0 = row0 * ROWB, d_x1 = (row0 + 64) * ROWB;
     const int d_w0 = XREG + row0 * ROWB, d_w1 = XREG + (row0 + 64) * ROWB;
-    const int nt = a.K / TK;
+    const int nt = a.K * ES / ROWB;  // K-tiles of 128 B per row: 64 bf16 / 128 fp8 elements
 
     // kinds: 0 = X0, 1 = W0, 2 = W1, 3 = X1.  One piece (PC) of unit KIND of K-tile TILE; tiles past the end re-read tile 0 (never consumed)
 #define W1_STAGE(KIND, TILE, PC)                                                                                      \
@@ -255,12 +292,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         const int sw = (rl >> 1) & 7;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            const int co = ((MI16 ? 4 * ks + (lane >> 4) : 2 * ks + hi) ^ sw) << 4;
+            // (FP8: `ks` is the 16-B half of the lane's 32-B fragment: chunks 2q, 2q + 1)
+            const int co = ((FP8 ? 2 * (lane >> 4) + ks : MI16 ? 4 * ks + (lane >> 4) : 2 * ks + hi) ^ sw) << 4;
             xo[ks] = (wm * 128 + rl) * ROWB + co;
             wo[ks] = XREG + (wn * 128 + rl) * ROWB + co;
             if (DIRECT) {  // lane row l15 of a w tile = row 8(l15 >> 2) + (l15 & 3) of its 32-row group (+4 for the group's second tile, in W1_READ1)
                 const int rho = 8 * (rl >> 2) + (rl & 3), sww = ((rl & 3) >> 1) | ((rl >> 2) << 1);
-                wo[ks] = XREG + (wn * 128 + rho) * ROWB + (((4 * ks + (lane >> 4)) ^ sww) << 4);
+                wo[ks] = XREG + (wn * 128 + rho) * ROWB + (((FP8 ? 2 * (lane >> 4) + ks : 4 * ks + (lane >> 4)) ^ sww) << 4);
             }
         }
     }
@@ -286,9 +324,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     bf16x8 XA[8], XB[8], WA[8], WB[8];  // fragment sets, in the order a phase consumes them: [ks * NBLK + block]
 
     // fragment J (0..7: block J % NBLK, k-step J / NBLK) of a unit: IS_X selects the x / w rows, ROW0 (0 / 64) the unit's first row in the wave tile
+    // (FP8: fragment J = 16-B half J & 1 of block J >> 1)
+#define W1_KS(J) (FP8 ? (J) & 1 : (J) / NBLK)
+#define W1_BLK(J) (FP8 ? (J) >> 1 : (J) % NBLK)
 #define W1_READ1(DST, BUFP, IS_X, ROW0, J) \
-    DST[J] = *reinterpret_cast<const bf16x8*>((BUFP) + ((IS_X) ? xo[(J) / NBLK] : wo[(J) / NBLK]) + \
-                                              ((ROW0) + ((DIRECT && !(IS_X)) ? 32 * (((J) % NBLK) >> 1) + 4 * (((J) % NBLK) & 1) : ((J) % NBLK) * BLKR)) * ROWB);
+    DST[J] = *reinterpret_cast<const bf16x8*>((BUFP) + ((IS_X) ? xo[W1_KS(J)] : wo[W1_KS(J)]) + \
+                                              ((ROW0) + ((DIRECT && !(IS_X)) ? 32 * (W1_BLK(J) >> 1) + 4 * (W1_BLK(J) & 1) : W1_BLK(J) * BLKR)) * ROWB);
 #define W1_PHASE_END(P)                                                 \
     if (!(VAR & 2)) {                                                   \
         asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");    \
@@ -306,8 +347,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     // slots 0..7 and the 4 pieces slots 8, 10, 12, 14 (else a read in every odd slot, a piece in every fourth); VAR bit 1: one barrier
     // per TWO phases (phase p stages U(p+7) and the wait is vmcnt(16)).  P = phase number within the K-tile; NQ / MQ = the quadrant.
 #define W1_PHASE(P, XS, WS, NQ, MQ, RDST, RBUF, RIS_X, ROW0)                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < (MI16 ? 32 : 16); ++i_) {                                   \
-        if (MI16) {                                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < ((MI16 && !FP8) ? 32 : 16); ++i_) {                         \
+        if (FP8) {                                                                                      \
+            const int nb_ = i_ >> 2, mb_ = i_ & 3;                                                      \
+            W1_MFMA_FP8(acc16[((NQ) * 4 + nb_) & (MI16 ? 7 : 0)][((MQ) * 4 + mb_) & (MI16 ? 7 : 0)], WS[2 * nb_], WS[2 * nb_ + 1], XS[2 * mb_], XS[2 * mb_ + 1]); \
+        } else if (MI16) {                                                                              \
             const int ks_ = i_ >> 4, nb_ = (i_ >> 2) & 3, mb_ = i_ & 3;                                 \
             W1_MFMA16(acc16[((NQ) * 4 + nb_) & (MI16 ? 7 : 0)][((MQ) * 4 + mb_) & (MI16 ? 7 : 0)], WS[ks_ * 4 + nb_], XS[ks_ * 4 + mb_]); \
         } else {                                                                                        \
@@ -316,8 +360,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         }                                                                                               \
         constexpr int sk_ = (VAR & 2) ? ((P) == 0 ? 0 : (P) == 1 ? 1 : (P) == 2 ? 2 : 3) : ((P) == 0 ? 1 : (P) == 1 ? 2 : (P) == 2 ? 3 : 0); \
         const int st_ = t + (PT) + 2 + ((!(VAR & 2) && (P) == 3) ? 1 : 0);                              \
-        if (!MI16 || (i_ & 1)) {                                                                        \
-            const int sl_ = MI16 ? i_ >> 1 : i_;                                                        \
+        if (!MI16 || FP8 || (i_ & 1)) {                                                                 \
+            const int sl_ = (MI16 && !FP8) ? i_ >> 1 : i_;                                              \
             if (VAR & 1) {                                                                              \
                 if (sl_ < 8) { W1_READ1(RDST, RBUF, RIS_X, ROW0, sl_ & 7) }                             \
                 else if ((sl_ & 1) == 0) W1_STAGE(sk_, st_, ((sl_ - 8) >> 1) & 3)                       \
@@ -401,7 +445,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc16[i][j]));
-        w1_direct_epilogue<EPI>(a, acc16, m0, n0, wm, wn, lane);
+        w1_direct_epilogue<EPI, FP8>(a, acc16, m0, n0, wm, wn, lane);
         // everything this wave has in flight — the next tile's units and the epilogue's stores (they share vmcnt, and reads / writes need not
         // retire in issue order) — before the counted waits of the next tile's loop, or before the workgroup ends with LDS writes outstanding
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -442,20 +486,22 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
 #undef W1_STAGE
 #undef W1_STAGE_UNIT
 #undef W1_READ1
+#undef W1_KS
+#undef W1_BLK
 #undef W1_PHASE
 #undef W1_PHASE_END
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int EPI, int VAR>
+template <int EPI, int VAR, bool FP8 = false>
 int launch(const GemmArgs& a, int batch, hipStream_t s) {
     static FvkLdsConfigured configured;
     constexpr bool DIRECT = (VAR & 12) == 12;
     constexpr int lds = DIRECT ? 2 * BUF : LDS_BYTES;  // the direct epilogue needs no staging region
-    if (int rc = fvk_config_lds(configured, (const void*)gemm_w1_kernel<EPI, VAR>, lds, "fvk_gemm_bf16 (w1)")) return rc;
+    if (int rc = fvk_config_lds(configured, (const void*)gemm_w1_kernel<EPI, VAR, FP8>, lds, FP8 ? "fvk_gemm_fp8 (w1)" : "fvk_gemm_bf16 (w1)")) return rc;
     const int tiles = a.ntm * a.ntn;
     const int grid = DIRECT ? 256 : tiles;  // DIRECT: persistent, one workgroup per CU (a workgroup without a tile returns at once)
-    hipLaunchKernelGGL((gemm_w1_kernel<EPI, VAR>), dim3(grid, batch), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((gemm_w1_kernel<EPI, VAR, FP8>), dim3(grid, batch), dim3(256), lds, s, a);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -477,6 +523,22 @@ int launch_var(const GemmArgs& a, int epilogue, int batch, hipStream_t s) {
         case FVK_EPI_SILU: return launch<FVK_EPI_SILU, VAR>(a, batch, s);
         case FVK_EPI_DIV: return launch<FVK_EPI_DIV, VAR>(a, batch, s);
         default: return launch<FVK_EPI_RESIDUAL_GATE, VAR>(a, batch, s);
+    }
+}
+
+bool gemm_w1_fp8_eligible(const GemmArgs& a) {
+    // whole double K-tiles of 128 fp8 elements, more than half a tile of rows, 32-bit offsets inside one 256-row panel
+    return a.K % 256 == 0 && a.M > 128 && a.N % 8 == 0 && a.ldc % 8 == 0 && a.lda % 16 == 0 && 255L * a.lda + a.K <= 0x7fffffffL;
+}
+
+int gemm_w1_fp8_launch(GemmArgs a, int epilogue, hipStream_t s) {
+    a.ntm = (a.M + TM - 1) / TM;
+    a.ntn = (a.N + TN - 1) / TN;
+    switch (epilogue) {
+        case FVK_EPI_NONE: return launch<FVK_EPI_NONE, 15, true>(a, 1, s);
+        case FVK_EPI_GELU_TANH: return launch<FVK_EPI_GELU_TANH, 15, true>(a, 1, s);
+        case FVK_EPI_SILU: return launch<FVK_EPI_SILU, 15, true>(a, 1, s);
+        default: return launch<FVK_EPI_RESIDUAL_GATE, 15, true>(a, 1, s);
     }
 }
 

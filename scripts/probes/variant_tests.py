@@ -184,6 +184,25 @@ def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
         assert (got[0].float() - outs[0][0].float()).abs().mean() < 1e-3
 
 
+@pytest.mark.parametrize("M,N,K,rowwise", [(700, 520, 512, False), (1030, 264, 1536, True), (300, 1000, 256, False)])
+def test_gemm_fp8_w1_and_pp_agree(ops, tunables, M, N, K, rowwise):
+    """fvk_gemm_fp8 on gemm_w1's kernel (16x16x128 MX-fp8 MFMAs, the default for K % 256 == 0) and on gemm_pp's (32x32x64, gemm_impl 2): the
+    same products summed in another order — equal to a bf16 ulp — for every epilogue, with ragged M / N tiles and per-row / per-channel scales."""
+    x, w, b = rnd((M, K), 1), rnd((N, K), 2, K**-0.5), rnd((N, ), 3)
+    res, gate = rnd((M, N), 4, 2.0), rnd((2, N), 5, 0.5, torch.float32)
+    xq, xs = ops.fp8_quantize(x.to(DEV), rowwise=rowwise)
+    wq, ws = ops.fp8_quantize(w.to(DEV), rowwise=rowwise)
+    outs = {}
+    for impl in (2, 0):
+        tunables("gemm_impl", impl)
+        outs[impl] = [ops.gemm_fp8(xq, xs, wq, ws, b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
+                                   gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None, rows_per_batch=M // 2 if e == ops.EPI_RESIDUAL_GATE else None).cpu()
+                      for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_GELU_TANH, ops.EPI_RESIDUAL_GATE)]
+    for i, (a_, b_) in enumerate(zip(outs[2], outs[0])):
+        close(b_, a_, atol=3e-2, rtol=2e-2, what=f"fp8 epilogue #{i}")
+        assert (a_.float() - b_.float()).abs().mean().item() < 1e-3
+
+
 @pytest.mark.parametrize("impl", [0, 1, 2, 3, 99, 200, 202, 300, 302, 318])
 @pytest.mark.parametrize("B,H,Sq,Skv", [(1, 2, 700, 700), (2, 3, 512, 130), (1, 1, 256, 64), (1, 2, 1030, 1999)])
 def test_attn_dense_impls(ops, tunables, impl, B, H, Sq, Skv):
