@@ -35,6 +35,9 @@
 // flight, about 2000-3000 cycles of flight).  Without VAR bit 1: a barrier per phase, phase p stages U(p+8), vmcnt(24).
 #include "gemm_common.h"
 #include "gemm_epilogue.h"
+#ifndef W1_ABL
+#define W1_ABL 0  // measurement builds (FVK_EXTRA_FLAGS=-DW1_ABL=n): 1 = epilogue without stores, 2 = no wait for the stores after the epilogue (UNSAFE)
+#endif
 
 namespace {
 
@@ -65,7 +68,7 @@ typedef int w1_v4i __attribute__((ext_vector_type(4)));
 // in the order that leaves lane (l15, g) with EIGHT consecutive output columns — tile 2P row 4g + e = column 32P + 8g + e, tile 2P + 1 the
 // columns + 4 — so a lane stores 16 B per (16-row m block, 32-column group): 64 contiguous bytes per output row and instruction.
 // Rounding points as everywhere: y = bf16(acc + bias), the epilogue on float(y), one more rounding.
-template <int EPI, bool FP8 = false>
+template <int EPI, bool FP8 = false, bool NT = false>
 __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4 (&acc)[8][8], int m0, int n0, int wm, int wn, int lane) {
     const int l15 = lane & 15, g = lane >> 4;
     const int ncol = n0 + wn * 128 + 8 * g;  // + 32 P
@@ -177,7 +180,12 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fadd_rn((float)resv[mb & 3][P][e], __fmul_rn((float)y[e], gt[e]));
                 }
-                st_bf16x8(a.out + (long)m * a.ldc + n, y);
+#if W1_ABL != 1  // (timing ablation 1: the epilogue without its stores)
+                if (NT) __builtin_nontemporal_store(y, reinterpret_cast<bf16x8*>(a.out + (long)m * a.ldc + n));  // streaming store (VAR bit 7)
+                else st_bf16x8(a.out + (long)m * a.ldc + n, y);
+#else
+                asm volatile("" :: "v"(y));
+#endif
             }
         }
     }
@@ -209,6 +217,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     // chunks), of which every XCD holds 32 consecutive ones (8 m x 4 n: 12 panels through its L2).  vb = the tile id.
     int vb = DIRECT ? 32 * (int)(blockIdx.x & 7) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (DIRECT && vb >= ntiles) return;  // fewer tiles than workgroups (workgroup-uniform, before any barrier)
+    if (DIRECT && (VAR & 96)) {
+        // A/B: staggered start.  Equal tiles keep all 256 workgroups in lockstep, so all 256 epilogues hit HBM in the same few microseconds (the
+        // chip-wide write rate they ask for is the HBM peak) while the store path idles through every main loop.  Workgroup b waits
+        // (b & 63) / 64 of a spread (VAR bits 5-6: ~4 / ~8 / ~16 us) before its first tile; the offsets persist from tile to tile.
+        const int units = (int)(blockIdx.x & 63) * ((VAR & 96) == 32 ? 1 : (VAR & 96) == 64 ? 2 : 4);  // units of 128 cycles
+        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(2);
+    }
     int m0, n0;
     auto tile_coords = [&](int bid) {
         const int nwg = ntiles;
@@ -445,17 +460,25 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" : "+a"(acc16[i][j]));
-        w1_direct_epilogue<EPI, FP8>(a, acc16, m0, n0, wm, wn, lane);
+        if (!(VAR & 16)) w1_direct_epilogue<EPI, FP8, (VAR & 128) != 0>(a, acc16, m0, n0, wm, wn, lane);  // VAR bit 4: timing ablation (no epilogue, no output)
         // everything this wave has in flight — the next tile's units and the epilogue's stores (they share vmcnt, and reads / writes need not
         // retire in issue order) — before the counted waits of the next tile's loop, or before the workgroup ends with LDS writes outstanding
+        if (more) {  // (the accumulators are re-zeroed while the stores drain)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+                    asm volatile("" : "+a"(acc16[i][j]));
+                }
+        }
+#if W1_ABL != 2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+        if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         if (!more) break;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
         vb += 256;
         m0 = m0n; n0 = n0n;
         kb = 0;  // (r_* already describe this tile)
@@ -531,15 +554,20 @@ bool gemm_w1_fp8_eligible(const GemmArgs& a) {
     return a.K % 256 == 0 && a.M > 128 && a.N % 8 == 0 && a.ldc % 8 == 0 && a.lda % 16 == 0 && 255L * a.lda + a.K <= 0x7fffffffL;
 }
 
+template <int VAR>
+int launch_fp8_var(const GemmArgs& a, int epilogue, hipStream_t s) {
+    switch (epilogue) {
+        case FVK_EPI_NONE: return launch<FVK_EPI_NONE, VAR, true>(a, 1, s);
+        case FVK_EPI_GELU_TANH: return launch<FVK_EPI_GELU_TANH, VAR, true>(a, 1, s);
+        case FVK_EPI_SILU: return launch<FVK_EPI_SILU, VAR, true>(a, 1, s);
+        default: return launch<FVK_EPI_RESIDUAL_GATE, VAR, true>(a, 1, s);
+    }
+}
+
 int gemm_w1_fp8_launch(GemmArgs a, int epilogue, hipStream_t s) {
     a.ntm = (a.M + TM - 1) / TM;
     a.ntn = (a.N + TN - 1) / TN;
-    switch (epilogue) {
-        case FVK_EPI_NONE: return launch<FVK_EPI_NONE, 15, true>(a, 1, s);
-        case FVK_EPI_GELU_TANH: return launch<FVK_EPI_GELU_TANH, 15, true>(a, 1, s);
-        case FVK_EPI_SILU: return launch<FVK_EPI_SILU, 15, true>(a, 1, s);
-        default: return launch<FVK_EPI_RESIDUAL_GATE, 15, true>(a, 1, s);
-    }
+    return a.N >= 4096 ? launch_fp8_var<143>(a, epilogue, s) : launch_fp8_var<15>(a, epilogue, s);  // streaming stores for wide outputs, as the bf16 path
 }
 
 int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
@@ -550,7 +578,7 @@ int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
     // 61 = VAR 7: the shipped arithmetic with the LDS-bounce epilogue and one workgroup per tile — byte-identical to the shipped kernel)
     const int impl = fvk::tunable(fvk::TUNE_GEMM_IMPL);
 #if FVK_VARIANTS
-    switch ((impl & 7) == 5 ? impl >> 3 : 15) {
+    switch ((impl & 7) == 5 ? impl >> 3 : -1) {
         case 0: return launch_var<0>(a, epilogue, batch, s);
         case 1: return launch_var<1>(a, epilogue, batch, s);
         case 2: return launch_var<2>(a, epilogue, batch, s);
@@ -559,11 +587,19 @@ int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
         case 5: return launch_var<5>(a, epilogue, batch, s);
         case 6: return launch_var<6>(a, epilogue, batch, s);
         case 7: return launch_var<7>(a, epilogue, batch, s);
+        case 31: return launch_var<31>(a, epilogue, batch, s);  // timing ablation: no epilogue
+        case 143: return launch_var<143>(a, epilogue, batch, s);  // streaming (nontemporal) output stores
+        case 15: return launch_var<15>(a, epilogue, batch, s);
+        case 47: return launch_var<47>(a, epilogue, batch, s);   // staggered start, ~4 us spread
+        case 79: return launch_var<79>(a, epilogue, batch, s);   // ~8 us
+        case 111: return launch_var<111>(a, epilogue, batch, s);  // ~16 us
         default: break;
     }
 #endif
     (void)impl;
-    return launch_var<15>(a, epilogue, batch, s);
+    // streaming output stores where the output is wide (N >= 4096: QKV, FFN-in, every 14B projection): +4 % on QKV, +6-10 % at the 14B shapes
+    // (the freshly written tile does not push the operand panels out of L2 / MALL); -1 % where the output is the narrow residual stream
+    return a.N >= 4096 ? launch_var<143>(a, epilogue, batch, s) : launch_var<15>(a, epilogue, batch, s);
 }
 
 }  // namespace fvk

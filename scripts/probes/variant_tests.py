@@ -157,7 +157,7 @@ def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
     res, gate = rnd((Mb, N), 4, 2.0), rnd((B, N), 5, 0.5, torch.float32)
     xd = rnd((Mb, 2 * K), 1).to(DEV)[:, K // 2:K // 2 + K]  # row stride 2K
     outs = {}
-    for impl in (228, 2, 1252, 5, 13, 21, 29, 0, 61, 125):  # gemm_ph shipped | gemm_pp | gemm_ph persistent | gemm_w1 with 32x32x16 MFMAs | shipped gemm_w1
+    for impl in (228, 2, 1252, 5, 13, 21, 29, 0, 61, 125, 1149):  # gemm_ph shipped | gemm_pp | gemm_ph persistent | gemm_w1 with 32x32x16 MFMAs | shipped gemm_w1
         tunables("gemm_impl", impl)
         outs[impl] = [ops.gemm(xd, w.to(DEV), b.to(DEV), epilogue=e, residual=res.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None,
                                gate=gate.to(DEV) if e == ops.EPI_RESIDUAL_GATE else None).cpu()
@@ -168,7 +168,9 @@ def test_gemm_ph_pp_persistent_bit_identical(ops, tunables, M, N, K):
         for i, (a_, b_) in enumerate(zip(outs[228], outs[impl])):
             assert torch.equal(a_, b_), f"impl {impl}, output #{i}"
     for i, (a_, b_) in enumerate(zip(outs[0], outs[125])):
-        assert torch.equal(a_, b_), f"shipped gemm_w1 is variant 125, output #{i}"
+        assert torch.equal(a_, b_), f"shipped gemm_w1 is variant 125 (or 1149 = the same with streaming stores, for wide outputs), output #{i}"
+    for i, (a_, b_) in enumerate(zip(outs[1149], outs[125])):
+        assert torch.equal(a_, b_), f"streaming stores changed output #{i}"
     for i, (a_, b_) in enumerate(zip(outs[125], outs[61])):  # direct epilogue + persistent workgroups: the same arithmetic per output element
         assert torch.equal(a_, b_), f"gemm_w1 direct-epilogue variant differs from the bounce epilogue, output #{i}"
     outs[0] = outs[228]
