@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # the non-shipping kernel variants behind fvk_set_tunable (scripts/probes/libfvk_probe.so, built by _build.build_probe()).
 PROBE = os.environ.get("FVK_PROBE_LIB") == "1"
 LIB_PATH = (os.path.join(os.path.dirname(HERE), "scripts", "probes", "libfvk_probe.so") if PROBE else os.path.join(HERE, "libfvk_amd.so"))
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 

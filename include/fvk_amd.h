@@ -27,7 +27,7 @@ extern "C" {
 #define FVK_ERR_LAUNCH (-2)  /* hipLaunch / hip runtime error                  */
 
 const char* fvk_last_error(void);
-int fvk_abi_version(void);                 /* bumps when a signature changes */
+int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3) */
 int fvk_device_arch(char* buf, int len);   /* gcnArchName of the current device ("gfx950...") */
 int fvk_is_probe_build(void);              /* 0: the product library; 1: the measurement build (scripts/probes/libfvk_probe.so) */
 /* Integer knobs for within-process A/B measurements (scripts/microbench.py); 0 = shipped configuration.
