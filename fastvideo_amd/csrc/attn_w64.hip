@@ -622,6 +622,7 @@ int launch_w64(const fvk_attn_args* a, hipStream_t s) {
 }
 
 
+#if FVK_VARIANTS  // (only the measurement build's split-KV launch uses it)
 // out[b, row, h, :] = sum_r 2^(lse_r - max) * o_part[r] / sum_r 2^(lse_r - max): one wave per (b, h, row), 2 columns per lane; HBM-bound
 // (reads n_split * 512 B, writes 256 B per row).
 __global__ __launch_bounds__(256) void attn_merge_splits_kernel(fvk_attn_args a, int n_split, const float* o_part, const float* lse_part) {
@@ -649,6 +650,8 @@ __global__ __launch_bounds__(256) void attn_merge_splits_kernel(fvk_attn_args a,
     *reinterpret_cast<bf16x2*>((bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs + (long)r * a.o_ss + lane * 2) = o2;
     if (a.lse && lane == 0) a.lse[row_id] = mx + log2f(wsum);
 }
+
+#endif
 
 }  // namespace
 

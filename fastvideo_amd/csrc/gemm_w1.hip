@@ -217,13 +217,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     // chunks), of which every XCD holds 32 consecutive ones (8 m x 4 n: 12 panels through its L2).  vb = the tile id.
     int vb = DIRECT ? 32 * (int)(blockIdx.x & 7) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (DIRECT && vb >= ntiles) return;  // fewer tiles than workgroups (workgroup-uniform, before any barrier)
-    if (DIRECT && (VAR & 96)) {
-        // A/B: staggered start.  Equal tiles keep all 256 workgroups in lockstep, so all 256 epilogues hit HBM in the same few microseconds (the
-        // chip-wide write rate they ask for is the HBM peak) while the store path idles through every main loop.  Workgroup b waits
-        // (b & 63) / 64 of a spread (VAR bits 5-6: ~4 / ~8 / ~16 us) before its first tile; the offsets persist from tile to tile.
-        const int units = (int)(blockIdx.x & 63) * ((VAR & 96) == 32 ? 1 : (VAR & 96) == 64 ? 2 : 4);  // units of 128 cycles
-        for (int i = 0; i < units; ++i) __builtin_amdgcn_s_sleep(2);
-    }
     int m0, n0;
     auto tile_coords = [&](int bid) {
         const int nwg = ntiles;
@@ -590,9 +583,6 @@ int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
         case 31: return launch_var<31>(a, epilogue, batch, s);  // timing ablation: no epilogue
         case 143: return launch_var<143>(a, epilogue, batch, s);  // streaming (nontemporal) output stores
         case 15: return launch_var<15>(a, epilogue, batch, s);
-        case 47: return launch_var<47>(a, epilogue, batch, s);   // staggered start, ~4 us spread
-        case 79: return launch_var<79>(a, epilogue, batch, s);   // ~8 us
-        case 111: return launch_var<111>(a, epilogue, batch, s);  // ~16 us
         default: break;
     }
 #endif

@@ -117,6 +117,16 @@ class SequenceParallel:
             e1.record()
             rec["events"].append((e0, e1))
 
+    def sum_over_ranks(self, values, device=None):
+        """Element-wise sum of a short list of floats over the group (every rank gets the same list back): lets the ranks take ONE decision from
+        per-rank measurements (wan_dit's in-place attention kernel choice).  P == 1: the values themselves."""
+        vals = [float(v) for v in values]
+        if self.lay.P == 1:
+            return vals
+        t = torch.tensor(vals, dtype=torch.float64, device="cpu" if (self._stage_host or device is None) else device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return [float(v) for v in t.cpu()]
+
     # -- sharding with zero padding (ref: distributed/utils.py:63-123, communication_op.py:61-91) ---------------
     def padded_len(self, S: int) -> int:
         return (S + self.lay.P - 1) // self.lay.P * self.lay.P

@@ -208,13 +208,16 @@ class WanTransformer3DModelHip:
         """Close the timing forward: the faster long-key kernel (median launch time, the first launch of each left out) is kept."""
         ev, self._tune = self._tune, None
         self.attn_autotune = False
-        if len(ev) < 6:  # too few long-key launches to compare (short sequences take the 8-wave kernel anyway)
+        if len(ev) < 6:  # too few long-key launches to compare (short sequences take the 8-wave kernel anyway); the same count on every rank
             return
         torch.cuda.synchronize()
         ms = {ops.ATTN_KERNEL_W16: [], ops.ATTN_KERNEL_W64: []}
         for kern, e0, e1 in ev[2:]:
             ms[kern].append(e0.elapsed_time(e1))
         med = {kk: sorted(v)[len(v) // 2] for kk, v in ms.items()}
+        if self.sp.lay.P > 1:  # sequence parallel: ONE decision for all ranks, from the sum of their medians
+            tot = self.sp.sum_over_ranks([med[ops.ATTN_KERNEL_W16], med[ops.ATTN_KERNEL_W64]], device=self.device)
+            med = {ops.ATTN_KERNEL_W16: tot[0] / self.sp.lay.P, ops.ATTN_KERNEL_W64: tot[1] / self.sp.lay.P}
         self.attn_kernel = min(med, key=med.get)
         self.attn_tune_report = {"attn_w16_ms": round(med[ops.ATTN_KERNEL_W16], 4), "attn_w64_ms": round(med[ops.ATTN_KERNEL_W64], 4),
                                  "launches_timed": len(ev) - 2, "kept": "attn_w16" if self.attn_kernel == ops.ATTN_KERNEL_W16 else "attn_w64"}
@@ -451,7 +454,7 @@ class WanTransformer3DModelHip:
         sp = self.sp
         P, rank = sp.lay.P, sp.lay.rank
         cos, sin = rope.get_rotary_pos_embed(grid, D, device=dev)
-        if self.attn_autotune and self.attention == "dense" and P == 1:
+        if self.attn_autotune and self.attention == "dense":
             self._tune = []  # this forward times the two long-key attention kernels in place (see __init__)
 
         # patch embedding (Conv3d k=s=patch == GEMM over patch rows), then shard the token axis

@@ -43,6 +43,8 @@ def _worker(rank, world, port, H, S, D, q, k, v, out_q, overlap=False):
         # shard + gather round trip of a [B,S,d] activation (ragged S -> zero padded)
         x = torch.arange(2 * S * 6, dtype=torch.float32).view(2, S, 6)
         back = sp.all_gather_unpad(sp.shard(x, dim=1), S, dim=1)
+        # one decision from per-rank measurements (the model's in-place attention kernel choice): every rank sees the same sums
+        assert sp.sum_over_ranks([1.0 + rank, 10.0]) == [world * (world + 1) / 2, 10.0 * world]
         if rank == 0:
             out_q.put((full, back.equal(x), (sp.lay.G, sp.lay.U)))
         dist.barrier()
