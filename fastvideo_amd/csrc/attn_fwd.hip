@@ -540,7 +540,7 @@ static int attn_dense_impl(const fvk_attn_args* a, int kernel, void* stream) {
             // agree to rounding.  attn_w16 needs ~6 % more matrix-pipe cycles and a fifth less energy per FLOP: launched back to back it
             // settles at a higher clock and is 5 % faster, but between the GEMMs of a DiT block the clock does not always get there within
             // one 5-ms launch and it can be 5 % slower (profiles/r03_attn_context.md) — the caller may time both in ITS context and choose
-            // (fvk_attn_dense_kernel_bf16; fastvideo_amd/wan_dit.py does, once, in its first forward).
+            // (fvk_attn_dense_kernel_bf16; fastvideo_amd/wan_dit.py does, once, in its second forward).
             return kernel == 2 ? fvk_attn_w64_launch(a, 0, (hipStream_t)stream) : fvk_attn_w16_launch(a, 0, (hipStream_t)stream);
         }
     }

@@ -69,12 +69,14 @@ class WanTransformer3DModelHip:
         self.attn_events = None  # set to a list to collect (start, end, Sq, Skv, heads) HIP-event pairs
         # Dense self-attention on long key axes has two kernels that agree to rounding (fvk_attn_dense_kernel_bf16: attn_w16 / attn_w64); which
         # is faster depends on the clock the device reaches between THIS model's other kernels (profiles/r03_attn_context.md).  attn_autotune:
-        # the first forward alternates them layer by layer, times every launch with HIP events, and keeps the faster one from then on (one
-        # synchronisation, once).  Off (default): the library default for every launch, bit-identical forwards from the first one on.
+        # the SECOND forward (the first one also pays module loads and allocator growth, and runs on a cold chip) alternates them layer by
+        # layer, times every launch with HIP events, and keeps the faster one from then on (one synchronisation, once).  Off (default): the
+        # library default for every launch, bit-identical forwards from the first one on.
         self.attn_kernel = ops.ATTN_KERNEL_DEFAULT
         self.attn_autotune = bool(attn_autotune)
         self.attn_tune_report = None
         self._tune = None
+        self._forwards = 0
         self.vsa_trace = None    # set to a list to collect every layer's VSA block mask (tests)
 
     # ------------------------------------------------------------------ weights
@@ -454,7 +456,7 @@ class WanTransformer3DModelHip:
         sp = self.sp
         P, rank = sp.lay.P, sp.lay.rank
         cos, sin = rope.get_rotary_pos_embed(grid, D, device=dev)
-        if self.attn_autotune and self.attention == "dense":
+        if self.attn_autotune and self.attention == "dense" and self._forwards >= 1:
             self._tune = []  # this forward times the two long-key attention kernels in place (see __init__)
 
         # patch embedding (Conv3d k=s=patch == GEMM over patch rows), then shard the token axis
@@ -580,6 +582,7 @@ class WanTransformer3DModelHip:
             trace["norm_out"] = x.clone()
         y = ops.gemm(x.reshape(B * S, d), w["proj_out.w"], w["proj_out.b"])
         c_out = y.shape[-1] // (pt * ph * pw)
+        self._forwards += 1
         if self._tune is not None:
             self._finish_attn_tune()
         return ops.unpatchify(y.view(B, S, -1), (B, c_out, T, Hh, W), self.patch)

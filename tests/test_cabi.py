@@ -73,6 +73,8 @@ def test_argument_checks_of_the_newer_entries(lib):
         lib.call("fvk_attn_dense_split_bf16", C.byref(aa), 1, p, p, None)
     with pytest.raises(RuntimeError, match="null workspace"):
         lib.call("fvk_attn_dense_split_bf16", C.byref(aa), 4, None, p, None)
+    with pytest.raises(RuntimeError, match="kernel=7"):   # the long-key kernel is 0 (default), 1 (attn_w16) or 2 (attn_w64)
+        lib.call("fvk_attn_dense_kernel_bf16", C.byref(aa), 7, None)
     with pytest.raises(RuntimeError, match="null gate"):
         lib.call("fvk_qkvg_norm_rope_pack_bf16", p, p, p, None, None, None, None, None, p, 4, 128, 128, 4, 0, 128, 1, 1, 1e-6, None)
     with pytest.raises(RuntimeError, match="unknown tunable"):

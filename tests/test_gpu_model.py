@@ -203,7 +203,7 @@ def test_loader_builds_the_same_model_from_safetensors(tiny, tmp_path, golden_di
 
 
 def test_attention_kernel_choice_in_place():
-    """attn_autotune: the first forward alternates the two long-key dense attention kernels (attn_w16 / attn_w64: the same arithmetic to
+    """attn_autotune: the second forward alternates the two long-key dense attention kernels (attn_w16 / attn_w64: the same arithmetic to
     rounding) layer by layer, times every launch, and keeps the faster; every later forward is bit-identical to the next; the result stays
     within rounding of the model that never tunes (library default for every launch)."""
     if not torch.cuda.is_available():
@@ -220,7 +220,9 @@ def test_attention_kernel_choice_in_place():
     y_off = plain(latent, ctx, ts)
     assert plain.attn_tune_report is None and plain.attn_kernel == ops.ATTN_KERNEL_DEFAULT and torch.equal(plain(latent, ctx, ts), y_off)
     model = WanTransformer3DModelHip(sd, cfg.num_heads, cfg.head_dim, cfg.patch_size, cfg.eps, cfg.freq_dim, attn_autotune=True)
-    y1 = model(latent, ctx, ts)
+    y0 = model(latent, ctx, ts)   # the first forward (module loads, cold chip) runs the default kernel and decides nothing
+    assert model.attn_tune_report is None and model.attn_autotune and torch.equal(y0, y_off)
+    y1 = model(latent, ctx, ts)   # the second one times both kernels in place
     rep = model.attn_tune_report
     assert rep and rep["kept"] in ("attn_w16", "attn_w64") and rep["launches_timed"] == cfg.num_layers - 2 and rep["attn_w16_ms"] > 0 < rep["attn_w64_ms"]
     assert model.attn_kernel in (ops.ATTN_KERNEL_W16, ops.ATTN_KERNEL_W64) and model._tune is None and not model.attn_autotune
