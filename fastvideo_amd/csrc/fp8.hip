@@ -180,6 +180,8 @@ extern "C" int fvk_gemm_fp8(const void* x_fp8, const void* w_fp8, const float* s
     a.M = M; a.N = N; a.K = K; a.lda = K; a.ldc = ldc; a.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : M;
     a.scale_a = scale_a; a.scale_b = scale_b; a.scale_a_rowwise = a_rowwise; a.scale_b_rowwise = b_rowwise;
     // gemm_w1.hip's kernel in its fp8 mode (16x16x128 MX-fp8 MFMAs) where K is a whole number of 256-element double tiles; gemm_impl 2 forces gemm_pp's
-    if (fvk::tunable(fvk::TUNE_GEMM_IMPL) != 2 && fvk::gemm_w1_fp8_eligible(a)) return fvk::gemm_w1_fp8_launch(a, epilogue, (hipStream_t)stream);
+    // (its direct epilogue holds two gate rows per wave: a gate finer than 128 rows stays on gemm_pp's LDS-bounce epilogue)
+    const bool fine_gate = epilogue == FVK_EPI_RESIDUAL_GATE && gate && a.rows_per_batch < 128;
+    if (fvk::tunable(fvk::TUNE_GEMM_IMPL) != 2 && !fine_gate && fvk::gemm_w1_fp8_eligible(a)) return fvk::gemm_w1_fp8_launch(a, epilogue, (hipStream_t)stream);
     return fvk::gemm_pp_fp8_launch(a, epilogue, (hipStream_t)stream);
 }

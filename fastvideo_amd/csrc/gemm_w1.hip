@@ -74,71 +74,61 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
     const int ncol = n0 + wn * 128 + 8 * g;  // + 32 P
     const int mrow = m0 + wm * 128 + l15;    // + 16 mb
     constexpr bool RG = EPI == FVK_EPI_RESIDUAL_GATE;
-    float b8[4][8];
+    // gate rows (one per rows_per_batch output rows; rows_per_batch >= 128 here — gemm_w1_launch sends finer gates to the LDS-bounce variant):
+    // the wave's 128 rows see at most TWO of them, loaded once per column group; row m takes the second one from `bnd` on
+    const int mf = m0 + wm * 128;
+    const int gb0 = RG ? mf / a.rows_per_batch : 0;
+    const int bnd = (gb0 + 1) * a.rows_per_batch;
+    const bool two_gates = RG && a.gate && bnd < mf + 128 && bnd < a.M;
+    // One 32-column group at a time, its eight m blocks inside: the per-column state (bias, fp8 weight scales, gate) and the group's eight
+    // residual vectors are all that is live beside the accumulators and the next tile's first fragments (which stay in registers across the
+    // epilogue) — no spills.
+    bf16x8 resv[RG ? 2 : 1][RG ? 8 : 1];  // the group's eight residual vectors, requested one group ahead
+    auto load_res = [&](int P) {
+        const int n = ncol + 32 * P, nc = n < a.N ? n : 0;
+#pragma unroll
+        for (int mb = 0; mb < (RG ? 8 : 0); ++mb) {
+            int m = mrow + 16 * mb;
+            m = m < a.M ? m : a.M - 1;  // clamped addresses: always inside the operand, masked at the store
+            resv[P & 1][mb] = ld_bf16x8(a.residual + (long)m * a.ldc + nc);
+        }
+    };
+    load_res(0);
 #pragma unroll
     for (int P = 0; P < 4; ++P) {
         const int n = ncol + 32 * P;
+        const int nc = n < a.N ? n : 0;
+        float b8[8], sb8[FP8 ? 8 : 1], gt0[RG ? 8 : 1], gt1[RG ? 8 : 1];
+        if (RG && P < 3) load_res(P + 1);
+        __builtin_amdgcn_sched_barrier(0);  // (no further hoisting: two groups of residual vectors in flight, not four)
         if (a.bias && n < a.N) {
             const bf16x8 bv = ld_bf16x8(a.bias + n);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) b8[P][e] = (float)bv[e];
+            for (int e = 0; e < 8; ++e) b8[e] = (float)bv[e];
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) b8[P][e] = 0.f;
+            for (int e = 0; e < 8; ++e) b8[e] = 0.f;
         }
-    }
-    float sb8[FP8 ? 4 : 1][FP8 ? 8 : 1];  // fp8: the weight scales of the lane's 32 columns
-    if constexpr (FP8) {
+        if constexpr (FP8) {
 #pragma unroll
-        for (int P = 0; P < 4; ++P)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int n = ncol + 32 * P + e;
-                sb8[P][e] = a.scale_b_rowwise ? (n < a.N ? a.scale_b[n] : 0.f) : a.scale_b[0];
-            }
-    }
-    // gated residual: the residual vectors of four m blocks are requested at a time (16 x 16 B per lane in flight; the next tile's first
-    // fragments stay live in registers across the epilogue, so not all 32); the gate rows are loaded once when the wave's 128 rows share a batch
-    bf16x8 resv[RG ? 4 : 1][RG ? 4 : 1];
-    float gt0[RG ? 4 : 1][RG ? 8 : 1];
-    bool gate_uniform = false;
-    auto load_res = [&](int mb0) {
-#pragma unroll
-        for (int i = 0; i < (RG ? 4 : 0); ++i) {
-            int m = mrow + 16 * (mb0 + i);
-            m = m < a.M ? m : a.M - 1;  // clamped addresses: always inside the operand, masked at the store
-#pragma unroll
-            for (int P = 0; P < 4; ++P) {
-                const int n = ncol + 32 * P;
-                resv[i][P] = ld_bf16x8(a.residual + (long)m * a.ldc + (n < a.N ? n : 0));
-            }
+            for (int e = 0; e < 8; ++e) sb8[e] = a.scale_b_rowwise ? (n + e < a.N ? a.scale_b[n + e] : 0.f) : a.scale_b[0];
         }
-    };
-    if constexpr (RG) {
-        load_res(0);
-        const int mf = m0 + wm * 128, ml = (mf + 127 < a.M ? mf + 127 : a.M - 1);
-        gate_uniform = a.gate && (mf / a.rows_per_batch == ml / a.rows_per_batch);
-#pragma unroll
-        for (int P = 0; P < 4; ++P) {
-            const int n = ncol + 32 * P;
-            if (gate_uniform) {
-                const float* gp = a.gate + (long)(mf / a.rows_per_batch) * a.N + (n < a.N ? n : 0);
+        if constexpr (RG) {
+            if (a.gate) {
+                const float* gp = a.gate + (long)gb0 * a.N + nc;
                 const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+                const float* gq = two_gates ? gp + a.N : gp;
+                const f32x4 h0 = *reinterpret_cast<const f32x4*>(gq), h1 = *reinterpret_cast<const f32x4*>(gq + 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { gt0[P][e] = g0[e]; gt0[P][4 + e] = g1[e]; }
+                for (int e = 0; e < 4; ++e) { gt0[e] = g0[e]; gt0[4 + e] = g1[e]; gt1[e] = h0[e]; gt1[4 + e] = h1[e]; }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) gt0[P][e] = 1.0f;
+                for (int e = 0; e < 8; ++e) gt0[e] = gt1[e] = 1.0f;
             }
         }
-    }
 #pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-        const int m = mrow + 16 * mb;
-        if (RG && mb == 4) load_res(4);
-#pragma unroll
-        for (int P = 0; P < 4; ++P) {
-            const int n = ncol + 32 * P;
+        for (int mb = 0; mb < 8; ++mb) {
+            const int m = mrow + 16 * mb;
             bf16x8 y;
             if (FP8) {
                 // ref: torch._scaled_mm(x_fp8, w_fp8.t(), scale_a, scale_b, out_dtype=bf16) then `out + bias` in bf16
@@ -146,14 +136,14 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
                 const float sa = a.scale_a_rowwise ? (m < a.M ? a.scale_a[m] : 0.f) : a.scale_a[0];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float y0 = (float)(bf16_t)((e < 4 ? acc[2 * P][mb][e] : acc[2 * P + 1][mb][e - 4]) * (sa * sb8[P][e]));
-                    y[e] = a.bias ? (bf16_t)(y0 + b8[P][e]) : (bf16_t)y0;
+                    const float y0 = (float)(bf16_t)((e < 4 ? acc[2 * P][mb][e] : acc[2 * P + 1][mb][e - 4]) * (sa * sb8[e]));
+                    y[e] = a.bias ? (bf16_t)(y0 + b8[e]) : (bf16_t)y0;
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    y[e] = (bf16_t)(acc[2 * P][mb][e] + b8[P][e]);
-                    y[4 + e] = (bf16_t)(acc[2 * P + 1][mb][e] + b8[P][4 + e]);
+                    y[e] = (bf16_t)(acc[2 * P][mb][e] + b8[e]);
+                    y[4 + e] = (bf16_t)(acc[2 * P + 1][mb][e] + b8[4 + e]);
                 }
             }
             if (m < a.M && n < a.N) {
@@ -167,18 +157,9 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fdiv_rn((float)y[e], a.epi_scalar);
                 } else if constexpr (RG) {
-                    float gt[8];
-                    if (gate_uniform || !a.gate) {
+                    const bool second = m >= bnd;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) gt[e] = gt0[P][e];
-                    } else {
-                        const float* gp = a.gate + (long)(m / a.rows_per_batch) * a.N + n;
-                        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { gt[e] = g0[e]; gt[4 + e] = g1[e]; }
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fadd_rn((float)resv[mb & 3][P][e], __fmul_rn((float)y[e], gt[e]));
+                    for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fadd_rn((float)resv[P & 1][mb][e], __fmul_rn((float)y[e], second ? gt1[e] : gt0[e]));
                 }
 #if W1_ABL != 1  // (timing ablation 1: the epilogue without its stores)
                 if (NT) __builtin_nontemporal_store(y, reinterpret_cast<bf16x8*>(a.out + (long)m * a.ldc + n));  // streaming store (VAR bit 7)
@@ -385,6 +366,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     // ---- prologue: both K-tiles' units staged in read order, X0(0) and W0(0) landed and read, X0(2) staged ("phase -1") --------
     W1_STAGE_UNIT(0, 0) W1_STAGE_UNIT(1, 0) W1_STAGE_UNIT(2, 0) W1_STAGE_UNIT(3, 0)
     W1_STAGE_UNIT(0, 1) W1_STAGE_UNIT(1, 1) W1_STAGE_UNIT(2, 1) W1_STAGE_UNIT(3, 1)
+    int touch[4] = {0, 0, 0, 0};  // destinations of the residual touch loads (values unused)
     bool first_tile = true;
     while (true) {  // tile loop (DIRECT: persistent; otherwise one pass)
     // DIRECT: the unit FIFO does not stop at a tile boundary — the last two K-tiles of a tile's loop stage (and its last two phases read) the
@@ -428,6 +410,19 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         if (DIRECT && t == nt - 2) {  // from here on every staged unit belongs to the next tile (K-tiles nt, nt+1 = its K-tiles 0, 1)
             r_x0 = rn_x0; r_x1 = rn_x1; r_w0 = rn_w0; r_w1 = rn_w1;
             kb = -nt * ROWB;
+            if (EPI == FVK_EPI_RESIDUAL_GATE) {
+                // touch this tile's residual rows (256 rows x 512 B = 4 cache lines a row; lane = row, one dword per line, results unused) two K-tiles
+                // before the epilogue reads them: they were written a whole layer ago, and the epilogue's own loads then find them in L2
+                int rr = m0 + wave * 64 + lane;
+                rr = rr < a.M ? rr : a.M - 1;
+                const int nn = n0 < a.N ? n0 : 0;
+                const bf16_t* tp = a.residual + (long)rr * a.ldc + nn;
+                const int cols = a.N - nn;  // columns of the tile inside the matrix (a multiple of 8)
+                // (the destination registers stay reserved until the wait behind the epilogue: the data arrives asynchronously)
+#pragma unroll
+                for (int sg = 0; sg < 4; ++sg)
+                    if (sg * 64 < cols) asm volatile("global_load_dword %0, %1, off" : "=v"(touch[sg]) : "v"(tp + sg * 64) : "memory");
+            }
         }
         const unsigned char* b0 = smem + (t & 1) * BUF;  // K-tiles t, t+2
         const unsigned char* b1 = smem + ((t + 1) & 1) * BUF;
@@ -471,6 +466,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
 #else
         if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+        asm volatile("" : "+v"(touch[0]), "+v"(touch[1]), "+v"(touch[2]), "+v"(touch[3]));  // the touch loads have landed: their registers are free from here
         if (!more) break;
         vb += 256;
         m0 = m0n; n0 = n0n;
@@ -587,6 +583,8 @@ int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
     }
 #endif
     (void)impl;
+    // a gate finer than 128 rows (per-token modulation): the direct epilogue holds two gate rows per wave, the LDS-bounce variant any number
+    if (epilogue == FVK_EPI_RESIDUAL_GATE && a.gate && a.rows_per_batch < 128) return launch_var<7>(a, epilogue, batch, s);
     // streaming output stores where the output is wide (N >= 4096: QKV, FFN-in, every 14B projection): +4 % on QKV, +6-10 % at the 14B shapes
     // (the freshly written tile does not push the operand panels out of L2 / MALL); -1 % where the output is the narrow residual stream
     return a.N >= 4096 ? launch_var<143>(a, epilogue, batch, s) : launch_var<15>(a, epilogue, batch, s);
