@@ -52,6 +52,8 @@ using fvk::GemmArgs;
 
 #define W1_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 #define W1_MFMA16(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
+// first touch of an accumulator in a tile (DIRECT: no zeroing pass — 256 v_accvgpr_write per tile otherwise)
+#define W1_MFMA16Z(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(A), "v"(B))
 typedef int w1_v8i __attribute__((ext_vector_type(8)));
 typedef int w1_v4i __attribute__((ext_vector_type(4)));
 // fp8: the two 16-B halves of each operand's 32-B fragment; unit block scales (E8M0 0x7F = 1.0)
@@ -62,6 +64,15 @@ typedef int w1_v4i __attribute__((ext_vector_type(4)));
         const w1_v8i wa_ = {a0_[0], a0_[1], a0_[2], a0_[3], a1_[0], a1_[1], a1_[2], a1_[3]};                                       \
         const w1_v8i xa_ = {b0_[0], b0_[1], b0_[2], b0_[3], b1_[0], b1_[1], b1_[2], b1_[3]};                                       \
         ACC = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa_, xa_, ACC, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);                 \
+    }
+#define W1_MFMA_FP8Z(ACC, A0, A1, B0, B1)                                                                                          \
+    {                                                                                                                              \
+        const w1_v4i a0_ = __builtin_bit_cast(w1_v4i, A0), a1_ = __builtin_bit_cast(w1_v4i, A1);                                   \
+        const w1_v4i b0_ = __builtin_bit_cast(w1_v4i, B0), b1_ = __builtin_bit_cast(w1_v4i, B1);                                   \
+        const w1_v8i wa_ = {a0_[0], a0_[1], a0_[2], a0_[3], a1_[0], a1_[1], a1_[2], a1_[3]};                                       \
+        const w1_v8i xa_ = {b0_[0], b0_[1], b0_[2], b0_[3], b1_[0], b1_[1], b1_[2], b1_[3]};                                       \
+        const f32x4 z_ = {0.f, 0.f, 0.f, 0.f};                                                                                     \
+        ACC = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa_, xa_, z_, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);                  \
     }
 
 // Direct epilogue (VAR bit 3, 16x16x32 accumulators): no LDS bounce.  The w rows of a 32-row group are fed to the two MFMA tiles of the group
@@ -294,14 +305,14 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
 
     f32x16 acc[MI16 ? 1 : 4][MI16 ? 1 : 4];   // 32x32x16: [nb][mb]
     f32x4 acc16[MI16 ? 8 : 1][MI16 ? 8 : 1];  // 16x16x32: [nb][mb]
-    if (MI16) {
+    if (MI16 && !DIRECT) {  // (DIRECT: a tile's first MFMA on an accumulator takes 0 as its C operand)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc16[i & (MI16 ? 7 : 0)][j & (MI16 ? 7 : 0)][r] = 0.f;
-    } else {
+    } else if (!MI16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -335,20 +346,22 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     // w fragment held over 4 MFMAs), with the unit read and the unit stage between them at 16 SLOTS.  VAR bit 0: the 8 fragment reads fill
     // slots 0..7 and the 4 pieces slots 8, 10, 12, 14 (else a read in every odd slot, a piece in every fourth); VAR bit 1: one barrier
     // per TWO phases (phase p stages U(p+7) and the wait is vmcnt(16)).  P = phase number within the K-tile; NQ / MQ = the quadrant.
-#define W1_PHASE(P, XS, WS, NQ, MQ, RDST, RBUF, RIS_X, ROW0)                                            \
+#define W1_PHASE(P, PTV, ZF, XS, WS, NQ, MQ, RDST, RBUF, RIS_X, ROW0)                                   \
     _Pragma("unroll") for (int i_ = 0; i_ < ((MI16 && !FP8) ? 32 : 16); ++i_) {                         \
         if (FP8) {                                                                                      \
             const int nb_ = i_ >> 2, mb_ = i_ & 3;                                                      \
-            W1_MFMA_FP8(acc16[((NQ) * 4 + nb_) & (MI16 ? 7 : 0)][((MQ) * 4 + mb_) & (MI16 ? 7 : 0)], WS[2 * nb_], WS[2 * nb_ + 1], XS[2 * mb_], XS[2 * mb_ + 1]); \
+            if (ZF) W1_MFMA_FP8Z(acc16[((NQ) * 4 + nb_) & (MI16 ? 7 : 0)][((MQ) * 4 + mb_) & (MI16 ? 7 : 0)], WS[2 * nb_], WS[2 * nb_ + 1], XS[2 * mb_], XS[2 * mb_ + 1]) \
+            else W1_MFMA_FP8(acc16[((NQ) * 4 + nb_) & (MI16 ? 7 : 0)][((MQ) * 4 + mb_) & (MI16 ? 7 : 0)], WS[2 * nb_], WS[2 * nb_ + 1], XS[2 * mb_], XS[2 * mb_ + 1]) \
         } else if (MI16) {                                                                              \
             const int ks_ = i_ >> 4, nb_ = (i_ >> 2) & 3, mb_ = i_ & 3;                                 \
-            W1_MFMA16(acc16[((NQ) * 4 + nb_) & (MI16 ? 7 : 0)][((MQ) * 4 + mb_) & (MI16 ? 7 : 0)], WS[ks_ * 4 + nb_], XS[ks_ * 4 + mb_]); \
+            if ((ZF) && ks_ == 0) W1_MFMA16Z(acc16[((NQ) * 4 + nb_) & (MI16 ? 7 : 0)][((MQ) * 4 + mb_) & (MI16 ? 7 : 0)], WS[ks_ * 4 + nb_], XS[ks_ * 4 + mb_]); \
+            else W1_MFMA16(acc16[((NQ) * 4 + nb_) & (MI16 ? 7 : 0)][((MQ) * 4 + mb_) & (MI16 ? 7 : 0)], WS[ks_ * 4 + nb_], XS[ks_ * 4 + mb_]); \
         } else {                                                                                        \
             const int ks_ = i_ >> 2, nb_ = (i_ >> 1) & 1, mb_ = i_ & 1;                                 \
             W1_MFMA(acc[((NQ) * 2 + nb_) & (MI16 ? 0 : 3)][((MQ) * 2 + mb_) & (MI16 ? 0 : 3)], WS[(ks_ * 2 + nb_) & 7], XS[(ks_ * 2 + mb_) & 7]); \
         }                                                                                               \
         constexpr int sk_ = (VAR & 2) ? ((P) == 0 ? 0 : (P) == 1 ? 1 : (P) == 2 ? 2 : 3) : ((P) == 0 ? 1 : (P) == 1 ? 2 : (P) == 2 ? 3 : 0); \
-        const int st_ = t + (PT) + 2 + ((!(VAR & 2) && (P) == 3) ? 1 : 0);                              \
+        const int st_ = t + (PTV) + 2 + ((!(VAR & 2) && (P) == 3) ? 1 : 0);                             \
         if (!MI16 || FP8 || (i_ & 1)) {                                                                 \
             const int sl_ = (MI16 && !FP8) ? i_ >> 1 : i_;                                              \
             if (VAR & 1) {                                                                              \
@@ -406,41 +419,44 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     }  // prologue (first tile)
     first_tile = false;
 
-    for (int t = 0; t < nt; t += 2) {  // nt is even (gemm_w1_eligible)
-        if (DIRECT && t == nt - 2) {  // from here on every staged unit belongs to the next tile (K-tiles nt, nt+1 = its K-tiles 0, 1)
-            r_x0 = rn_x0; r_x1 = rn_x1; r_w0 = rn_w0; r_w1 = rn_w1;
-            kb = -nt * ROWB;
-            if (EPI == FVK_EPI_RESIDUAL_GATE) {
-                // touch this tile's residual rows (256 rows x 512 B = 4 cache lines a row; lane = row, one dword per line, results unused) two K-tiles
-                // before the epilogue reads them: they were written a whole layer ago, and the epilogue's own loads then find them in L2
-                int rr = m0 + wave * 64 + lane;
-                rr = rr < a.M ? rr : a.M - 1;
-                const int nn = n0 < a.N ? n0 : 0;
-                const bf16_t* tp = a.residual + (long)rr * a.ldc + nn;
-                const int cols = a.N - nn;  // columns of the tile inside the matrix (a multiple of 8)
-                // (the destination registers stay reserved until the wait behind the epilogue: the data arrives asynchronously)
-#pragma unroll
-                for (int sg = 0; sg < 4; ++sg)
-                    if (sg * 64 < cols) asm volatile("global_load_dword %0, %1, off" : "=v"(touch[sg]) : "v"(tp + sg * 64) : "memory");
-            }
-        }
-        const unsigned char* b0 = smem + (t & 1) * BUF;  // K-tiles t, t+2
-        const unsigned char* b1 = smem + ((t + 1) & 1) * BUF;
-        // K-tile t: W0 in WA, W1 in WB.   stage (VAR bit 1 clear): phases 0..3 stage W0(t+2), W1(t+2), X1(t+2), X0(t+3); (set): X0(t+2), W0(t+2), W1(t+2), X1(t+2)
-#define PT 0
-        W1_PHASE(0, XA, WA, 0, 0, WB, b0, false, 64)  // X0 x W0; read W1(t)
-        W1_PHASE(1, XA, WB, 1, 0, XB, b0, true, 64)   // X0 x W1; read X1(t)
-        W1_PHASE(2, XB, WB, 1, 1, XA, b1, true, 0)    // X1 x W1; read X0(t+1)
-        W1_PHASE(3, XB, WA, 0, 1, WB, b1, false, 0)   // X1 x W0; read W0(t+1)
-#undef PT
-#define PT 1
-        // K-tile t+1: W0 in WB, W1 in WA
-        W1_PHASE(0, XA, WB, 0, 0, WA, b1, false, 64)  // read W1(t+1)
-        W1_PHASE(1, XA, WA, 1, 0, XB, b1, true, 64)   // read X1(t+1)
-        W1_PHASE(2, XB, WA, 1, 1, XA, b0, true, 0)    // read X0(t+2)
-        W1_PHASE(3, XB, WB, 0, 1, WA, b0, false, 0)   // read W0(t+2)
-#undef PT
+    // One pair of K-tiles.  In the pair that holds the tile's last K-tiles (t == nt - 2) every staged unit already belongs to the workgroup's NEXT
+    // tile (K-tiles nt, nt+1 = its K-tiles 0, 1), and the gated-residual epilogue's residual rows are touched (256 rows x 512 B = 4 cache
+    // lines a row; lane = row, one dword per line, results unused, destination registers reserved until the wait behind the epilogue): written a
+    // whole layer ago, they are then found in L2 by the epilogue's own loads.  Phases: X0 x W0 (reads W1(t)), X0 x W1 (X1(t)), X1 x W1
+    // (X0(t+1)), X1 x W0 (W0(t+1)); then the same on K-tile t+1 with the W sets swapped.  ZF_: the first K-tile's MFMAs take 0 as C.
+#define W1_ITER(ZF_) \
+        if (DIRECT && t == nt - 2) { \
+            r_x0 = rn_x0; r_x1 = rn_x1; r_w0 = rn_w0; r_w1 = rn_w1; \
+            kb = -nt * ROWB; \
+            if (EPI == FVK_EPI_RESIDUAL_GATE) { \
+                int rr = m0 + wave * 64 + lane; \
+                rr = rr < a.M ? rr : a.M - 1; \
+                const int nn = n0 < a.N ? n0 : 0; \
+                const bf16_t* tp = a.residual + (long)rr * a.ldc + nn; \
+                const int cols = a.N - nn; \
+                _Pragma("unroll") for (int sg = 0; sg < 4; ++sg) \
+                    if (sg * 64 < cols) asm volatile("global_load_dword %0, %1, off" : "=v"(touch[sg]) : "v"(tp + sg * 64) : "memory"); \
+            } \
+        } \
+        const unsigned char* b0 = smem + (t & 1) * BUF; \
+        const unsigned char* b1 = smem + ((t + 1) & 1) * BUF; \
+        W1_PHASE(0, 0, ZF_, XA, WA, 0, 0, WB, b0, false, 64) \
+        W1_PHASE(1, 0, ZF_, XA, WB, 1, 0, XB, b0, true, 64) \
+        W1_PHASE(2, 0, ZF_, XB, WB, 1, 1, XA, b1, true, 0) \
+        W1_PHASE(3, 0, ZF_, XB, WA, 0, 1, WB, b1, false, 0) \
+        W1_PHASE(0, 1, 0, XA, WB, 0, 0, WA, b1, false, 64) \
+        W1_PHASE(1, 1, 0, XA, WA, 1, 0, XB, b1, true, 64) \
+        W1_PHASE(2, 1, 0, XB, WA, 1, 1, XA, b0, true, 0) \
+        W1_PHASE(3, 1, 0, XB, WB, 0, 1, WA, b0, false, 0)
+    // K-tile pairs (nt is even: gemm_w1_eligible); K-tile t: W0 in WA, W1 in WB, K-tile t+1 the other way round.  DIRECT: the first pair is
+    // peeled — its first K-tile's MFMAs are each accumulator's first touch in the tile and take 0 as C (no zeroing pass)
+    if constexpr (DIRECT) {
+        { const int t = 0; W1_ITER(1) }
+        for (int t = 2; t < nt; t += 2) { W1_ITER(0) }
+    } else {
+        for (int t = 0; t < nt; t += 2) { W1_ITER(0) }
     }
+#undef W1_ITER
     if constexpr (DIRECT) {
         // the accumulators were written by asm MFMAs: the compiler knows no hazard distance to its own reads of them
         asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
@@ -451,16 +467,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         if (!(VAR & 16)) w1_direct_epilogue<EPI, FP8, (VAR & 128) != 0>(a, acc16, m0, n0, wm, wn, lane);  // VAR bit 4: timing ablation (no epilogue, no output)
         // everything this wave has in flight — the next tile's units and the epilogue's stores (they share vmcnt, and reads / writes need not
         // retire in issue order) — before the counted waits of the next tile's loop, or before the workgroup ends with LDS writes outstanding
-        if (more) {  // (the accumulators are re-zeroed while the stores drain)
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
-                    asm volatile("" : "+a"(acc16[i][j]));
-                }
-        }
 #if W1_ABL != 2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
