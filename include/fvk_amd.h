@@ -35,10 +35,12 @@ int fvk_is_probe_build(void);              /* 0: the product library; 1: the mea
  * (FVK_ERR_ARG).  The non-shipping kernels, schedules and timing ablations live in the measurement build of the same sources
  * (-DFVK_PROBE_BUILD + scripts/probes/{attn_pp,attn_vsa}.hip -> scripts/probes/libfvk_probe.so; FVK_PROBE_LIB=1 makes the Python
  * binding load it), where:
- *   "gemm_impl": 0 auto (256x256 LDS-DMA ping-pong kernel when eligible), 1 force the 128x128 register-staged kernel, 2 / 3 gemm_pp,
- *                4 + 8 * VAR gemm_ph variants
+ *   "gemm_impl": 0 auto (gemm_w1 for K % 128 == 0, else gemm_ph / gemm_pp; fp8: gemm_w1 for K % 256 == 0), 1 force the 128x128
+ *                register-staged kernel, 2 / 3 gemm_pp (also its fp8 kernel), 4 + 8 * VAR gemm_ph variants (228 = its shipped schedule),
+ *                5 + 8 * VAR gemm_w1 variants (125 / 1149 = the shipped configuration without / with streaming stores)
  *   "vae_conv_impl": 0 auto (halo-reuse kernel for 3x3 spatial taps), 1 force the per-tap gather kernel, 2 lockstep 96-channel schedule
- *   "attn_impl": 0 auto (8-wave ping-pong kernel, 128-key tiles), 1 force the 4-wave kernel, 2.. measurement variants, 120 + bits ablations
+ *   "attn_impl": 0 auto (attn_w16 from 2048 keys, else the 8-wave kernel attn_pp2), 1 force the 4-wave kernel, 2..98 attn_pp, 99.. attn_pp2
+ *                and its variants / ablations, 200.. attn_w64 and variants, 300.. attn_w16 and variants (31x = timing ablations)
  *   "vsa_impl": 1 block-per-row top-k kernel */
 int fvk_set_tunable(const char* name, int value);
 
