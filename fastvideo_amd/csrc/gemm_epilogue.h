@@ -20,6 +20,24 @@ __device__ __forceinline__ float gelu_tanh_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + t);
 }
 
+// Two values at once: the multiplies / adds as packed fp32 operations (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32 — the same IEEE results as the
+// scalar forms; a gain only where no MFMA runs beside them, i.e. in an exposed epilogue), the two transcendentals per value as before.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t gelu_tanh_fast2(f32x2_t x) {
+    const float c0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;
+    const float c1 = c0 * 0.044715f;
+    const f32x2_t c0v = {c0, c0}, c1v = {c1, c1}, one = {1.0f, 1.0f};
+    const f32x2_t u = x * __builtin_elementwise_fma(x * x, c1v, c0v);
+    f32x2_t t;
+    t[0] = __builtin_amdgcn_exp2f(u[0]);
+    t[1] = __builtin_amdgcn_exp2f(u[1]);
+    const f32x2_t d = one + t;
+    f32x2_t r;
+    r[0] = __builtin_amdgcn_rcpf(d[0]);
+    r[1] = __builtin_amdgcn_rcpf(d[1]);
+    return x * r;
+}
+
 // The caller guarantees that no wave still reads or DMA-writes the LDS ring (drained + barrier) before calling.
 // PREF (gated-residual epilogue): all 16 residual vectors of the lane are requested BEFORE the accumulators are packed and bounced
 // (one exposed HBM latency per tile instead of four), and the gate row is loaded once when the wave's 128 rows share a batch.

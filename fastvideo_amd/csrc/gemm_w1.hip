@@ -160,7 +160,11 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
             if (m < a.M && n < a.N) {
                 if (EPI == FVK_EPI_GELU_TANH) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = (bf16_t)fvk::gelu_tanh_fast((float)y[e]);
+                    for (int e = 0; e < 8; e += 2) {  // pairs: packed fp32 arithmetic (this epilogue runs with the matrix pipe idle)
+                        const fvk::f32x2_t g2 = fvk::gelu_tanh_fast2(fvk::f32x2_t{(float)y[e], (float)y[e + 1]});
+                        y[e] = (bf16_t)g2[0];
+                        y[e + 1] = (bf16_t)g2[1];
+                    }
                 } else if (EPI == FVK_EPI_SILU) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) y[e] = (bf16_t)silu_f32((float)y[e]);
