@@ -15,6 +15,7 @@
 // Epilogue variants follow the reference's rounding points: y = bf16(acc + bias) first, then the activation /
 // gated residual on float(y), then one more rounding.
 #include "gemm_common.h"
+#include "gemm_epilogue.h"
 
 namespace {
 
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmArgs a) {
                 } else if (EPI == FVK_EPI_RESIDUAL_GATE) {
                     const float res = (float)a.residual[(long)m * a.ldc + n];
                     const float g = a.gate ? a.gate[(long)(m / a.rows_per_batch) * a.N + n] : 1.0f;
-                    y = __fadd_rn(res, __fmul_rn(y, g));
+                    y = fvk::mul_then_add(res, y, g);  // two roundings (gemm_epilogue.h)
                 }
                 a.out[(long)m * a.ldc + n] = (bf16_t)y;
             }

@@ -20,6 +20,14 @@ __device__ __forceinline__ float gelu_tanh_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + t);
 }
 
+// residual + y * gate with the product rounded before the sum — the reference's two eager ops (`residual + x * gate`: layernorm.py:91-109).
+// hipcc contracts __fmul_rn + __fadd_rn into one fused multiply-add unless contraction is switched off where they meet.
+__device__ __forceinline__ float mul_then_add(float r, float y, float g) {
+#pragma clang fp contract(off)
+    const float p = y * g;
+    return r + p;
+}
+
 // Two values at once: the multiplies / adds as packed fp32 operations (v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32 — the same IEEE results as the
 // scalar forms; a gain only where no MFMA runs beside them, i.e. in an exposed epilogue), the two transcendentals per value as before.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -148,7 +156,7 @@ __device__ __forceinline__ void gemm_tile_epilogue(const GemmArgs& a, Acc& acc, 
                     for (int e = 0; e < 8; ++e) gt[e] = 1.0f;
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fadd_rn((float)resv[it][e], __fmul_rn((float)y[e], gt[e]));
+                for (int e = 0; e < 8; ++e) y[e] = (bf16_t)mul_then_add((float)resv[it][e], (float)y[e], gt[e]);
                 st_bf16x8(a.out + (long)m * a.ldc + n, y);
             }
         }
@@ -182,7 +190,7 @@ __device__ __forceinline__ void gemm_tile_epilogue(const GemmArgs& a, Acc& acc, 
                     for (int e = 0; e < 8; ++e) gt[e] = 1.0f;
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fadd_rn((float)res[e], __fmul_rn((float)y[e], gt[e]));
+                for (int e = 0; e < 8; ++e) y[e] = (bf16_t)mul_then_add((float)res[e], (float)y[e], gt[e]);
             }
             st_bf16x8(a.out + (long)m * a.ldc + n, y);
         }

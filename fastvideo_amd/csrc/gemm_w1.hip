@@ -75,6 +75,13 @@ typedef int w1_v4i __attribute__((ext_vector_type(4)));
         ACC = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa_, xa_, z_, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);                  \
     }
 
+// r + y * g on two values with the product rounded before the sum (the reference's two eager ops: no fused multiply-add)
+__device__ __forceinline__ fvk::f32x2_t w1_mul_add2(fvk::f32x2_t r, fvk::f32x2_t y, fvk::f32x2_t g) {
+#pragma clang fp contract(off)
+    const fvk::f32x2_t p = y * g;
+    return r + p;
+}
+
 // Direct epilogue (VAR bit 3, 16x16x32 accumulators): no LDS bounce.  The w rows of a 32-row group are fed to the two MFMA tiles of the group
 // in the order that leaves lane (l15, g) with EIGHT consecutive output columns — tile 2P row 4g + e = column 32P + 8g + e, tile 2P + 1 the
 // columns + 4 — so a lane stores 16 B per (16-row m block, 32-column group): 64 contiguous bytes per output row and instruction.
@@ -152,9 +159,11 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    y[e] = (bf16_t)(acc[2 * P][mb][e] + b8[e]);
-                    y[4 + e] = (bf16_t)(acc[2 * P + 1][mb][e] + b8[4 + e]);
+                for (int e = 0; e < 4; e += 2) {  // (pairs: v_pk_add_f32 — the same sums)
+                    const fvk::f32x2_t lo = fvk::f32x2_t{acc[2 * P][mb][e], acc[2 * P][mb][e + 1]} + fvk::f32x2_t{b8[e], b8[e + 1]};
+                    const fvk::f32x2_t hi = fvk::f32x2_t{acc[2 * P + 1][mb][e], acc[2 * P + 1][mb][e + 1]} + fvk::f32x2_t{b8[4 + e], b8[5 + e]};
+                    y[e] = (bf16_t)lo[0]; y[e + 1] = (bf16_t)lo[1];
+                    y[4 + e] = (bf16_t)hi[0]; y[5 + e] = (bf16_t)hi[1];
                 }
             }
             if (m < a.M && n < a.N) {
@@ -174,7 +183,11 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
                 } else if constexpr (RG) {
                     const bool second = m >= bnd;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = (bf16_t)__fadd_rn((float)resv[P & 1][mb][e], __fmul_rn((float)y[e], second ? gt1[e] : gt0[e]));
+                    for (int e = 0; e < 8; e += 2) {  // (pairs; multiply and add stay two roundings: w1_mul_add2)
+                        const fvk::f32x2_t o2 = w1_mul_add2(fvk::f32x2_t{(float)resv[P & 1][mb][e], (float)resv[P & 1][mb][e + 1]}, fvk::f32x2_t{(float)y[e], (float)y[e + 1]},
+                                                            fvk::f32x2_t{second ? gt1[e] : gt0[e], second ? gt1[e + 1] : gt0[e + 1]});
+                        y[e] = (bf16_t)o2[0]; y[e + 1] = (bf16_t)o2[1];
+                    }
                 }
 #if W1_ABL != 1  // (timing ablation 1: the epilogue without its stores)
                 if (NT) __builtin_nontemporal_store(y, reinterpret_cast<bf16x8*>(a.out + (long)m * a.ldc + n));  // streaming store (VAR bit 7)
@@ -383,7 +396,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     // ---- prologue: both K-tiles' units staged in read order, X0(0) and W0(0) landed and read, X0(2) staged ("phase -1") --------
     W1_STAGE_UNIT(0, 0) W1_STAGE_UNIT(1, 0) W1_STAGE_UNIT(2, 0) W1_STAGE_UNIT(3, 0)
     W1_STAGE_UNIT(0, 1) W1_STAGE_UNIT(1, 1) W1_STAGE_UNIT(2, 1) W1_STAGE_UNIT(3, 1)
-    int touch[4] = {0, 0, 0, 0};  // destinations of the residual touch loads (values unused)
     bool first_tile = true;
     while (true) {  // tile loop (DIRECT: persistent; otherwise one pass)
     // DIRECT: the unit FIFO does not stop at a tile boundary — the last two K-tiles of a tile's loop stage (and its last two phases read) the
@@ -425,21 +437,24 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
 
     // One pair of K-tiles.  In the pair that holds the tile's last K-tiles (t == nt - 2) every staged unit already belongs to the workgroup's NEXT
     // tile (K-tiles nt, nt+1 = its K-tiles 0, 1), and the gated-residual epilogue's residual rows are touched (256 rows x 512 B = 4 cache
-    // lines a row; lane = row, one dword per line, results unused, destination registers reserved until the wait behind the epilogue): written a
-    // whole layer ago, they are then found in L2 by the epilogue's own loads.  Phases: X0 x W0 (reads W1(t)), X0 x W1 (X1(t)), X1 x W1
+    // lines a row; lane = row, one dword per line by LDS-DMA into a 4-KiB dump area behind the ring — no destination register to keep alive,
+    // rows / columns outside the matrix fall outside the descriptor and fetch nothing): written a whole layer ago, they are then found in L2 by
+    // the epilogue's own loads.  Phases: X0 x W0 (reads W1(t)), X0 x W1 (X1(t)), X1 x W1
     // (X0(t+1)), X1 x W0 (W0(t+1)); then the same on K-tile t+1 with the W sets swapped.  ZF_: the first K-tile's MFMAs take 0 as C.
 #define W1_ITER(ZF_) \
         if (DIRECT && t == nt - 2) { \
             r_x0 = rn_x0; r_x1 = rn_x1; r_w0 = rn_w0; r_w1 = rn_w1; \
             kb = -nt * ROWB; \
             if (EPI == FVK_EPI_RESIDUAL_GATE) { \
-                int rr = m0 + wave * 64 + lane; \
-                rr = rr < a.M ? rr : a.M - 1; \
-                const int nn = n0 < a.N ? n0 : 0; \
-                const bf16_t* tp = a.residual + (long)rr * a.ldc + nn; \
-                const int cols = a.N - nn; \
-                _Pragma("unroll") for (int sg = 0; sg < 4; ++sg) \
-                    if (sg * 64 < cols) asm volatile("global_load_dword %0, %1, off" : "=v"(touch[sg]) : "v"(tp + sg * 64) : "memory"); \
+                int rv_ = a.M - m0, cv_ = a.N - n0; \
+                rv_ = rv_ > 256 ? 256 : rv_; cv_ = cv_ > 256 ? 256 : cv_; \
+                if (rv_ > 0 && cv_ > 0) { \
+                    const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual + (long)m0 * a.ldc + n0), 0, \
+                                                                                         (int)((((long)rv_ - 1) * a.ldc + cv_) * 2), 0x00020000); \
+                    const int vo_ = (wave * 64 + lane) * (int)(a.ldc * 2); \
+                    _Pragma("unroll") for (int sg = 0; sg < 4; ++sg) \
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rr_, (lds_void*)(smem + 2 * BUF + wave * 1024 + sg * 256), 4, vo_, sg * 128, 0, 0); \
+                } \
             } \
         } \
         const unsigned char* b0 = smem + (t & 1) * BUF; \
@@ -476,7 +491,6 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
 #else
         if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
-        asm volatile("" : "+v"(touch[0]), "+v"(touch[1]), "+v"(touch[2]), "+v"(touch[3]));  // the touch loads have landed: their registers are free from here
         if (!more) break;
         vb += 256;
         m0 = m0n; n0 = n0n;
@@ -519,7 +533,7 @@ template <int EPI, int VAR, bool FP8 = false>
 int launch(const GemmArgs& a, int batch, hipStream_t s) {
     static FvkLdsConfigured configured;
     constexpr bool DIRECT = (VAR & 12) == 12;
-    constexpr int lds = DIRECT ? 2 * BUF : LDS_BYTES;  // the direct epilogue needs no staging region
+    constexpr int lds = DIRECT ? 2 * BUF + (EPI == FVK_EPI_RESIDUAL_GATE ? 4096 : 0) : LDS_BYTES;  // the direct epilogue needs no staging region (gated residual: + the touch loads' dump area)
     if (int rc = fvk_config_lds(configured, (const void*)gemm_w1_kernel<EPI, VAR, FP8>, lds, FP8 ? "fvk_gemm_fp8 (w1)" : "fvk_gemm_bf16 (w1)")) return rc;
     const int tiles = a.ntm * a.ntn;
     const int grid = DIRECT ? 256 : tiles;  // DIRECT: persistent, one workgroup per CU (a workgroup without a tile returns at once)
