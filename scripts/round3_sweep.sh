@@ -2,7 +2,7 @@
 # round 3, final visit S: FULL gpu suite, then the round's sweep of bench lines (contract, sta, vsa, fp8, cfg1, cfg5, vae)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-OUT=gpurun_out/r3s
+OUT=gpurun_out/r3sweep
 mkdir -p "$OUT"
 echo "== full gpu suite"
 timeout 1800 python -m pytest tests -m gpu -q --durations=8 > "$OUT/pytest_full.log" 2>&1
