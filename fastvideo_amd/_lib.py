@@ -34,6 +34,7 @@ SIGNATURES = {
     "fvk_device_arch": [C.c_char_p, i32],
     "fvk_set_tunable": [C.c_char_p, i32],
     "fvk_ln_modulate_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
+    "fvk_ln_modulate_fp8_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, f32, i32, vp],
     "fvk_scale_residual_bf16": [vp, vp, vp, vp, i32, i32, i32, vp],
     "fvk_rmsnorm_rope_bf16": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, i32, i32, i32, i32, i32, i64, i64, f32, vp],
     "fvk_rmsnorm_rope_scatter_bf16": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, i32, i32, i32, i32, i32, i64, i64, f32,

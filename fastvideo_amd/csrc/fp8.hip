@@ -7,11 +7,13 @@
 //   q       = e4m3fn_rne( clamp( bf16( float(x) / float(bf16(scale)) ), -448, 448 ) )       (the reference divides in bf16)
 // The GEMM itself is gemm_pp.hip's kernel instantiated with FP8 = true (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales).
 #include "gemm_common.h"
+#include "fp8_common.h"
 
 namespace {
 
-constexpr float FP8_MAX = 448.0f;
-constexpr float FP8_MIN_SCALE = 1.0f / (448.0f * 512.0f);
+using fvk::FP8_MAX;
+using fvk::FP8_MIN_SCALE;
+using fvk::fp8_pack8;
 
 // rowwise: one wave per row.  tensorwise: grid-stride over rows, one atomicMax per wave on the (non-negative) float bits.
 template <bool ROWWISE>
@@ -66,21 +68,6 @@ __global__ __launch_bounds__(256) void fp8_absmax_flat_kernel(const bf16_t* __re
     __syncthreads();
     if (threadIdx.x == 0)
         atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));
-}
-
-__device__ __forceinline__ int2 fp8_pack8(const bf16x8 v, float sb) {
-    float f[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const float d = (float)(bf16_t)__fdiv_rn((float)v[e], sb);
-        f[e] = fminf(fmaxf(d, -FP8_MAX), FP8_MAX);
-    }
-    int w0 = 0, w1 = 0;
-    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
-    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
-    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
-    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
-    return make_int2(w0, w1);
 }
 
 template <bool ROWWISE>

@@ -9,6 +9,7 @@
 // contraction is disabled in this file so separately-rounded reference ops stay separately rounded.
 #pragma clang fp contract(off)
 #include "fvk_common.h"
+#include "fp8_common.h"
 
 namespace {
 
@@ -25,10 +26,16 @@ struct LnArgs {
     int M, d, rows_per_batch;
     float eps;
     int flags;
+    // fvk_ln_modulate_fp8_bf16: the row's PER-TOKEN e4m3 quantisation (fp8_config.py:62-68 applied to the bf16 output row, which one wave
+    // holds in registers) written beside — or instead of (out == NULL) — the bf16 row: q_out [M, d] bytes, q_scale [M] fp32
+    unsigned char* q_out;
+    float* q_scale;
 };
 
-template <int VPL>
+template <int VPL, bool QUANT = false>
 __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs a) {
+    bf16x8 ov[QUANT ? VPL : 1];  // QUANT: the output row, kept for the quantisation pass
+    float amax = 0.f;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.M) return;
@@ -131,7 +138,22 @@ __global__ __launch_bounds__(256) void ln_modulate_kernel(LnArgs a) {
             bf16x8 o;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (bf16_t)n[j];
-            st_bf16x8(a.out + rbase + c * 8, o);
+            if (a.out) st_bf16x8(a.out + rbase + c * 8, o);
+            if (QUANT) {
+                ov[i] = o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf((float)o[j]));
+            }
+        }
+    }
+    if (QUANT) {  // the stand-alone quantiser's arithmetic (fp8.hip: fp8_absmax_kernel<true> + fp8_quantize_kernel<true>) on the row in registers
+        const float scale = fvk::fp8_scale_of(wave_max(amax));
+        if (lane == 0) a.q_scale[row] = scale;
+        const float sb = (float)(bf16_t)scale;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nchunks) *reinterpret_cast<int2*>(a.q_out + rbase + c * 8) = fvk::fp8_pack8(ov[i], sb);
         }
     }
 }
@@ -319,13 +341,32 @@ extern "C" int fvk_ln_modulate_bf16(const void* x, const void* residual, const f
     FVK_CHECK(!(gate && !residual), FVK_ERR_ARG, "fvk_ln_modulate_bf16: gate without residual");
     if (M == 0) return FVK_OK;
     LnArgs a{(const bf16_t*)x, (const bf16_t*)residual, gate, ln_w, ln_b, mul, add, (bf16_t*)res_out, (bf16_t*)out,
-             M, d, rows_per_batch, eps, flags};
+             M, d, rows_per_batch, eps, flags, nullptr, nullptr};
     int rc = dispatch_vpl(d, [&](auto vpl) {
         hipLaunchKernelGGL((ln_modulate_kernel<decltype(vpl)::value>), dim3((M + 3) / 4), dim3(256), 0,
                            (hipStream_t)stream, a);
         return FVK_OK;
     });
     FVK_CHECK(rc == FVK_OK, rc, "fvk_ln_modulate_bf16: unsupported d=%d", d);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+extern "C" int fvk_ln_modulate_fp8_bf16(const void* x, const void* residual, const float* gate, const float* ln_w, const float* ln_b,
+                                        const float* mul, const float* add, void* res_out, void* out, void* q_out, float* q_scale, int M,
+                                        int d, int rows_per_batch, float eps, int flags, void* stream) {
+    FVK_CHECK(x && q_out && q_scale, FVK_ERR_ARG, "fvk_ln_modulate_fp8_bf16: null x / q_out / q_scale");
+    FVK_CHECK(M >= 0 && d > 0 && d % 8 == 0 && d <= 8192, FVK_ERR_ARG, "fvk_ln_modulate_fp8_bf16: d=%d must be a multiple of 8 and <= 8192", d);
+    FVK_CHECK(rows_per_batch > 0, FVK_ERR_ARG, "fvk_ln_modulate_fp8_bf16: rows_per_batch must be > 0");
+    FVK_CHECK(!(gate && !residual), FVK_ERR_ARG, "fvk_ln_modulate_fp8_bf16: gate without residual");
+    if (M == 0) return FVK_OK;
+    LnArgs a{(const bf16_t*)x, (const bf16_t*)residual, gate, ln_w, ln_b, mul, add, (bf16_t*)res_out, (bf16_t*)out,
+             M, d, rows_per_batch, eps, flags, (unsigned char*)q_out, q_scale};
+    int rc = dispatch_vpl(d, [&](auto vpl) {
+        hipLaunchKernelGGL((ln_modulate_kernel<decltype(vpl)::value, true>), dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
+        return FVK_OK;
+    });
+    FVK_CHECK(rc == FVK_OK, rc, "fvk_ln_modulate_fp8_bf16: unsupported d=%d", d);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }

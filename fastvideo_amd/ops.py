@@ -49,8 +49,11 @@ def set_tunable(name: str, value: int) -> None:
 
 # ------------------------------------------------------------------ norm / modulate
 def ln_modulate(x, *, residual=None, gate=None, ln_w=None, ln_b=None, mul=None, add=None, eps=1e-6,
-                round_residual=False, round_norm=False, want_residual=False, rows_per_batch=None):
-    """See fvk_ln_modulate_bf16.  x/residual bf16 [..., d]; gate/mul/add fp32 [B, d] (or [B,1,d])."""
+                round_residual=False, round_norm=False, want_residual=False, rows_per_batch=None, fp8_rowwise=None):
+    """See fvk_ln_modulate_bf16.  x/residual bf16 [..., d]; gate/mul/add fp32 [B, d] (or [B,1,d]).
+    fp8_rowwise: None = bf16 output only; "only" = the per-token e4m3 quantisation (q [M,d] float8_e4m3fn, scale [M,1] fp32) INSTEAD of the
+    bf16 output, "both" = the bf16 output and the pair (fvk_ln_modulate_fp8_bf16).  The first returned value is then (q, scale) or
+    (out, (q, scale))."""
     _chk(x, BF16, "x")
     d = x.shape[-1]
     x2 = x.contiguous().view(-1, d)
@@ -64,15 +67,24 @@ def ln_modulate(x, *, residual=None, gate=None, ln_w=None, ln_b=None, mul=None, 
             B = max(B, t.numel() // d)
     if rows_per_batch is None:
         rows_per_batch = max(M // B, 1)
-    out = torch.empty_like(x2)
+    if fp8_rowwise not in (None, "only", "both"):
+        raise ValueError(f"ln_modulate: fp8_rowwise={fp8_rowwise!r} (None, 'only' or 'both')")
+    out = torch.empty_like(x2) if fp8_rowwise != "only" else None
     res_out = torch.empty_like(x2) if want_residual else None
     flags = (LN_ROUND_RESIDUAL if round_residual else 0) | (LN_ROUND_NORM if round_norm else 0)
     gate, mul, add, ln_w, ln_b = (_f32(t, n) for t, n in ((gate, "gate"), (mul, "mul"), (add, "add"),
                                                           (ln_w, "ln_w"), (ln_b, "ln_b")))
-    _lib.call("fvk_ln_modulate_bf16", _p(x2), _p(res2), _p(gate), _p(ln_w), _p(ln_b), _p(mul), _p(add), _p(res_out),
-              _p(out), M, d, rows_per_batch, float(eps), flags, _stream())
-    out = out.view(x.shape)
-    return (out, res_out.view(x.shape)) if want_residual else out
+    if fp8_rowwise is None:
+        _lib.call("fvk_ln_modulate_bf16", _p(x2), _p(res2), _p(gate), _p(ln_w), _p(ln_b), _p(mul), _p(add), _p(res_out),
+                  _p(out), M, d, rows_per_batch, float(eps), flags, _stream())
+        first = out.view(x.shape)
+    else:
+        q = torch.empty((M, d), dtype=FP8, device=x.device)
+        qs = torch.empty((M,), dtype=torch.float32, device=x.device)
+        _lib.call("fvk_ln_modulate_fp8_bf16", _p(x2), _p(res2), _p(gate), _p(ln_w), _p(ln_b), _p(mul), _p(add), _p(res_out),
+                  _p(out), _p(q), _p(qs), M, d, rows_per_batch, float(eps), flags, _stream())
+        first = (q, qs.view(M, 1)) if out is None else (out.view(x.shape), (q, qs.view(M, 1)))
+    return (first, res_out.view(x.shape)) if want_residual else first
 
 
 def scale_residual(residual, x, gate=None, rows_per_batch=None):

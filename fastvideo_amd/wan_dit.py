@@ -439,7 +439,10 @@ class WanTransformer3DModelHip:
         """y = epilogue(x @ W^T + bias) through the bf16 GEMM or the fp8 path (dynamic activation quantisation + fp8 MFMA GEMM)."""
         if not self.quant:
             return ops.gemm(x, b[key + "_w"], bias, **kw)
-        xq, xs = ops.fp8_quantize(x, rowwise=(self.quant == "fp8_channel"))
+        if isinstance(x, tuple):  # already quantised per token by the producing LayerNorm pass (ops.ln_modulate(fp8_rowwise=...))
+            xq, xs = x
+        else:
+            xq, xs = ops.fp8_quantize(x, rowwise=(self.quant == "fp8_channel"))
         return ops.gemm_fp8(xq, xs, b[key + "_q"], b[key + "_s"], bias, **kw)
 
     # ------------------------------------------------------------------ forward
@@ -519,7 +522,10 @@ class WanTransformer3DModelHip:
         x = x.reshape(B * Sl, d)
         for i, b in enumerate(self.blocks):
             shift_i, mul_i, gate_i, c_shift_i, mul_c_i, c_gate_i = mods(i)
-            nh = ops.ln_modulate(x, mul=mul_i, add=shift_i, eps=self.eps, rows_per_batch=rpb)
+            # fp8_channel: the per-token quantisation of a LayerNorm output that only feeds linears is written by the LayerNorm pass itself
+            # (byte-identical to the stand-alone quantiser; no bf16 copy, no absmax + quantise passes)
+            fq = "only" if self.quant == "fp8_channel" else None
+            nh = ops.ln_modulate(x, mul=mul_i, add=shift_i, eps=self.eps, rows_per_batch=rpb, fp8_rowwise=fq if b["n_qkv"] != 4 else None)
             if self.quant and b["n_qkv"] == 4:
                 qkv = torch.empty((B * Sl, 4 * d), dtype=BF16, device=dev)
                 self._lin(nh, b, "qkv", b["qkv_b"], out=qkv[:, :3 * d])
@@ -555,7 +561,7 @@ class WanTransformer3DModelHip:
                     attn[bi * Sl:(bi + 1) * Sl] = o
             a_out = self._lin(attn, b, "o", b["o_b"])
             nh, x = ops.ln_modulate(a_out, residual=x, gate=gate_i, ln_w=b["ln2_w"], ln_b=b["ln2_b"], eps=self.eps,
-                                    want_residual=True, rows_per_batch=rpb)
+                                    want_residual=True, rows_per_batch=rpb, fp8_rowwise=fq)
             if trace is not None:
                 trace[f"blocks.{i}.after_self_attn"] = x.view(B, Sl, d).clone()
             # cross attention over the text tokens (WanT2VCrossAttention, wanvideo.py:188-222)
@@ -567,7 +573,7 @@ class WanTransformer3DModelHip:
                                 layout="bshd")
             c_out = self._lin(co.view(B * Sl, d), b, "co", b["co_b"])
             nh, x = ops.ln_modulate(c_out, residual=x, mul=mul_c_i, add=c_shift_i, eps=self.eps, round_residual=True,
-                                    round_norm=True, want_residual=True, rows_per_batch=rpb)
+                                    round_norm=True, want_residual=True, rows_per_batch=rpb, fp8_rowwise=fq)
             f = self._lin(nh, b, "f1", b["f1_b"], epilogue=ops.EPI_GELU_TANH)
             x = self._lin(f, b, "f2", b["f2_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=c_gate_i, rows_per_batch=rpb)
             if trace is not None:

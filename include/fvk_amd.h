@@ -62,6 +62,13 @@ int fvk_ln_modulate_bf16(const void* x, const void* residual, const float* gate,
                          const float* ln_b, const float* mul, const float* add, void* res_out, void* out,
                          int M, int d, int rows_per_batch, float eps, int flags, void* stream);
 
+/* fvk_ln_modulate_bf16 that ALSO (out != NULL) or ONLY (out == NULL) writes the per-token e4m3 quantisation of its bf16 output row:
+ * q_out [M, d] e4m3 bytes, q_scale [M] fp32 — byte- and bit-identical to fvk_fp8_quantize_bf16(rowwise = 1) applied to the bf16 output
+ * (ref: _quantize_rowwise, fastvideo/layers/quantization/fp8_config.py:62-68; the fp8_channel linear that consumes the row then needs no
+ * separate absmax + quantise passes). */
+int fvk_ln_modulate_fp8_bf16(const void* x, const void* residual, const float* gate, const float* ln_w, const float* ln_b, const float* mul,
+                             const float* add, void* res_out, void* out, void* q_out, float* q_scale, int M, int d, int rows_per_batch,
+                             float eps, int flags, void* stream);
 /* out = bf16(residual + x * gate) — ScaleResidual (ref: layernorm.py:91-109). gate fp32 [M/rows_per_batch, d]. */
 int fvk_scale_residual_bf16(const void* residual, const void* x, const float* gate, void* out, int M, int d,
                             int rows_per_batch, void* stream);

@@ -7,6 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "fp8_quant.pt")
+DEV = "cuda"
 
 
 @pytest.fixture(scope="module")
@@ -84,3 +85,33 @@ def test_fp8_errors_are_loud(ops):
         ops.gemm_fp8(q[:, :32].contiguous(), s, q[:, :32].contiguous(), s)   # K % 64 != 0
     with pytest.raises(RuntimeError):
         ops.fp8_quantize(x.float())
+
+
+@pytest.mark.parametrize("M,d", [(700, 1536), (130, 5120), (64, 256)])
+def test_ln_modulate_writes_the_per_token_quantisation(ops, M, d):
+    """fvk_ln_modulate_fp8_bf16: the LayerNorm / modulation pass writes the per-token e4m3 quantisation of its bf16 output row — bytes and scales
+    identical to fvk_fp8_quantize_bf16(rowwise) applied to that output — in the three forms the DiT block uses (plain modulation; gated residual
+    + affine LayerNorm; residual + modulation with the reference's bf16 rounding points), instead of or beside the bf16 output."""
+    g = torch.Generator().manual_seed(M + d)
+    x, res = (torch.randn((M, d), generator=g) * 3).bfloat16().to(DEV), torch.randn((M, d), generator=g).bfloat16().to(DEV)
+    x[5] *= 200.0          # a row whose quotient clamps at 448 nowhere but whose scale differs by orders of magnitude
+    x[7] = 0               # an all-zero row: the floor of the scale
+    gate, mul, add = (torch.randn((2, d), generator=g).to(DEV) for _ in range(3))
+    lw, lb = torch.randn(d, generator=g).to(DEV), torch.randn(d, generator=g).to(DEV)
+    rpb = M // 2
+    forms = [dict(mul=1 + mul, add=add, rows_per_batch=rpb),
+             dict(residual=res, gate=gate, ln_w=lw, ln_b=lb, want_residual=True, rows_per_batch=rpb),
+             dict(residual=res, mul=1 + mul, add=add, round_residual=True, round_norm=True, want_residual=True, rows_per_batch=rpb)]
+    for kw in forms:
+        ref = ops.ln_modulate(x, **kw)
+        ref_out, ref_res = ref if kw.get("want_residual") else (ref, None)
+        q_ref, s_ref = ops.fp8_quantize(ref_out, rowwise=True)
+        for mode in ("only", "both"):
+            got = ops.ln_modulate(x, fp8_rowwise=mode, **kw)
+            first, got_res = got if kw.get("want_residual") else (got, None)
+            out, (q, s) = (None, first) if mode == "only" else first
+            assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8)) and torch.equal(s, s_ref)
+            assert out is None or torch.equal(out, ref_out)
+            assert ref_res is None or torch.equal(got_res, ref_res)
+    with pytest.raises(ValueError, match="fp8_rowwise"):
+        ops.ln_modulate(x, fp8_rowwise="yes")
