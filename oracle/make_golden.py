@@ -76,6 +76,8 @@ def vsa_meta():
 
 
 def rope():
+    """rope.pt: sampled rows + checksums of the reference tables (start_frame = 0); rope_start.pt (round 4): the FULL fp32 tables of small
+    grids with start_frame > 0 (the causal rollout's call, causal_wanvideo.py:586-598) and sampled rows + checksums at the 480p block grid."""
     from fastvideo.layers.rotary_embedding import get_rotary_pos_embed
     res = {}
     for grid in [(21, 30, 52), (3, 4, 4), (3, 5, 7)]:
@@ -87,11 +89,25 @@ def rope():
                                              cos_abs=cos.double().abs().sum().item())
     torch.save(res, os.path.join(OUT, "rope.pt"))
     print("rope.pt ok")
+    res = {}
+    for grid, start in [((3, 4, 4), 0), ((3, 4, 4), 3), ((2, 5, 7), 6), ((3, 30, 52), 18), ((1, 30, 52), 20)]:
+        cos, sin = get_rotary_pos_embed(grid, 1536, 12, [44, 42, 42], dtype=torch.float64, rope_theta=10000, start_frame=start)
+        cos, sin = cos.float(), sin.float()
+        ent = dict(cos_sum=cos.double().sum().item(), sin_sum=sin.double().sum().item(), cos_abs=cos.double().abs().sum().item())
+        if cos.shape[0] <= 128:
+            ent.update(rows=torch.arange(cos.shape[0]), cos=cos.clone(), sin=sin.clone())
+        else:
+            rows = torch.tensor([0, 1, grid[2], grid[1] * grid[2] - 1, cos.shape[0] // 2, cos.shape[0] - 1])
+            ent.update(rows=rows, cos=cos[rows].clone(), sin=sin[rows].clone())
+        res["x".join(map(str, grid)) + f"@{start}"] = ent
+    torch.save(res, os.path.join(OUT, "rope_start.pt"))
+    print("rope_start.pt ok")
 
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     R.init_distributed()
-    wan_tiny()
-    vsa_meta()
-    rope()
+    only = sys.argv[1:]
+    for fn in (wan_tiny, vsa_meta, rope):
+        if not only or fn.__name__ in only:
+            fn()
