@@ -167,8 +167,8 @@ def attention_traffic_from_profiles(kernel="attn_w16"):
 
 
 def vae_cpu_baseline(latent_shape, budget_frames=2):
-    """CPU baseline of the VAE stage on a bounded sample: the reference's own ``AutoencoderKLWan.decode`` (fp32, its
-    default precision) on the first ``budget_frames`` latent frames at the full spatial size, when a reference tree is present (live or
+    """CPU baseline of the VAE stage on a bounded sample: the reference's own ``AutoencoderKLWan.decode`` (fp32 on the host — the
+    CPU has no bf16 autocast speed-up to offer) on the first ``budget_frames`` latent frames at the full spatial size, when a reference tree is present (live or
     staged); else the oracle port (oracle/vae_oracle.py).  Scaled to the full latent by algorithmic FLOPs."""
     from fastvideo_amd.wan_config import vae_decode_flops
     _, _, T, H, W = latent_shape
@@ -212,8 +212,9 @@ def vae_cpu_baseline(latent_shape, budget_frames=2):
 def measure_vae(latent_shape, steps, warmup, frames_per_pass=4):
     """One step = one causal-3D-conv VAE decode (``AutoencoderKLWan.decode``, fastvideo/models/vaes/wanvae.py:1189-1215) of ``latent_shape``
     on the current GPU: cfg2 [1,16,21,60,104] -> [1,3,81,480,832], cfg5 [1,16,33,90,160] -> [1,3,129,720,1280]; random-init Wan2.1-VAE
-    decoder (base_dim 96, 73 M parameters).  Served precision: the reference's ``vae_precision = "bf16"`` mode (bf16 activations, fp32
-    accumulation, fp32 norms, fp32 pixels out) — NOT its default "fp32", which WanVaeDecoderHip refuses; parity at real frame sizes against
+    decoder (base_dim 96, 73 M parameters).  Served precision: bf16 autocast (bf16 activations, fp32 accumulation, fp32 norms, fp32
+    pixels out) — the Wan pipelines' decode default (``vae_decode_precision = "bf16"``, configs/pipelines/wan.py:59, preferred by
+    decoding.py:165-167); an explicit "fp32" override is refused by WanVaeDecoderHip, not served.  Parity at real frame sizes against
     the reference's fp32 decode, bounded by the reference's own bf16-autocast error: tests/test_gpu_vae_real.py."""
     from fastvideo_amd import ops
     from fastvideo_amd.wan_config import vae_decode_flops, wan_vae_param_spec
@@ -259,8 +260,8 @@ def measure_vae(latent_shape, steps, warmup, frames_per_pass=4):
     return {"metric": f"Wan2.1 VAE decode, latent {list(latent_shape)} -> pixels {list(y.shape)} (one decode per step)",
             "value": round(frames / (elapsed / steps), 2), "unit": "pixel-frames/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 (the reference's vae_precision='bf16' mode: bf16 activations / MFMA operands, fp32 accumulation + norms, fp32 pixels; "
-                     "its default 'fp32' is refused, not served)",
+            "dtype": "bf16 (the Wan pipelines' decode default, vae_decode_precision='bf16', configs/pipelines/wan.py:59: bf16 activations / MFMA "
+                     "operands, fp32 accumulation + norms, fp32 pixels; an explicit 'fp32' override is refused, not served)",
             "data": "synthetic (randn latent, random-init decoder)",
             "config": {"workload": f"Wan2.1 VAE decoder (base_dim 96), frame-chunked cached decode of latent {list(latent_shape)}", "parallelism": "1 GPU",
                        "frames_per_pass": frames_per_pass},

@@ -81,9 +81,10 @@ class WanVaeDecoderHip:
         **"bf16"** mode only: bf16 activations in HBM, bf16 MFMA operands, fp32 accumulation and fp32 norm / SiLU arithmetic — the
         same rounding points as the reference's bf16 autocast (conv outputs and residual sums bf16, norms fp32).  Its error against
         the reference's fp32 decode is bounded, quantile by quantile, by the error of the reference's OWN bf16-autocast decode at
-        real frame sizes (tests/test_gpu_vae_real.py).  "fp32" — the Wan pipeline's default (configs/pipelines/wan.py:54), whose
-        own test tolerance is atol 1e-5 (tests/vaes/test_wan_vae.py:87) — is REFUSED rather than silently served at lower
-        precision: a pipeline that needs fp32 pixels keeps the reference decoder; "fp16" is refused too (no fp16 kernels)."""
+        real frame sizes (tests/test_gpu_vae_real.py).  bf16 IS the Wan pipeline's decode default: ``vae_decode_precision = "bf16"``
+        (configs/pipelines/wan.py:59) wins over ``vae_precision = "fp32"`` (wan.py:54, kept for the ENCODE) in decoding.py:165-167.
+        "fp32" (a user override; the reference's own fp32 test tolerance is atol 1e-5, tests/vaes/test_wan_vae.py:87) is REFUSED
+        rather than silently served at lower precision; "fp16" is refused too (no fp16 kernels)."""
         if precision != "bf16":
             raise ValueError(f"WanVaeDecoderHip serves vae_precision='bf16' only (got {precision!r}): the gfx950 decode keeps bf16 "
                              "activations with fp32 accumulation; set pipeline_config.vae_precision / vae_decode_precision to 'bf16' or keep "
