@@ -396,10 +396,11 @@ def main():
     if args.attention == "dense":
         # launches may differ in head count (pipelined SP exchange: two head chunks per layer): total FLOPs / total time
         flops_launch = sum(4.0 * sq_ * skv_ * h_ * cfg.head_dim for _, _, sq_, skv_, h_ in events) / len(events)
-        from fastvideo_amd import ops as _ops
-        dense_kernel = "attn_w64" if model.attn_kernel == _ops.ATTN_KERNEL_W64 else "attn_w16"
-        kname = (f"{dense_kernel}_kernel (dense self-attention: 4 waves x 64 query rows, one wave per SIMD, "
-                 f"{'32x32x16' if dense_kernel == 'attn_w64' else '16x16x32'} MFMAs, 64-key sub-tiles software-pipelined in the wave)")
+        ran = model.dense_kernel_ran or "attn_w16"       # what the last self-attention launch actually ran (wan_dit._dense_attn)
+        dense_kernel = "attn_w64" if ran == "attn_w64" else "attn_pp2" if ran == "attn_pp2" else "attn_w16"
+        kname = (f"{ran}_kernel (dense self-attention: 4 waves x 64 query rows, one wave per SIMD, "
+                 f"{'32x32x16' if dense_kernel == 'attn_w64' else '16x16x32'} MFMAs, 64-key sub-tiles software-pipelined in the wave)"
+                 if dense_kernel != "attn_pp2" else "attn_pp2_kernel (dense self-attention, short key axis: 8-wave ping-pong kernel)")
     else:
         # sparse modes: the algorithmic work is the selected fraction of the dense score matrix (VSA: top-k of the 64-token blocks
         # + the coarse branch, negligible; STA: the window's share of key tokens); the timed region is the whole attention

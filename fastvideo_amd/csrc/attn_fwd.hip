@@ -509,7 +509,7 @@ int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
 static int attn_dense_impl(const fvk_attn_args* a, int kernel, void* stream) {
     int rc = check_common(a, "fvk_attn_dense_bf16");
     if (rc) return rc;
-    FVK_CHECK(kernel >= 0 && kernel <= 2, FVK_ERR_ARG, "fvk_attn_dense_kernel_bf16: kernel=%d (0 default, 1 attn_w16, 2 attn_w64)", kernel);
+    FVK_CHECK(kernel >= 0 && kernel <= 3, FVK_ERR_ARG, "fvk_attn_dense_kernel_bf16: kernel=%d (0 default, 1 attn_w16, 2 attn_w64, 3 attn_pp2)", kernel);
     // full-length query blocks go to the 8-wave ping-pong kernel (attn_pp.hip); "attn_impl" = 1 forces this 4-wave kernel,
     // 2 / 3 select the alternative DMA placements of the ping-pong kernel (measurement only)
     FVK_CHECK(a->qk_dim == 0 || a->qk_dim == 128 || a->qk_dim == 384, FVK_ERR_ARG, "fvk_attn_dense_bf16: qk_dim=%d unsupported (128 or 384)",
@@ -535,7 +535,7 @@ static int attn_dense_impl(const fvk_attn_args* a, int kernel, void* stream) {
         // cost more than its leaner stream saves below ~1 800 keys (same box, 32 760 x 12 queries, us attn_pp2 / attn_w16: 512 keys 130 / 153,
         // 1024: 213 / 232, 1536: 295 / 303, 2048: 379 / 368, 3072: 541 / 511, 4096: 701 / 656; profiles/r03_attn_short_keys.log)
         if (impl == 0) {
-            if (a->Skv < 2048) return fvk_attn_pp2_launch(a, 0, (hipStream_t)stream);
+            if (a->Skv < 2048 || kernel == 3) return fvk_attn_pp2_launch(a, 0, (hipStream_t)stream);  // 3: online softmax at any length
             // long key axes: the one-wave-per-SIMD design, on 16x16x32 MFMAs (attn_w16.hip, the default) or 32x32x16 (attn_w64.hip).  The two
             // agree to rounding.  attn_w16 needs ~6 % more matrix-pipe cycles and a fifth less energy per FLOP: launched back to back it
             // settles at a higher clock and is 5 % faster, but between the GEMMs of a DiT block the clock does not always get there within

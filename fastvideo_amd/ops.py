@@ -99,22 +99,28 @@ def scale_residual(residual, x, gate=None, rows_per_batch=None):
     return out.view(x.shape)
 
 
-_ROW_MAPS_OK: dict = {}
+import weakref
+
+_ROW_MAPS_OK: dict = {}  # id(map tensor) -> {(version, output rows)}; the entry dies with the tensor (weakref.finalize)
 
 
 def _check_row_map(rmap, n_out_rows):
-    """A scatter map is dereferenced by the kernel without a bound: check max(map) < rows of the output ONCE per (map storage,
+    """A scatter map is dereferenced by the kernel without a bound: check max(map) < rows of the output ONCE per (map tensor,
     version, output rows) — the maps are per-geometry metadata built once and reused every layer, so this costs one device
-    sync per geometry, not per call."""
-    key = (rmap.data_ptr(), rmap.numel(), rmap._version, int(n_out_rows))
-    if key in _ROW_MAPS_OK:
+    sync per geometry, not per call.  Keyed on the tensor OBJECT, not its address: the entry is dropped when the tensor is collected, so
+    a freed map whose storage (or id) is reused by another map of the same length can never inherit the verdict."""
+    seen = _ROW_MAPS_OK.get(id(rmap))
+    key = (rmap._version, int(n_out_rows))
+    if seen is not None and key in seen:
         return
     hi = int(rmap.max().item()) if rmap.numel() else -1
     if hi >= n_out_rows:
         raise RuntimeError(f"rmsnorm_rope: row map addresses row {hi} of an output with {n_out_rows} rows")
-    if len(_ROW_MAPS_OK) > 256:
-        _ROW_MAPS_OK.clear()
-    _ROW_MAPS_OK[key] = True
+    if seen is None:
+        _ROW_MAPS_OK[id(rmap)] = {key}
+        weakref.finalize(rmap, _ROW_MAPS_OK.pop, id(rmap), None)
+    else:
+        seen.add(key)
 
 
 def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_len=None, eps=1e-6, outs=None, pos_offset=0, row_maps=None):
@@ -363,7 +369,22 @@ def attn_key_splits(n_query_blocks: int, n_stages: int) -> int:
     return best
 
 
-ATTN_KERNEL_DEFAULT, ATTN_KERNEL_W16, ATTN_KERNEL_W64 = 0, 1, 2  # fvk_attn_dense_kernel_bf16: the long-key kernel on 16x16x32 / 32x32x16 MFMAs
+def attn_key_splits_for(q, k, layout="bshd") -> int:
+    """The key-run count attn_dense(key_splits=None) picks for these operands (1 = the plain kernels)."""
+    if layout == "bshd":
+        B, Sq, H, D = q.shape
+        Skv = k.shape[1]
+    else:
+        B, H, Sq, D = q.shape
+        Skv = k.shape[2]
+    if Sq < 256 or D != 128:
+        return 1
+    return attn_key_splits(-(-Sq // 256) * H * B, -(-Skv // 128))
+
+
+# fvk_attn_dense_kernel_bf16: the long-key kernel on 16x16x32 / 32x32x16 MFMAs (fixed softmax reference), or the 8-wave online-softmax kernel
+# at any key length (the flash-attention rounding points; for parity-critical callers)
+ATTN_KERNEL_DEFAULT, ATTN_KERNEL_W16, ATTN_KERNEL_W64, ATTN_KERNEL_PP2 = 0, 1, 2, 3
 
 
 def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, return_lse=False, key_splits=None, kernel=ATTN_KERNEL_DEFAULT):
@@ -382,10 +403,12 @@ def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, retur
         lse = torch.empty((B, H, Sq), dtype=torch.float32, device=q.device)
     a = _attn_args(q, k, vt, o, scale, layout, lse)
     if key_splits is None:
-        key_splits = 1
-        if a.Sq >= 256 and q.shape[-1] == 128:
-            key_splits = attn_key_splits(-(-a.Sq // 256) * a.H * a.B, -(-a.Skv // 128))
+        key_splits = attn_key_splits_for(q, k, layout)
     if key_splits > 1:
+        if kernel in (ATTN_KERNEL_W64, ATTN_KERNEL_PP2):
+            # the split-KV form exists on attn_w16 only: never run a kernel other than the one the caller named (and may report)
+            raise RuntimeError(f"attn_dense: kernel={kernel} cannot be combined with key_splits > 1 (the split-KV form runs attn_w16); "
+                               "pass key_splits=1 or the default kernel")
         rows = a.B * a.H * a.Sq
         o_part = torch.empty((key_splits, rows, 128), dtype=torch.float32, device=q.device)
         lse_part = torch.empty((key_splits, rows), dtype=torch.float32, device=q.device)

@@ -75,6 +75,7 @@ class WanTransformer3DModelHip:
         self.attn_kernel = ops.ATTN_KERNEL_DEFAULT
         self.attn_autotune = bool(attn_autotune)
         self.attn_tune_report = None
+        self.dense_kernel_ran = None  # name of the kernel the LAST dense self-attention launch ran (bench.py reports it)
         self._tune = None
         self._forwards = 0
         self.vsa_trace = None    # set to a list to collect every layer's VSA block mask (tests)
@@ -224,6 +225,35 @@ class WanTransformer3DModelHip:
         self.attn_tune_report = {"attn_w16_ms": round(med[ops.ATTN_KERNEL_W16], 4), "attn_w64_ms": round(med[ops.ATTN_KERNEL_W64], 4),
                                  "launches_timed": len(ev) - 2, "kept": "attn_w16" if self.attn_kernel == ops.ATTN_KERNEL_W16 else "attn_w64"}
 
+    def _dense_attn(self, q4, k4, v4):
+        """Dense self-attention of ALL batch elements in ONE launch: q4 [B,Sq,h,D], k4 / v4 [B,Skv,h,D] (strided views ok) -> o [B,Sq,h,D].
+        The reference runs the classifier-free-guidance pair as two forwards (denoising.py:497-560); batched here (DenoisingLoopHip(cfg_batch=
+        True)) the pair shares every launch — per sample the arithmetic is the same (rows and batch elements are independent in every kernel)."""
+        vt = ops.v_transpose(v4)
+        kern, tune = self.attn_kernel, self._tune
+        splits = ops.attn_key_splits_for(q4, k4)
+        long_keys = q4.shape[1] >= 256 and k4.shape[1] >= 2048
+        if splits > 1 or not long_keys:
+            # short key axes take the 8-wave kernel and split-KV grids always run attn_w16 (fvk_attn_dense_split_bf16): nothing to choose
+            # between, nothing to time — and the kernel a caller may report is the one that ran
+            kern, tune = ops.ATTN_KERNEL_DEFAULT, None
+        elif tune is not None:
+            kern = (ops.ATTN_KERNEL_W16, ops.ATTN_KERNEL_W64)[len(tune) % 2]
+        self.dense_kernel_ran = (f"attn_w16 split-KV x{splits}" if splits > 1 else "attn_pp2" if not long_keys else
+                                 "attn_w64" if kern == ops.ATTN_KERNEL_W64 else "attn_w16")
+        if self.attn_events is None and tune is None:
+            return ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd", kernel=kern)
+        # bench.py roofline leg / the in-place kernel choice: HIP events on the launch stream around the dominant kernel only
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        o = ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd", kernel=kern)
+        e1.record()
+        if self.attn_events is not None:
+            self.attn_events.append((e0, e1, q4.shape[1], k4.shape[1], q4.shape[2] * q4.shape[0]))
+        if tune is not None:
+            tune.append((kern, e0, e1))
+        return o
+
     def _attn_local(self, q, k, v, kv_len, grid, gate=None):
         if self.attn_events is None or self.attention == "dense":
             return self._attn_local_impl(q, k, v, kv_len, grid, gate)
@@ -239,24 +269,7 @@ class WanTransformer3DModelHip:
         """q [Sq,h,D], k/v [Skv,h,D] (strided views ok) -> o [Sq,h,D] contiguous."""
         q4, k4, v4 = q.unsqueeze(0), k[:kv_len].unsqueeze(0), v[:kv_len].unsqueeze(0)
         if self.attention == "dense":
-            vt = ops.v_transpose(v4)
-            kern, tune = self.attn_kernel, self._tune
-            if tune is not None and q4.shape[1] >= 256 and k4.shape[1] >= 2048:
-                kern = (ops.ATTN_KERNEL_W16, ops.ATTN_KERNEL_W64)[len(tune) % 2]
-            elif tune is not None:
-                tune = None
-            if self.attn_events is None and tune is None:
-                return ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd", kernel=kern)[0]
-            # bench.py roofline leg / the in-place kernel choice: HIP events on the launch stream around the dominant kernel only
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            o = ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd", kernel=kern)[0]
-            e1.record()
-            if self.attn_events is not None:
-                self.attn_events.append((e0, e1, q4.shape[1], k4.shape[1], q4.shape[2]))
-            if tune is not None:
-                tune.append((kern, e0, e1))
-            return o
+            return self._dense_attn(q4, k4, v4)[0]
         if self.attention == "vsa":
             # ref: VideoSparseAttentionImpl.preprocess_qkv / forward / postprocess_output (video_sparse_attn.py:254-342)
             # Everything stays [1, S_pad, h, D] ("bshd"): the kernels take strides, so there is no transpose / contiguous copy; the four
@@ -408,7 +421,16 @@ class WanTransformer3DModelHip:
             if want:
                 res, inter = res
                 self.vsa_trace.append(inter["mask"])
-            return res[0]
+            return zero_pad_rows(res[0], n)
+
+        def zero_pad_rows(o, n):
+            # rows >= S are the shards' zero-padding tokens (S % P != 0): no tile-major row maps to them, so the scattering epilogues never
+            # write them, and exchange #2 ships them to the last shard's owner, where they enter the o-projection — harmless for the
+            # row-wise bf16 path (all_gather_unpad drops them), but a tensor-wise fp8 absmax over all rows would take its scale from
+            # uninitialised memory.  The dense path's pad queries are finite by construction; make these finite (zero) too.
+            if n > S:
+                o[S:].zero_()
+            return o
 
         def sta_fn(r4, plan):
             n, NS, hg, _ = r4.shape
@@ -420,7 +442,7 @@ class WanTransformer3DModelHip:
             vt = ops.v_transpose(r4[:S, 1].unsqueeze(0), src_rows=m["v_src_rows"])
             o = ops.attn_tile_lists(qg, kt, None, m["group_q2k_idx"], m["group_q2k_num"], m["block_sizes"], 256, None, scale=D**-0.5,
                                     layout="bshd", vt=vt, o_rows=m["group_token_of_row"], n_out_rows=n)
-            return o[0]
+            return zero_pad_rows(o[0], n)
 
         fn = vsa_fn if self.attention == "vsa" else sta_fn
         if self.attn_events is not None:
@@ -533,8 +555,14 @@ class WanTransformer3DModelHip:
             else:
                 qkv = self._lin(nh, b, "qkv", b["qkv_b"])  # [B*Sl, 3d (+d gate)]; fp8: nh quantised once for q, k and v (wants_prequantized_input)
             nq = b["n_qkv"]
-            attn = torch.empty((B * Sl, d), dtype=BF16, device=dev) if B > 1 else None
-            for bi in range(B):
+            batched = B > 1 and P == 1 and self.attention == "dense"
+            attn = torch.empty((B * Sl, d), dtype=BF16, device=dev) if (B > 1 and not batched) else None
+            if batched:
+                # all batch elements (the classifier-free-guidance pair) in one QK-norm / RoPE pass, one V^T pass and ONE attention launch:
+                # positions are row % S in the norm pass, the attention kernels take the batch as a grid dimension
+                qn, kn = ops.rmsnorm_rope([qkv[:, :d], qkv[:, d:2 * d]], [b["nq_w"], b["nk_w"]], cos, sin, head_dim=D, seq_len=S, eps=self.eps)
+                attn = self._dense_attn(qn.view(B, S, H, D), kn.view(B, S, H, D), qkv[:, 2 * d:3 * d].view(B, S, H, D)).view(B * S, d)
+            for bi in range(0 if batched else B):
                 rows = qkv[bi * Sl:(bi + 1) * Sl]
                 gate = rows[:, 3 * d:4 * d].view(Sl, H, D) if nq == 4 else None
                 fn = lambda q_, k_, v_, kv_len, g_=None: self._attn_local(q_, k_, v_, kv_len, grid, g_)

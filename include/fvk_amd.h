@@ -190,7 +190,10 @@ int fvk_attn_dense_bf16(const fvk_attn_args* a, void* stream);
  * matrix-pipe cycles), 2 = attn_w64 (32x32x16 MFMAs).  Same result to rounding (different summation order inside the MFMA; kernel 2 sums the
  * fp32 probabilities for lse).  Which is faster depends on the clock the device reaches in the CALLER'S launch sequence: back to back kernel 1
  * is ~5 % faster, between the GEMMs of a DiT block it is anywhere from 5 % faster to 5 % slower (profiles/r03_attn_context.md); a caller that
- * cares times both in place once.  Key axes below 2048 ignore the choice (8-wave kernel). */
+ * cares times both in place once.  Key axes below 2048 ignore the choice (8-wave kernel).
+ * kernel 3 = attn_pp2 at ANY key length: the 8-wave kernel with the reference kernels' ONLINE softmax (running row max, rescale of O) — for a
+ * parity-critical caller that wants the flash-attention rounding points (P rounded after subtracting the running maximum, as
+ * flash_attn.py / st_attn_triton.py do) rather than the long-key kernels' fixed softmax reference; ~10 % slower at 32 760 keys. */
 int fvk_attn_dense_kernel_bf16(const fvk_attn_args* a, int kernel, void* stream);
 /* The same attention with the KEY axis cut into n_split runs of whole 128-key stages, each (query block, head, batch, run) its own workgroup,
  * and a merge pass: for grids too small to fill the 256 CUs — the per-rank shapes of sequence parallelism (SP = 8 on Wan2.1-1.3B: 3 heads x

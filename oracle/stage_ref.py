@@ -18,8 +18,8 @@ import recipe loads for a DiT forward, a VAE decode, the VSA backend and the Uni
 whole tree (``tree_sha256``), which ``bench.py`` prints next to a ``kind: "reference"`` CPU baseline.
 
 ``stage()`` is a PURE FILE COPY: it never imports or executes reference code.  It is an explicit step of the test / bench harness
-(``python -m oracle.stage_ref``, also called by ``scripts/gpu_round.sh`` before a gpurun); ``__graft_entry__.build()`` does not call
-it.  The list itself is regenerated only on request (``python -m oracle.stage_ref --discover``: runs the import recipe in a
+(``python -m oracle.stage_ref``, also called by ``scripts/gpu_round.sh`` before a gpurun) and ``__graft_entry__.build()`` calls it
+best-effort AFTER the product library is built and loaded (a failure there is a warning, never a build failure).  The list itself is regenerated only on request (``python -m oracle.stage_ref --discover``: runs the import recipe in a
 subprocess and lists ``sys.modules`` — the one place reference code executes, never part of a build).
 """
 from __future__ import annotations
