@@ -209,6 +209,53 @@ def vae_cpu_baseline(latent_shape, budget_frames=2):
                        f"scaled by algorithmic FLOPs x{scale:.2f} to {T} latent frames", ms_per_step=round(per_decode * 1e3, 1))
 
 
+def measure_cfg_step(model, cfg, latent, ctx, steps=4, warmup=1):
+    """The REAL denoising step of the BASELINE config (SURVEY §8 a1 / §8d: "a CFG step = 2 forwards, reported separately";
+    fastvideo/pipelines/stages/denoising.py:372-596): conditional + unconditional DiT forward on the bf16 latent, then the fused
+    classifier-free-guidance combine + FlowUniPC scheduler step on the fp32 latent (fvk_cfg_unipc_step) — measured both as the reference
+    runs it (two forwards per step) and with the pair as ONE batch-2 forward (DenoisingLoopHip(cfg_batch=True): bit-identical per sample,
+    tests/test_gpu_sched.py; half the launches, twice the grid per launch).  Dense self-attention launches are timed with HIP events in
+    both modes, which answers whether the longer launches of the batched pair hold the clock better."""
+    from fastvideo_amd.scheduler import DenoisingLoopHip
+    dev = latent.device
+    g = torch.Generator(device=dev).manual_seed(7)
+    neg = torch.randn(ctx.shape, generator=g, device=dev).bfloat16()
+    x0 = torch.randn(latent.shape, generator=g, device=dev)
+    out = {"what": "one classifier-free-guidance denoising step = conditional + unconditional DiT forward + fused CFG combine + FlowUniPC step "
+                   "(denoising.py:372-596), 50-step schedule, guidance 3.0, flow shift 3.0; same model, latent and text length as the contract line",
+           "steps": steps, "warmup": warmup}
+    for name, batch in (("two_forwards", False), ("batch2_forward", True)):
+        loop = DenoisingLoopHip(model, 50, flow_shift=3.0, guidance_scale=3.0, cfg_batch=batch)
+        loop.stepper.reset()
+        x, x16 = x0.clone(), x0.to(torch.bfloat16)
+        for i in range(warmup):
+            x, x16 = loop.step(i, x, x16, ctx, neg)
+        torch.cuda.synchronize()
+        model.attn_events = []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            if i == warmup + steps - 1:
+                e0.record()
+            x, x16 = loop.step(i, x, x16, ctx, neg)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        events, model.attn_events = model.attn_events, None
+        if not torch.isfinite(x).all():
+            raise RuntimeError("cfg step: non-finite latent")
+        a_ms = [a.elapsed_time(b) for a, b, *_ in events]
+        fl = sum(4.0 * sq * skv * h * cfg.head_dim for _, _, sq, skv, h in events)
+        out[name] = {"ms_per_step": round(ms, 3), "attn_launches_per_step": len(events) // steps,
+                     "attn_mean_launch_ms": round(sum(a_ms) / len(a_ms), 4), "attn_tflops": round(fl / (sum(a_ms) * 1e-3) / 1e12, 1)}
+    S = (latent.shape[2]) * (latent.shape[3] // 2) * (latent.shape[4] // 2)
+    fl_step = 2 * __import__("fastvideo_amd.wan_config", fromlist=["x"]).algorithmic_flops(cfg, S, ctx.shape[1])["total"]
+    for name in ("two_forwards", "batch2_forward"):
+        out[name]["step_tflops"] = round(fl_step / (out[name]["ms_per_step"] * 1e-3) / 1e12, 1)
+        out[name]["step_frac_of_bf16_peak"] = round(out[name]["step_tflops"] / PEAK_BF16_TFLOPS, 4)
+    out["batch2_speedup"] = round(out["two_forwards"]["ms_per_step"] / out["batch2_forward"]["ms_per_step"], 4)
+    return out
+
+
 def measure_vae(latent_shape, steps, warmup, frames_per_pass=4):
     """One step = one causal-3D-conv VAE decode (``AutoencoderKLWan.decode``, fastvideo/models/vaes/wanvae.py:1189-1215) of ``latent_shape``
     on the current GPU: cfg2 [1,16,21,60,104] -> [1,3,81,480,832], cfg5 [1,16,33,90,160] -> [1,3,129,720,1280]; random-init Wan2.1-VAE
@@ -304,6 +351,10 @@ def main():
     ap.add_argument("--quant", default=None, choices=["fp8", "fp8_channel"],
                     help="fp8 linear path (BASELINE config 5's GEMM dtype); the contract line is the default bf16 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power-trace", action="store_true", help="do not sample socket power / shader clock (amdsmi, 20 Hz, a host thread) "
+                    "during the timed region (the `power` object)")
+    ap.add_argument("--no-cfg-step", action="store_true", help="skip the `cfg_step` sub-object (the full classifier-free-guidance denoising step: "
+                    "2 forwards + fused CFG / UniPC tail, measured after the timed region)")
     ap.add_argument("--no-vae", action="store_true", help="skip the `vae` sub-object (VAE decode of the same latent, measured after the timed region)")
     ap.add_argument("--cpu-baseline-kind", default="auto", choices=["auto", "reference", "port"],
                     help="auto: the reference itself when a reference tree is present (live or staged), else the oracle port")
@@ -376,11 +427,34 @@ def main():
     model.attn_events = []
     if world > 1:
         model.sp.stats = {}  # per-exchange bytes + HIP-event pairs on the compute stream (fastvideo_amd/distributed.py)
+    sampler, power_err = None, None
+    if rank == 0 and not args.no_power_trace:
+        try:  # scripts/power_trace.py: a host thread reading socket power + shader clock at 20 Hz (measurement only; never required)
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("power_trace", os.path.join(ROOT, "scripts", "power_trace.py"))
+            pt = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(pt)
+            sampler = pt.PowerSampler(20.0, local_rank).start()
+        except Exception as ex:  # noqa: BLE001
+            sampler, power_err = None, repr(ex)[:200]
     t0 = time.perf_counter()
+    wall0 = time.time()
     for _ in range(args.steps):
         y = model(latent, ctx, ts)
     sync()
     elapsed = time.perf_counter() - t0
+    wall1 = time.time()
+    power = {"error": power_err} if power_err else None
+    if sampler is not None and not sampler.available:
+        sampler.stop()
+        power = {"error": "no power / clock source readable", "sampler_errors": sampler.errors[:4]}
+    elif sampler is not None:
+        samples = sampler.stop()
+        power = pt.summarize(samples, wall0, wall1, sampler.src.name if sampler.available else None)
+        power["what"] = ("socket power and shader clock of this GPU sampled by a host thread over the K timed steps (scripts/power_trace.py); "
+                         "a MEASURED clock, unlike roofline.clock_from_profiled_cycles_ghz")
+        if sampler.errors:
+            power["sampler_errors"] = sampler.errors[:4]
     events, model.attn_events = model.attn_events, None
     if not torch.isfinite(y.float()).all():
         raise SystemExit("non-finite output")
@@ -429,9 +503,15 @@ def main():
     if gui_cycles:
         # DVFS separated from stalls: GRBM_GUI_ACTIVE (busy shader cycles, summed over the 8 XCDs by rocprofv3; same binary, same shape, so
         # the cycle count per launch carries over) / the LIVE launch duration = the clock this run sustained; the MFMA peak scales with it
+        # NOT a per-run measurement of the clock: the cycle count comes from ONE profiled pass of this binary (a constant of the binary and
+        # the shape), only the duration is live — so "FLOP per profiled busy cycle" below is the same number in every run (it is the matrix
+        # pipe's busy share of the kernel's cycles, ~0.73), and the clock derived from it moves only with the live duration.  The MEASURED
+        # clock and power of this run are in the `power` object (amdsmi samples over the timed region).
         clk = gui_cycles / 8 / (mean_ms * 1e-3) / 1e9
-        roof.update(effective_clock_ghz=round(clk, 3), peak_at_effective_clock=round(PEAK_BF16_TFLOPS * clk / 2.4, 1),
-                    frac_of_clock_limited_peak=round(achieved / (PEAK_BF16_TFLOPS * clk / 2.4), 4))
+        roof.update(clock_from_profiled_cycles_ghz=round(clk, 3),
+                    flop_per_profiled_cycle_frac_of_peak=round(achieved / (PEAK_BF16_TFLOPS * clk / 2.4), 4),
+                    profiled_cycles_note="GRBM_GUI_ACTIVE per launch from the committed PMC pass (a constant of the binary) / the live launch "
+                                         "duration; flop_per_profiled_cycle_frac_of_peak is therefore a constant of the binary, not of this run")
     fl = WC.algorithmic_flops(cfg, S, L_text)
     if args.attention != "dense":
         # sparse modes: the algorithmic work of self-attention is the SELECTED share of the score matrix, not the dense count
@@ -453,6 +533,8 @@ def main():
         "step_tflops": round(fl["total"] / (ms_per_step * 1e-3) / 1e12, 1),
         "step_frac_of_bf16_peak": round(fl["total"] / (ms_per_step * 1e-3) / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
         "roofline": roof,
+        "power": power,
+        "timed_region_unix": [round(wall0, 4), round(wall1, 4)],  # host clock around the K timed steps: scripts/power_trace.py cuts its samples here
     }
     if world > 1:
         # sequence-parallel exchange accounting of THIS rank (rank 0): bytes sent to other ranks and the time the compute stream spent
@@ -473,6 +555,12 @@ def main():
         out["INVALID"] = "debug run with fewer layers"
     if shared:
         out["INVALID"] = "test hook: ranks share one GPU and exchange through gloo"
+    if world == 1 and args.attention == "dense" and not args.no_cfg_step:
+        # the denoising step the BASELINE config actually runs 50 times (2 forwards + the fused scheduler tail), AFTER the timed region
+        try:
+            out["cfg_step"] = measure_cfg_step(model, cfg, latent, ctx)
+        except Exception as ex:  # noqa: BLE001 - never hide the contract number
+            out["cfg_step"] = {"error": repr(ex)[:300]}
     if world == 1 and args.config in ("cfg2", "cfg5") and not args.layers and not args.no_vae:
         # the other hot kernel family of the path, measured AFTER the timed region on the same latent geometry, so that the
         # driver's record carries it too: `vae` = the --stage vae line without its CPU baseline (3 decodes after 1 warm-up)

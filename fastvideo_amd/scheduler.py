@@ -121,7 +121,7 @@ class DenoisingLoopHip:
 
     def __init__(self, transformer, num_inference_steps: int, flow_shift: float = 3.0, guidance_scale: float = 1.0,
                  transformer_2=None, boundary_ratio: float | None = None, guidance_scale_2: float | None = None,
-                 num_train_timesteps: int = 1000, scalar_rounding: str = "fp32"):
+                 num_train_timesteps: int = 1000, scalar_rounding: str = "fp32", cfg_batch: bool = False):
         """``scalar_rounding``: "fp32" (default) keeps the 0-d ``sigma_t`` / Python ``guidance_scale`` operands in fp32 inside the step
         kernel — what the reference's eager elementwise kernels do ON THE GPU with a CPU-scalar operand, i.e. what a user of the
         reference on an accelerator gets; "bf16" reproduces the reference's CPU eager path (the scalar is cast to the tensor dtype
@@ -133,6 +133,9 @@ class DenoisingLoopHip:
         with ``guidance_scale_2`` (denoising.py:251-256, 377-403).  Both experts stay resident (2 x 28 GB of bf16 weights in 288 GB
         of HBM), so the reference's per-boundary CPU offload shuffle has no counterpart here."""
         self.model, self.g = transformer, float(guidance_scale)
+        # cfg_batch: the classifier-free-guidance pair as one batch-2 forward (see ``step``); off = the reference's two forwards per step
+        # (denoising.py:497-560).  Needs equal-length prompt / negative embeddings (the pipelines pad both to 512 text tokens).
+        self.cfg_batch = bool(cfg_batch)
         self.model_2 = transformer_2
         self.g2 = float(guidance_scale if guidance_scale_2 is None else guidance_scale_2)
         self.boundary_timestep = None if boundary_ratio is None else boundary_ratio * num_train_timesteps
@@ -148,6 +151,23 @@ class DenoisingLoopHip:
         return self.model_2, self.g2
 
     @torch.no_grad()
+    def step(self, i: int, x, x16, prompt_embeds, negative_prompt_embeds=None):
+        """Denoising step i of the schedule: DiT forward(s) on the bf16 latent ``x16`` + the fused CFG / UniPC tail on the fp32 latent ``x``.
+        Returns the next (x, x16).  With ``cfg_batch`` the conditional / unconditional pair runs as ONE batch-2 forward (latent repeated,
+        embeddings stacked): every kernel of the model is row- and batch-independent, so each half equals its stand-alone forward bit for bit
+        (tests/test_gpu_sched.py), while the pair shares every launch — half the launches, twice the grid per launch."""
+        model, g = self.expert_for(float(self.stepper.timesteps[i]))
+        use_cfg = negative_prompt_embeds is not None and self.g > 1.0  # batch-level switch (pipeline_batch_info.py:270-272)
+        t = self.stepper.timesteps[i].to(device=x.device, dtype=torch.float32).reshape(1)
+        if use_cfg and self.cfg_batch:
+            pair = model(x16.expand(2, *x16.shape[1:]).contiguous(), torch.cat([prompt_embeds, negative_prompt_embeds], 0), t.repeat(2))
+            cond, uncond = pair[0:1], pair[1:2]
+        else:
+            cond = model(x16, prompt_embeds, t)
+            uncond = model(x16, negative_prompt_embeds, t) if use_cfg else None
+        return self.stepper.step(cond, x, uncond, g)
+
+    @torch.no_grad()
     def run(self, latents, prompt_embeds, negative_prompt_embeds=None, num_steps: int | None = None):
         """latents fp32 [1,C,T,H,W]; embeds bf16 [1,L,text_dim].  Returns the denoised latents (fp32)."""
         self.stepper.reset()
@@ -155,12 +175,7 @@ class DenoisingLoopHip:
         x16 = x.to(BF16)
         n = len(self.stepper.timesteps) if num_steps is None else num_steps
         for i in range(n):
-            model, g = self.expert_for(float(self.stepper.timesteps[i]))
-            use_cfg = negative_prompt_embeds is not None and self.g > 1.0  # batch-level switch (pipeline_batch_info.py:270-272)
-            t = self.stepper.timesteps[i].to(device=x.device, dtype=torch.float32).reshape(1)
-            cond = model(x16, prompt_embeds, t)
-            uncond = model(x16, negative_prompt_embeds, t) if use_cfg else None
-            x, x16 = self.stepper.step(cond, x, uncond, g)
+            x, x16 = self.step(i, x, x16, prompt_embeds, negative_prompt_embeds)
         return x
 
 

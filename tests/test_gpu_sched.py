@@ -109,6 +109,31 @@ def test_denoising_loop_two_steps_vs_oracle(golden_dir):
     err = (y - x).abs()
     print(f"denoising loop: max|err|={err.max().item():.4g} mean|err|={err.mean().item():.4g} ref_absmean={x.abs().mean().item():.4g}")
     assert err.mean().item() < 2e-2 and err.max().item() < 0.5
+    # cfg_batch: the conditional / unconditional pair as ONE batch-2 forward == the two forwards, bit for bit (dense, one GPU: the batch is
+    # a grid dimension of every kernel, rows and batch elements are independent), through two full steps
+    yb = DenoisingLoopHip(model, 4, flow_shift=3.0, guidance_scale=4.0, cfg_batch=True).run(lat.cuda(), c["ctx"].cuda(), neg.cuda(), num_steps=2).cpu()
+    assert torch.equal(yb, y), f"cfg_batch differs from two forwards: max {(yb - y).abs().max().item()}"
+
+
+@pytest.mark.parametrize("attention", ["dense", "vsa", "sta"])
+def test_batch2_forward_equals_two_forwards(golden_dir, attention):
+    """WanTransformer3DModelHip on a batch of two (same latent, two prompts, the CFG pair) == the two single forwards bit for bit, in every
+    attention mode (dense: one attention launch for the batch; sparse modes: per-sample launches)."""
+    _need_gpu()
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    fx = torch.load(os.path.join(golden_dir, "wan_tiny.pt"), weights_only=False)
+    H = fx["config"]["num_heads"]
+    kw = {} if attention == "dense" else dict(attention="vsa", vsa_sparsity=0.5) if attention == "vsa" else dict(attention="sta", sta_window=(1, 3, 1), sta_tile=(2, 4, 8))
+    model = WanTransformer3DModelHip(fx["state_dict"], num_heads=H, **kw)
+    gen = torch.Generator().manual_seed(3)
+    lat = torch.randn((1, 16, 5, 20, 36), generator=gen).bfloat16().cuda()   # 5 x 10 x 18 = 900 tokens: long enough for the 256-row kernels
+    c = fx["cases"][0]
+    neg = torch.randn(c["ctx"].shape, generator=gen).bfloat16().cuda()
+    t = torch.tensor([617.0]).cuda()
+    a, b = model(lat, c["ctx"].cuda(), t), model(lat, neg, t)
+    pair = model(lat.expand(2, -1, -1, -1, -1).contiguous(), torch.cat([c["ctx"].cuda(), neg], 0), t.repeat(2))
+    assert torch.equal(pair[0:1], a) and torch.equal(pair[1:2], b)
+    assert not torch.equal(a, b)
 
 
 def test_two_expert_loop_switches_at_the_boundary(golden_dir):
