@@ -16,27 +16,18 @@
 // ref: WanCausalConv3d.forward (fastvideo/models/vaes/wanvae.py:198-207), WanResample (:277-284, :247-248), WanResidualBlock (:462),
 //      AutoencoderKLWan.decode's clamp (:1210-1211).
 #include "fvk_common.h"
+#include "vae_conv3_args.h"
 #include <type_traits>
 
 int fvk_vae_conv_tunable();  // vae_conv.hip: the "vae_conv_impl" measurement switch
 
 namespace {
 
-struct Conv3Args {
-    const bf16_t* in; const bf16_t* w; const bf16_t* bias; bf16_t* out; const bf16_t* residual; float* out_f32;
-    long out_fs, res_fs, plane_stride;
-    int T, H, W, Hin, Win, Cin, Cout, KT;
-    int ring, ring_start;
-    int tiles_h, tiles_w, ntn;
-    // fused WanRMS_norm (+SiLU) of this conv's output into the CONSUMER conv's input ring: norm_out != NULL.  Cout == 96: one wave holds all
-    // channels of its 64 pixels; Cout == 192 (WNW = 2): the two waves of a pixel row pair hold 96 channels each and exchange their partial
-    // sums of squares through LDS (one extra barrier).  write_raw == 0 drops the un-normed store (conv1 -> norm2 -> conv2 in a residual block).
-    const float* norm_gamma; bf16_t* norm_out;
-    int norm_ring, norm_slot0, norm_silu, write_raw;
-};
-
-enum { EPI_BIAS = 0, EPI_RESIDUAL = 1, EPI_FINAL = 2 };
-constexpr unsigned OOB = 0xFFFFFF00u;  // a buffer offset past every descriptor's range: the load returns zeros
+using fvkc3::Conv3Args;
+using fvkc3::EPI_BIAS;
+using fvkc3::EPI_RESIDUAL;
+using fvkc3::EPI_FINAL;
+using fvkc3::OOB;
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {  // counted wait: at most N of this wave's VMEM operations still in flight
@@ -510,6 +501,12 @@ int fvk_vae_conv3_launch(const void* in, const void* w, const void* bias, void* 
     a.out_fs = out_fs; a.res_fs = res_fs; a.plane_stride = plane_stride;
     a.T = T; a.H = H; a.W = W; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KT = KT; a.ring = ring; a.ring_start = ring_start;
     if (epilogue == EPI_FINAL && !ups && Cout <= 32) return launch3<1, EPI_FINAL, false, 1>(a, s);  // conv_out: one 32-channel block per wave
+    // non-upsampling bf16-output convs: the one-wave-per-SIMD kernel on 16x16x32 MFMAs (vae_conv3w.hip, round 4); "vae_conv_impl" 3 (measurement
+    // build) keeps this file's 8-wave kernel for A/B and the <= 1-ulp comparison tests
+    if (!ups && (!FVK_VARIANTS || fvk_vae_conv_tunable() != 3)) {
+        int rc = FVK_OK;
+        if (fvk_vae_conv3w_launch(a, epilogue, s, &rc)) return rc;
+    }
     const int w96 = (Cout + 95) / 96 * 96, w192 = (Cout + 191) / 192 * 192;
     if (w192 <= w96) return launch3_e<2>(a, epilogue, ups != 0, s);
     return launch3_e<1>(a, epilogue, ups != 0, s);

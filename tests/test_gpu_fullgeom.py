@@ -128,5 +128,30 @@ def test_thirty_layers_at_1_3b_geometry_match_oracle():
     frac_out = (err > lim).float().mean().item()
     print(f"30 layers, model output: max|err|={err.max().item():.4g} mean|err|={err.mean().item():.4g} ref_absmean={ref.abs().mean().item():.4g} "
           f"outside the DiT bound: {frac_out:.3g}")
-    assert frac_out <= 1e-4 and not (err > 3 * lim).any()
+    # the reference's own DiT bound, un-softened (fastvideo/tests/transformers/test_wanvideo.py:109 allows NO element outside atol 1e-1 /
+    # rtol 1e-2); rounds 1-3 allowed 1e-4 of the elements up to 3x the limit here — never needed: measured max 6.3e-2
+    assert frac_out == 0.0, f"{int((err > lim).sum())} elements outside the reference's DiT bound"
     assert err.mean().item() < 2e-2
+
+
+def test_full_contract_vs_reference_fixture(golden_dir):
+    """THE contract workload end to end: Wan2.1-T2V-1.3B, 30 layers, latent [1,16,21,60,104] = 32 760 tokens, 512 text tokens — the HIP
+    forward against the REAL reference's CPU forward (bf16 weights under bf16 autocast, SDPA backend) of the same seeded weights and
+    inputs, stored in tests/golden/contract_full_ref.pt by ``scripts/full_contract_parity.py reference`` (run in the build container, log in
+    profiles/r04_full_contract_reference.log).  Every one of the 2 096 640 output elements must be inside the reference's DiT bound (atol 1e-1,
+    rtol 1e-2), for the default long-key attention kernel AND the other two selectable ones (attn_autotune may keep either of the first
+    two: whichever it keeps has passed this)."""
+    import importlib.util
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    fix = os.path.join(golden_dir, "contract_full_ref.pt")
+    spec = importlib.util.spec_from_file_location("full_contract_parity", os.path.join(os.path.dirname(golden_dir), "..", "scripts", "full_contract_parity.py"))
+    fcp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fcp)
+    out_json = os.path.join(os.path.dirname(golden_dir), "..", "gpurun_out", "full_contract_parity.json")
+    res = fcp.leg_hip(fix, out_json)
+    for name, r in res["kernels"].items():
+        print(name, r)
+        assert r["elements"] == 16 * 21 * 60 * 104
+        assert r["outside_dit_bound_atol1e-1_rtol1e-2"] == 0, f"{name}: {r}"
+        assert r["mean_err"] < 2e-2 and r["worst_ratio_to_bound"] < 1.0, f"{name}: {r}"
