@@ -14,6 +14,7 @@ ap.add_argument("--frames", type=int, default=21)
 ap.add_argument("--h", type=int, default=60)
 ap.add_argument("--w", type=int, default=104)
 ap.add_argument("--frames-per-pass", type=int, default=4)
+ap.add_argument("--impl", type=int, default=0, help="vae_conv_impl tunable (measurement build, FVK_PROBE_LIB=1): 3 = the 8-wave vae_conv3.hip kernels everywhere")
 args = ap.parse_args()
 
 from fastvideo_amd import ops
@@ -27,6 +28,8 @@ for n, s in wan_vae_param_spec(base_dim=96):
     for d in s[1:]:
         fan_in *= d
     sd[n] = torch.ones(s) if "gamma" in n else (((torch.rand(s, generator=g) * 2 - 1) * (3.0 / fan_in)**0.5) if len(s) >= 4 else torch.zeros(s))
+if args.impl:
+    ops.set_tunable("vae_conv_impl", args.impl)
 dec = WanVaeDecoderHip(sd, frames_per_pass=args.frames_per_pass)
 z = torch.randn((1, 16, args.frames, args.h, args.w), generator=g).cuda()
 dec.decode(z)
