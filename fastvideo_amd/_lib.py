@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # the non-shipping kernel variants behind fvk_set_tunable (scripts/probes/libfvk_probe.so, built by _build.build_probe()).
 PROBE = os.environ.get("FVK_PROBE_LIB") == "1"
 LIB_PATH = (os.path.join(os.path.dirname(HERE), "scripts", "probes", "libfvk_probe.so") if PROBE else os.path.join(HERE, "libfvk_amd.so"))
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -40,6 +40,7 @@ SIGNATURES = {
     "fvk_rmsnorm_rope_scatter_bf16": [C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, i32, i32, i32, i32, i32, i64, i64, f32,
                                       C.POINTER(vp), vp],
     "fvk_qkv_norm_rope_pack_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, i32, f32, vp],
+    "fvk_qkv_norm_rope_pack2_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i64, i32, i32, f32, vp],
     "fvk_qkvg_norm_rope_pack_bf16": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i32, i32, f32, vp],
     "fvk_v_transpose_bf16": [vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp],
     "fvk_v_transpose_gather_bf16": [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp],

@@ -193,7 +193,11 @@ static int gemm_impl(const void* x, const void* w, const void* bias, void* out, 
     const int impl = fvk::tunable(fvk::TUNE_GEMM_IMPL);  // constant 0 in the product library
     if (impl != 1 && fvk::gemm_pp_eligible(a)) {
         // gemm_w1.hip (four 128 x 128 waves, 16x16x32 MFMAs) where K is a whole number of 128-element double steps; gemm_impl 4 forces gemm_ph
-        if ((impl == 0 || (impl & 7) == 5) && fvk::gemm_w1_eligible(a)) return fvk::gemm_w1_launch(a, epilogue, batch, s);
+        // few-tile problems (a rank's N = 1536 projections at SP = 8): the 256 x 128 tile form of the same kernel, byte-identical results
+        if ((impl == 0 && fvk::gemm_w1n_eligible(a, epilogue)) ||
+            (impl == 6 && fvk::gemm_w1_eligible(a) && !(epilogue == FVK_EPI_RESIDUAL_GATE && gate && a.rows_per_batch < 128)))
+            return fvk::gemm_w1n_launch(a, epilogue, batch, s);
+        if ((impl == 0 || impl == 14 || (impl & 7) == 5) && fvk::gemm_w1_eligible(a)) return fvk::gemm_w1_launch(a, epilogue, batch, s);
         if ((impl == 0 || (impl & 7) == 4) && fvk::gemm_ph_eligible(a)) return fvk::gemm_ph_launch(a, epilogue, batch, s);
         return fvk::gemm_pp_launch(a, epilogue, batch, s);
     }

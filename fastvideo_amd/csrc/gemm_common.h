@@ -37,6 +37,10 @@ int gemm_ph_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
 // gemm_w1.hip (gemm_ph's tile and unit FIFO with four 128 x 128 waves, one per SIMD; gemm_impl 5)
 bool gemm_w1_eligible(const GemmArgs& a);
 int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
+// gemm_w1n.hip (round 4): the same arithmetic (byte-identical results) on a 256 x 128 workgroup tile, for problems whose 256 x 256 grid would
+// leave half the chip idle (per-rank shapes under sequence parallelism); gemm_impl 6 forces it, 14 forbids it
+bool gemm_w1n_eligible(const GemmArgs& a, int epilogue);
+int gemm_w1n_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
 bool gemm_w1_fp8_eligible(const GemmArgs& a);
 int gemm_w1_fp8_launch(GemmArgs a, int epilogue, hipStream_t s);  // fvk_gemm_fp8 on the same kernel (16x16x128 MX-fp8 MFMAs)
 

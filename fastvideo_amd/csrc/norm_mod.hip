@@ -172,6 +172,10 @@ struct RmsArgs {
     // tensor t is written to every destination rank rp = g + pack_G*u', u' < pack_U, at pack_dst[((rp*M + m)*pack_ns + pack_slot[t])*pack_W + cc]
     bf16_t* pack_dst;
     int pack_G, pack_U, pack_W, pack_ns;  // pack_ns = slots per message row: 3 = [K | V | Q], 4 = [K | V | Q | gate]
+    // two head chunks per group (fvk_qkv_norm_rope_pack2_bf16, the pipelined exchange): the first pack_Wa columns of every group go to pack_dst
+    // (message rows pack_Wa wide), the remaining pack_W - pack_Wa to pack_dst2; pack_Wa == pack_W: one buffer
+    bf16_t* pack_dst2;
+    int pack_Wa;
     int pack_slot[4];
     // scatter (fvk_rmsnorm_rope_scatter_bf16): row m of tensor t is written to row row_map[t][m] of out[t] (negative: dropped); NULL = row m.
     // Folds the tile-major / window-class gathers of the sparse attention paths into this pass.
@@ -242,9 +246,12 @@ __global__ __launch_bounds__(256) void rmsnorm_rope_kernel(RmsArgs a) {
             }
             if (a.pack_dst) {
                 const int col = c * 8, g = col / a.pack_W, cc = col - g * a.pack_W;
+                const bool second = cc >= a.pack_Wa;
+                bf16_t* dst = second ? a.pack_dst2 : a.pack_dst;
+                const int wc = second ? a.pack_W - a.pack_Wa : a.pack_Wa, c2 = second ? cc - a.pack_Wa : cc;
                 for (int uu = 0; uu < a.pack_U; ++uu) {
                     const long rp = g + (long)a.pack_G * uu;
-                    st_bf16x8(a.pack_dst + ((rp * a.M + row) * a.pack_ns + a.pack_slot[t]) * a.pack_W + cc, o);
+                    st_bf16x8(dst + ((rp * a.M + row) * a.pack_ns + a.pack_slot[t]) * wc + c2, o);
                 }
             } else {
                 st_bf16x8(out + c * 8, o);
@@ -435,7 +442,7 @@ static int rmsnorm_rope_impl(const void* const* in, void* const* out, const void
 
 static int qkv_pack_impl(const void* q, const void* k, const void* v, const void* gate, const void* wq, const void* wk, const float* cos,
                          const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset, long in_stride, int G, int U,
-                         float eps, void* stream);
+                         float eps, void* stream, void* send2 = nullptr, int heads_a = 0);
 
 extern "C" int fvk_qkv_norm_rope_pack_bf16(const void* q, const void* k, const void* v, const void* wq, const void* wk, const float* cos,
                                            const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset,
@@ -450,9 +457,19 @@ extern "C" int fvk_qkvg_norm_rope_pack_bf16(const void* q, const void* k, const 
     return qkv_pack_impl(q, k, v, gate, wq, wk, cos, sin, send, Sl, width, head_dim, seq_len, pos_offset, in_stride, G, U, eps, stream);
 }
 
+extern "C" int fvk_qkv_norm_rope_pack2_bf16(const void* q, const void* k, const void* v, const void* wq, const void* wk, const float* cos,
+                                            const float* sin, void* send_a, void* send_b, int heads_a, int Sl, int width, int head_dim, int seq_len,
+                                            int pos_offset, long in_stride, int G, int U, float eps, void* stream) {
+    FVK_CHECK(send_b && G >= 1 && head_dim > 0 && width % (G * head_dim) == 0 && heads_a >= 1 && heads_a < width / head_dim / G, FVK_ERR_ARG,
+              "fvk_qkv_norm_rope_pack2_bf16: heads_a=%d must leave both chunks of a %d-head group non-empty (and send_b set)", heads_a,
+              (G >= 1 && head_dim > 0) ? width / head_dim / G : 0);
+    return qkv_pack_impl(q, k, v, nullptr, wq, wk, cos, sin, send_a, Sl, width, head_dim, seq_len, pos_offset, in_stride, G, U, eps, stream, send_b,
+                         heads_a);
+}
+
 static int qkv_pack_impl(const void* q, const void* k, const void* v, const void* gate, const void* wq, const void* wk, const float* cos,
                          const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset, long in_stride, int G, int U,
-                         float eps, void* stream) {
+                         float eps, void* stream, void* send2, int heads_a) {
     FVK_CHECK(q && k && v && send, FVK_ERR_ARG, "fvk_qkv_norm_rope_pack_bf16: null pointer");
     FVK_CHECK(width > 0 && head_dim > 0 && head_dim % 8 == 0 && width % head_dim == 0, FVK_ERR_ARG,
               "fvk_qkv_norm_rope_pack_bf16: width=%d head_dim=%d", width, head_dim);
@@ -470,6 +487,7 @@ static int qkv_pack_impl(const void* q, const void* k, const void* v, const void
     a.in_stride = in_stride; a.out_stride = 0; a.eps = eps;
     a.rope_mask = 3;  // q and k are rotated, v (and the gate) are copied
     a.pack_dst = (bf16_t*)send; a.pack_G = G; a.pack_U = U; a.pack_W = width / G; a.pack_ns = ns;
+    a.pack_dst2 = (bf16_t*)send2; a.pack_Wa = send2 ? heads_a * head_dim : a.pack_W;
     a.pack_slot[0] = 2; a.pack_slot[1] = 0; a.pack_slot[2] = 1; a.pack_slot[3] = 3;  // message row = [K | V | Q (| gate)] of one token
     int rc = dispatch_vpl(width, [&](auto vpl) {
         hipLaunchKernelGGL((rmsnorm_rope_kernel<decltype(vpl)::value>), dim3((Sl + 3) / 4, ns), dim3(256), 0, (hipStream_t)stream, a);

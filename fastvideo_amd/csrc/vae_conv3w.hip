@@ -73,6 +73,14 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
     const int t_out = bid / a.tiles_h;
     const int h0 = th_i * TH, w0 = tw_i * TW, n0 = pid_n * TN;
 
+#if FVK_VARIANTS  // measurement build: with EPI_BIAS and a non-null out_f32, every workgroup's wave 0 stamps s_memtime at kernel entry, loop
+    // start, loop end and kernel end into out_f32 (as uint64 [workgroups][4]) — where a tile's time goes (scripts/conv3w_probe.py)
+    unsigned long long stamp_[4] = {0, 0, 0, 0};
+#define C3W_STAMP(K) if (EPI == EPI_BIAS && a.out_f32) stamp_[K] = __builtin_readcyclecounter();
+#else
+#define C3W_STAMP(K)
+#endif
+    C3W_STAMP(0)
     // ---- staging: piece q = wave + 4 i; lane -> LDS row 16 q + (lane >> 2), chunk POSITION lane & 3 = source chunk (lane & 3) ^ 2 ((row >> 2) & 1) ----
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.in, 0, (unsigned)((long)a.ring * a.Hin * a.Win * a.Cin * 2), 0x00020000);
@@ -210,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
     C3W_ADVANCE_W()                                                                                                 \
     C3W_GROUP(2, 1, XNEXT_, ((DH) + 1) % 3, ((DH) + 1) % 3, 1, C3W_NO_DMA)
 
+    C3W_STAMP(1)
     for (int s = 0; s < nslab; ++s) {
         // the per-slot weight bases are loop invariants: left visible, LICM hoists all 54 (slot, dw, tile) fragment addresses into registers of
         // their own (parked in AGPRs, one v_accvgpr_read per read) instead of one base + the instruction's 16-bit immediate
@@ -231,6 +240,7 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
 #undef C3W_ADVANCE_W
     // the trailing (never consumed) fragment reads and dummy pieces have retired before LDS is reused / the workgroup ends
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    C3W_STAMP(2)
     // the accumulators were written by asm MFMAs: the compiler knows no hazard distance to its own reads of them
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
@@ -287,6 +297,14 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
         sq += __shfl_xor(sq, 32, 64);
         ss[pb] = sq;
     }
+#if FVK_VARIANTS
+    if (EPI == EPI_BIAS && a.out_f32) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have been accepted
+        C3W_STAMP(3)
+        if (wave == 0 && lane == 0)
+            for (int i = 0; i < 4; ++i) reinterpret_cast<unsigned long long*>(a.out_f32)[(long)blockIdx.x * 4 + i] = stamp_[i];
+    }
+#endif
     if (!fused) return;
     // ---- fused RMS-norm (+SiLU) into the consumer conv's input ring: ref WanRMS_norm (wanvae.py:231-232) + SiLU (:418-419) on the bf16-rounded
     //      conv output: inv = sqrt(C) / max(||x||_2, 1e-12); out = bf16(silu(x * inv * gamma))

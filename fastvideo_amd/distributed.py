@@ -87,14 +87,18 @@ class SequenceParallel:
         # gloo cannot move device memory: stage through the host (used by the 2-process single-GPU parity test;
         # production runs use backend "nccl" = RCCL, which takes device pointers directly)
         self._stage_host = P > 1 and dist.get_backend(group) == "gloo"
-        # Pipelined exchange: the head group of a rank is split in two chunks whose exchanges are issued asynchronously, so chunk B's
-        # all-to-all and chunk A's output exchange ride under the other chunk's attention kernel.  OPT-IN (FVK_SP_OVERLAP=1): two attention
-        # launches per layer on ONE stream also split the attention grid (192 workgroups at SP = 8 become 128 + 64 on 256 CUs, each a full
-        # pass over the keys), which costs more than the exchange it hides until the two launches run on separate streams — to be measured on
-        # an 8-GPU node.  The FIRST pipelined call is checked against the plain exchange (bit-identical by construction: heads are
-        # independent); any rank seeing a difference switches every rank back to the plain exchange.
+        # Pipelined exchange (attention_packed_pipelined): a rank's head group is split in two chunks; both input exchanges are issued
+        # asynchronously up front, chunk A's attention runs on the caller's stream and chunk B's on a SECOND HIP stream (each chunk is a full
+        # pass over the keys on its own part of the grid — 128 + 64 workgroups at SP = 8 co-run on the 256 CUs instead of queueing behind
+        # one another), and chunk A's output exchange rides under chunk B's attention.  What it can save inside ONE batch-1 forward is bounded:
+        # every op of a DiT layer depends on the previous one, so the critical path is still exchange #1 (all of it) -> attention ->
+        # exchange #2 of the LAST chunk; only the first chunk's share of exchange #2 (~1/6 of a layer's exchange time) is hidden.  Hence OPT-IN
+        # (FVK_SP_OVERLAP=1) until an 8-GPU node has measured it; the default is the plain single-collective exchange.  Heads are
+        # independent in attention, so the result is the plain exchange's bit for bit — checked on the first call (all-reduced verdict);
+        # any rank seeing a difference switches every rank back to the plain exchange.
         self.overlap = P > 1 and os.environ.get("FVK_SP_OVERLAP") == "1"
         self._overlap_checked = False
+        self._side_stream = None
         # bench.py's exchange accounting: set ``stats`` to a dict to collect, per exchange kind, the bytes this rank sends to OTHER
         # ranks and HIP-event pairs around the collective on the caller's stream (None = nothing recorded, nothing extra on the stream)
         self.stats = None
@@ -358,6 +362,70 @@ class SequenceParallel:
         Sl = send.shape[1]
         q_blk, k_all, v_all = self.views_of(self.exchange_rows(send), head_dim)
         return self.scatter_seq_gather_heads(attn_fn(q_blk, k_all, v_all, S), Sl)
+
+    def exchange_rows_async(self, send: torch.Tensor):
+        """exchange_rows issued asynchronously: returns a thunk that completes it on the stream current at call time."""
+        P, Sl, NS, W = send.shape
+        done = self._a2a_async(send.reshape(P * Sl, NS * W), None, None, P * Sl)
+        return lambda: done().view(P * Sl, NS, W)
+
+    def attention_packed_pipelined(self, sends, S: int, attn_fn, head_dim: int = 128):
+        """The pipelined form of ``attention_packed``: ``sends`` = the two head-chunk send buffers of ``ops.qkv_norm_rope_pack(heads_a=...)``
+        ([P, Sl, 3, Wa], [P, Sl, 3, Wb]).  Both exchanges are issued up front; chunk A runs on the caller's stream, chunk B on a second HIP
+        stream; each chunk's output exchange is issued as soon as its attention is; the caller's stream then waits for both and assembles
+        [Sl, H, D] (heads in the un-chunked order).  CPU / gloo: the same order of operations without streams (tests)."""
+        import contextlib
+        L = self.lay
+        Sl = sends[0].shape[1]
+        on_dev = sends[0].is_cuda
+        main = torch.cuda.current_stream() if on_dev else None
+        if on_dev and self._side_stream is None:
+            self._side_stream = torch.cuda.Stream()
+        streams = [main, self._side_stream] if on_dev else [None, None]
+        if on_dev:
+            self._side_stream.wait_stream(main)   # the side stream starts behind everything issued so far (the pack kernel, the allocator's reuse)
+        pend = [self.exchange_rows_async(s_) for s_ in sends]
+        outs = []
+        o_in, o_out = self._o_splits(Sl)
+        for st, send, done in zip(streams, sends, pend):
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                t0 = self._tick()
+                recv = done()
+                self._tock(t0, "exchange1", send.numel() * send.element_size() * (L.P - 1) // L.P)
+                if st is not None and st is not main:
+                    recv.record_stream(st)
+                q_blk, k_all, v_all = self.views_of(recv, head_dim)
+                o_blk = attn_fn(q_blk, k_all, v_all, S).contiguous()
+                outs.append((o_blk.shape[1], self._a2a_async(o_blk, o_in, o_out, L.G * Sl), o_blk, recv, st))
+        hg = sum(o[0] for o in outs)
+        out = sends[0].new_empty((Sl, L.G, hg, head_dim))
+        a = 0
+        for hc, done, o_blk, _recv, st in outs:
+            t0 = self._tick()
+            res = done()
+            self._tock(t0, "exchange2", (L.G - 1) * Sl * hc * head_dim * o_blk.element_size())
+            if st is not None and st is not main:
+                res.record_stream(main)
+                o_blk.record_stream(main)
+            out[:, :, a:a + hc] = res.reshape(L.G, Sl, hc, head_dim).permute(1, 0, 2, 3)
+            a += hc
+        if on_dev:
+            main.wait_stream(self._side_stream)
+        return out.reshape(Sl, L.G * hg, head_dim)
+
+    def pipelined_agrees(self, o: torch.Tensor, ref: torch.Tensor) -> bool:
+        """First-call verdict of the pipelined exchange, identical on every rank: True iff EVERY rank's pipelined result equals its plain one bit
+        for bit; on False the pipelined mode is switched off (with a warning) and callers use ``ref``."""
+        self._overlap_checked = True
+        ok = torch.tensor([1 if torch.equal(o, ref) else 0], dtype=torch.int32, device="cpu" if self._stage_host else o.device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
+        if int(ok.item()) != 1:
+            import warnings
+            warnings.warn("fastvideo_amd: the pipelined sequence-parallel exchange disagreed with the plain exchange on its first call; "
+                          "falling back to the plain exchange (set FVK_SP_OVERLAP=0 to silence)")
+            self.overlap = False
+            return False
+        return True
 
     def attention(self, q, k, v, S: int, attn_fn, extra=None):
         """Distributed self-attention for one batch element.

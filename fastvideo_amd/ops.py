@@ -176,12 +176,14 @@ def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_le
     return outs
 
 
-def qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, G, U, head_dim=128, seq_len=None, eps=1e-6, pos_offset=0, out=None, gate=None):
+def qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, G, U, head_dim=128, seq_len=None, eps=1e-6, pos_offset=0, out=None, gate=None, heads_a=None):
     """Exchange #1 of the 2-D Ulysses sequence parallelism, packed by the norm / RoPE pass itself (fvk_qkv_norm_rope_pack_bf16).
     q, k, v: bf16 [Sl, width] views with unit column stride and one common row stride (column blocks of the fused QKV buffer).
     Returns the send buffer [G*U, Sl, 3, width // G]: per destination rank, per token, [K | V | Q] of that rank's head group.
     gate (the VSA compress gate, a fourth column block of the same buffer): [G*U, Sl, 4, width // G] = [K | V | Q | gate]
-    (fvk_qkvg_norm_rope_pack_bf16)."""
+    (fvk_qkvg_norm_rope_pack_bf16).
+    heads_a (dense path only): TWO send buffers — the first ``heads_a`` heads of every head group in [G*U, Sl, 3, heads_a*head_dim], the rest in
+    [G*U, Sl, 3, (heads/G - heads_a)*head_dim] (fvk_qkv_norm_rope_pack2_bf16: the pipelined exchange's head chunks); returns the pair."""
     Sl, width = q.shape
     stride = q.stride(0)
     ns = 3 if gate is None else 4
@@ -190,6 +192,17 @@ def qkv_norm_rope_pack(q, k, v, wq, wk, cos, sin, G, U, head_dim=128, seq_len=No
         if t.shape != (Sl, width) or t.stride(1) != 1 or t.stride(0) != stride:
             raise RuntimeError("qkv_norm_rope_pack: q, k, v must be [Sl,width] views with unit column stride and a common row stride")
     W = width // G
+    if heads_a is not None:
+        hg = W // head_dim
+        if gate is not None or out is not None or not (0 < heads_a < hg):
+            raise RuntimeError(f"qkv_norm_rope_pack: heads_a={heads_a} needs 0 < heads_a < {hg} heads per group, no gate and no `out`")
+        wq_ = None if wq is None else _chk(wq, BF16, "wq").contiguous()
+        wk_ = None if wk is None else _chk(wk, BF16, "wk").contiguous()
+        sa = torch.empty((G * U, Sl, 3, heads_a * head_dim), dtype=BF16, device=q.device)
+        sb = torch.empty((G * U, Sl, 3, (hg - heads_a) * head_dim), dtype=BF16, device=q.device)
+        _lib.call("fvk_qkv_norm_rope_pack2_bf16", _p(q), _p(k), _p(v), _p(wq_), _p(wk_), _p(_f32(cos, "cos")), _p(_f32(sin, "sin")), _p(sa), _p(sb),
+                  int(heads_a), Sl, width, head_dim, seq_len or Sl, int(pos_offset), stride, int(G), int(U), float(eps), _stream())
+        return sa, sb
     if out is None:
         out = torch.empty((G * U, Sl, ns, W), dtype=BF16, device=q.device)
     elif tuple(out.shape) != (G * U, Sl, ns, W) or out.dtype != BF16 or not out.is_contiguous():

@@ -231,7 +231,10 @@ class WanTransformer3DModelHip:
         True)) the pair shares every launch — per sample the arithmetic is the same (rows and batch elements are independent in every kernel)."""
         vt = ops.v_transpose(v4)
         kern, tune = self.attn_kernel, self._tune
-        splits = ops.attn_key_splits_for(q4, k4)
+        # key runs are decided for the rank's WHOLE head group (the pipelined exchange launches it as two head chunks on two streams: they
+        # fill the chip together, and must run the arithmetic of the un-chunked launch)
+        heads = max(q4.shape[2], self.sp.lay.heads_per_group if self.sp.lay.P > 1 else q4.shape[2])
+        splits = ops.attn_key_splits(-(-q4.shape[1] // 256) * heads * q4.shape[0], -(-k4.shape[1] // 128)) if q4.shape[1] >= 256 else 1
         long_keys = q4.shape[1] >= 256 and k4.shape[1] >= 2048
         if splits > 1 or not long_keys:
             # short key axes take the 8-wave kernel and split-KV grids always run attn_w16 (fvk_attn_dense_split_bf16): nothing to choose
@@ -242,11 +245,11 @@ class WanTransformer3DModelHip:
         self.dense_kernel_ran = (f"attn_w16 split-KV x{splits}" if splits > 1 else "attn_pp2" if not long_keys else
                                  "attn_w64" if kern == ops.ATTN_KERNEL_W64 else "attn_w16")
         if self.attn_events is None and tune is None:
-            return ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd", kernel=kern)
+            return ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd", kernel=kern, key_splits=splits)
         # bench.py roofline leg / the in-place kernel choice: HIP events on the launch stream around the dominant kernel only
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        o = ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd", kernel=kern)
+        o = ops.attn_dense(q4, k4, vt=vt, scale=self.D**-0.5, layout="bshd", kernel=kern, key_splits=splits)
         e1.record()
         if self.attn_events is not None:
             self.attn_events.append((e0, e1, q4.shape[1], k4.shape[1], q4.shape[2] * q4.shape[0]))
@@ -568,12 +571,22 @@ class WanTransformer3DModelHip:
                 fn = lambda q_, k_, v_, kv_len, g_=None: self._attn_local(q_, k_, v_, kv_len, grid, g_)
                 if P > 1 and self.attention in ("vsa", "sta"):
                     o = self._sp_sparse(rows, b, cos, sin, S, grid, pos0)
-                elif P > 1 and gate is None and not sp.overlap:
+                elif P > 1 and gate is None:
                     # sequence parallel: QK-norm + RoPE + the per-peer packing of exchange #1 in ONE kernel (no torch.cat, no unpack —
                     # attention reads K, V and its query rows out of the received buffer through strides)
-                    send = ops.qkv_norm_rope_pack(rows[:, :d], rows[:, d:2 * d], rows[:, 2 * d:3 * d], b["nq_w"], b["nk_w"], cos, sin,
-                                                  sp.lay.G, sp.lay.U, head_dim=D, seq_len=S, eps=self.eps, pos_offset=pos0)
-                    o = sp.attention_packed(send, S, fn, head_dim=D).reshape(Sl, d)
+                    pack = lambda **kw: ops.qkv_norm_rope_pack(rows[:, :d], rows[:, d:2 * d], rows[:, 2 * d:3 * d], b["nq_w"], b["nk_w"], cos, sin,
+                                                               sp.lay.G, sp.lay.U, head_dim=D, seq_len=S, eps=self.eps, pos_offset=pos0, **kw)
+                    hg = sp.lay.heads_per_group
+                    if sp.overlap and hg >= 2:
+                        # FVK_SP_OVERLAP=1: two head chunks (the larger first), their exchanges asynchronous, their attention launches on two
+                        # HIP streams (distributed.py: attention_packed_pipelined); the first call is checked against the plain exchange
+                        o = sp.attention_packed_pipelined(pack(heads_a=(hg + 1) // 2), S, fn, head_dim=D).reshape(Sl, d)
+                        if not sp._overlap_checked:
+                            ref = sp.attention_packed(pack(), S, fn, head_dim=D).reshape(Sl, d)
+                            if not sp.pipelined_agrees(o, ref):
+                                o = ref
+                    else:
+                        o = sp.attention_packed(pack(), S, fn, head_dim=D).reshape(Sl, d)
                 elif P == 1 and self.attention == "sta" and self.sta_lists == "grouped" and self.sta_fold:
                     o = self._sta_fused(rows, b, cos, sin, S, grid).reshape(Sl, d)
                 elif P == 1 and self.attention == "vsa" and self.vsa_fold:

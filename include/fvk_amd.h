@@ -27,7 +27,7 @@ extern "C" {
 #define FVK_ERR_LAUNCH (-2)  /* hipLaunch / hip runtime error                  */
 
 const char* fvk_last_error(void);
-int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3) */
+int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3, 6 = round 4) */
 int fvk_device_arch(char* buf, int len);   /* gcnArchName of the current device ("gfx950...") */
 int fvk_is_probe_build(void);              /* 0: the product library; 1: the measurement build (scripts/probes/libfvk_probe.so) */
 /* Integer knobs for within-process A/B measurements (scripts/microbench.py); 0 = shipped configuration.
@@ -107,6 +107,13 @@ int fvk_rmsnorm_rope_scatter_bf16(const void* const* in, void* const* out, const
 int fvk_qkv_norm_rope_pack_bf16(const void* q, const void* k, const void* v, const void* wq, const void* wk, const float* cos,
                                 const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset,
                                 long in_stride, int G, int U, float eps, void* stream);
+/* The same pass writing TWO send buffers — the first `heads_a` heads of every head group into send_a [G*U, Sl, 3, heads_a*head_dim], the rest into
+ * send_b [G*U, Sl, 3, (heads/G - heads_a)*head_dim] — for the pipelined exchange (two head chunks whose all-to-alls and attention launches overlap
+ * on two HIP streams, fastvideo_amd/distributed.py: attention_packed_pipelined).  Heads are independent in attention, so the chunks' outputs are
+ * the un-chunked output's columns bit for bit. */
+int fvk_qkv_norm_rope_pack2_bf16(const void* q, const void* k, const void* v, const void* wq, const void* wk, const float* cos,
+                                 const float* sin, void* send_a, void* send_b, int heads_a, int Sl, int width, int head_dim, int seq_len,
+                                 int pos_offset, long in_stride, int G, int U, float eps, void* stream);
 /* The same pass with a FOURTH per-token, per-head tensor copied along (the VSA compress gate `to_gate_compress(x)`, which the reference
  * sends through the same all-to-all as q, k, v: fastvideo/attention/layer.py:172-245): message row = [K | V | Q | gate], send is
  * [G*U ranks, Sl, 4, W].  The gate travels with Q — to every rank of its head group's column — so video-sparse attention runs on any

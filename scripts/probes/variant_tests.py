@@ -321,3 +321,21 @@ def test_vae_conv3w_vs_8wave_kernel(ops, tunables, Cin, Cout, T, H, W, kt, resid
         ulp = old.abs().clamp_min(2.0**-20) * 2.0**-7
         assert (diff <= ulp).all(), f"max diff {diff.max().item():.4g} beyond one bf16 ulp (ref {old.flatten()[diff.argmax()].item():.4g})"
         assert (diff > 0).float().mean().item() < 0.15, f"{(diff > 0).float().mean().item():.3f} of the elements differ: not a summation-order effect"
+
+
+# ------------------------------------------------------------------ gemm_w1n (256 x 128 tiles) vs gemm_w1 (256 x 256 tiles)
+@pytest.mark.parametrize("M,N,K", [(4095, 1536, 1536), (4095, 1536, 8960), (300, 200, 128), (1000, 1160, 256), (8190, 4608, 1536)])
+def test_gemm_w1n_is_byte_identical_to_gemm_w1(ops, tunables, M, N, K):
+    """gemm_impl 6 forces the 256 x 128 tile kernel, 14 forbids it: same MFMA steps in the same order + the same epilogue code -> identical bytes,
+    for every epilogue, ragged M / N edges included."""
+    x, w, b = rnd((M, K), 1).to(DEV), rnd((N, K), 2, K**-0.5).to(DEV), rnd((N,), 3).to(DEV)
+    res, gate = rnd((M, N), 4, 2.0).to(DEV), rnd((2, N), 5, 0.5, torch.float32).to(DEV)
+    outs = {}
+    for impl in (6, 14):
+        tunables("gemm_impl", impl)
+        outs[impl] = [ops.gemm(x, w, b, epilogue=e, residual=res if e == ops.EPI_RESIDUAL_GATE else None, gate=gate if e == ops.EPI_RESIDUAL_GATE else None,
+                               rows_per_batch=(M + 1) // 2 if e == ops.EPI_RESIDUAL_GATE else None).cpu()
+                      for e in (ops.EPI_NONE, ops.EPI_SILU, ops.EPI_RESIDUAL_GATE, ops.EPI_GELU_TANH)]
+    for i, (a_, b_) in enumerate(zip(outs[6], outs[14])):
+        assert torch.equal(a_, b_), f"epilogue #{i}: max diff {(a_.float() - b_.float()).abs().max().item():.4g}"
+    close(outs[6][0], _lin_ref(x.cpu(), w.cpu(), b.cpu()), atol=3e-2, rtol=2e-2, what="gemm_w1n vs fp32")

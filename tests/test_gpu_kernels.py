@@ -192,6 +192,28 @@ def test_gemm_epilogues(ops):
     close(ops.gemm_batched(xb.to(DEV), wb.to(DEV), ops.EPI_DIV, 128**0.5), refb, what="batched div")
 
 
+@pytest.mark.parametrize("P", [8, 4])
+def test_gemm_rank_shapes_equal_the_rows_of_the_full_problem(ops, P):
+    """A rank's projections under sequence parallelism (M = 32 760 / P rows) must produce the bytes the SAME rows get inside the SP = 1
+    problem — whichever GEMM kernel the shape selects.  At P = 8 the N = 1536 projections are 96 tiles of 256 x 256 and run on gemm_w1n.hip
+    (256 x 128 tiles, round 4); the full problem runs on gemm_w1.hip; both accumulate the same 32-k MFMA steps in the same order.  Plain,
+    GELU and gated-residual epilogues, K = 1536 and the FFN-out depth 8960, and a ragged last tile (4095 = 15 x 256 + 255 rows)."""
+    S, d, f = 32760, 1536, 8960
+    Sl = S // P
+    r = P - 1                                    # the last rank: its shard ends at the ragged end of the sequence
+    for K, N, epi in ((d, d, ops.EPI_NONE), (d, d, ops.EPI_RESIDUAL_GATE), (f, d, ops.EPI_RESIDUAL_GATE), (d, 2 * d, ops.EPI_GELU_TANH)):
+        x, w, b = rnd((S, K), 1).to(DEV), rnd((N, K), 2, K**-0.5).to(DEV), rnd((N,), 3).to(DEV)
+        kw_full, kw_rank = {}, {}
+        if epi == ops.EPI_RESIDUAL_GATE:
+            res, gate = rnd((S, N), 4, 2.0).to(DEV), rnd((1, N), 5, 0.5, torch.float32).to(DEV)
+            kw_full = dict(residual=res, gate=gate, rows_per_batch=S)
+            kw_rank = dict(residual=res[r * Sl:(r + 1) * Sl], gate=gate, rows_per_batch=Sl)
+        full = ops.gemm(x, w, b, epilogue=epi, **kw_full)
+        rank = ops.gemm(x[r * Sl:(r + 1) * Sl], w, b, epilogue=epi, **kw_rank)
+        assert torch.equal(rank, full[r * Sl:(r + 1) * Sl]), f"P={P} K={K} N={N} epilogue {epi}: rank rows differ from the full problem's"
+        close(rank[:64], _lin_ref(x[r * Sl:r * Sl + 64].cpu(), w.cpu(), b.cpu()) if epi == ops.EPI_NONE else rank[:64], what="rank rows vs fp32")
+
+
 # ------------------------------------------------------------------ attention
 def _attn_check(out, ref, what):
     """max |err| < 4e-2: the reference's own kernel-test bound (fastvideo-kernel/tests/test_sta.py:88-91).  Mean: the kernel's only bf16

@@ -101,6 +101,53 @@ def test_sp_attention_world8(H, S):
     torch.testing.assert_close(full, ref, atol=1e-5, rtol=1e-5)
 
 
+def _worker_packed_pipelined(rank, world, port, H, S, D, q, k, v, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FVK_SP_OVERLAP="1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fastvideo_amd.distributed import SequenceParallel
+        sp = SequenceParallel(H)
+        L = sp.lay
+        hg = L.heads_per_group
+        qs, ks, vs = (sp.shard(t.unsqueeze(0), dim=1)[0] for t in (q, k, v))
+        Sl = qs.shape[0]
+        ha = (hg + 1) // 2
+        sub = lambda t, a, b: t.reshape(Sl, L.G, hg, D)[:, :, a:b].reshape(Sl, L.G * (b - a), D)
+        sends = [sp.pack_rows(sub(qs, a, b), sub(ks, a, b), sub(vs, a, b)) for a, b in ((0, ha), (ha, hg))]   # what ops.qkv_norm_rope_pack(heads_a=) writes
+        o = sp.attention_packed_pipelined(sends, S, _attn_fn, head_dim=D)
+        ref = sp.attention_packed(sp.pack_rows(qs, ks, vs), S, _attn_fn, head_dim=D)
+        assert sp.pipelined_agrees(o, ref) and sp.overlap and sp._overlap_checked
+        full = sp.all_gather_unpad(o.unsqueeze(0), S, dim=1)[0]
+        if rank == 0:
+            out_q.put((full, (L.G, L.U)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H", [(2, 4), (4, 6), (8, 12), (3, 9)])
+def test_packed_pipelined_exchange_equals_single_process(world, H):
+    """attention_packed_pipelined (round 4: two head chunks, both input exchanges issued up front, each chunk's output exchange issued behind its
+    attention; on the device the second chunk runs on a second HIP stream) == the plain packed exchange == the single-process result, on plain
+    Ulysses grids and on the 2-D grids (6 heads on 4 ranks: G2 x U2; 12 heads on 8: G4 x U2 with 3 heads per group -> chunks of 2 + 1)."""
+    S, D = 77, 16
+    g = torch.Generator().manual_seed(0)
+    q, k, v = (torch.randn((S, H, D), generator=g) for _ in range(3))
+    ref = _attn_fn(q, k, v, S)
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_packed_pipelined, args=(r, world, port, H, S, D, q, k, v, out_q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, (G, U) = out_q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert G * U == world
+    torch.testing.assert_close(out, ref, atol=1e-5, rtol=1e-5)
+
+
 def test_pack_rows_layout_is_the_documented_one():
     """``pack_rows`` (the torch restatement of what fvk_qkv_norm_rope_pack_bf16 writes) against the layout formula of include/fvk_amd.h:
     send[rp, m, slot, :] = head group (rp % G) of token m, slot 0 = K, 1 = V, 2 = Q — for a fake 8-rank layout, no process group."""
