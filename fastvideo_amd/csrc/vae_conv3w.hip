@@ -38,14 +38,14 @@ using fvkc3::OOB;
 #define C3W_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 
 template <int WNW, int EPI>
-__global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
+__global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int ntiles) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = WNW == 1 ? 16 : 8, TW = 32;      // workgroup tile in pixels (4 waves x 4 rows, or 2 row groups x 2 channel halves)
     constexpr int TN = WNW * 96;                        // output channels per workgroup
     constexpr int HH = TH + 2, WW = 40, WWV = TW + 2;   // halo slab: HH rows pitched WW pixels, WWV of them used
     constexpr int ROWB = WW * 64;                       // bytes per halo row (2560: a multiple of 512, so (p >> 2) & 1 is row-invariant)
     constexpr int XPIECES = HH * WW / 16;               // 16-pixel DMA pieces per slab: 45 / 25
-    constexpr int XS = (XPIECES + 3) / 4;               // per wave: 12 / 7
+    constexpr int XS = (XPIECES + 3) / 4;               // per wave: 12 / 7 (the surplus slots of the later waves are skipped)
     constexpr int XS0 = (XS + 1) / 2, XS1 = XS - XS0;   // issued during dh = 0 / dh = 1 of the previous slab
     constexpr int SLAB = XPIECES * 1024;
     constexpr int WT = TN / 16;                         // 16-row weight tiles per dw block: 6 / 12
@@ -53,8 +53,8 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
     constexpr int WS = (WPIECES + 3) / 4;               // per wave: 5 / 9
     constexpr int WSTEP = WPIECES * 1024;
     constexpr int W_BASE = 2 * SLAB;
-    constexpr int SCRATCH = W_BASE + 3 * WSTEP;         // 1 KiB landing zone of the surplus (dummy) pieces
-    static_assert(HH * WW % 16 == 0 && SCRATCH + 1024 <= 160 * 1024, "LDS budget");
+    constexpr int XCH = W_BASE + 3 * WSTEP;             // WNW = 2: 2 KiB for the partner waves' partial sums of squares (fused norm)
+    static_assert(HH * WW % 16 == 0 && XCH + (WNW == 2 ? 2048 : 0) <= 160 * 1024, "LDS budget");
     static_assert(WS + (XS0 > XS1 ? XS0 : XS1) <= 16, "DMA issue slots of a step's second group exhausted");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
@@ -65,22 +65,31 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
     const int l15 = lane & 15, qk = lane >> 4;
     const int wrow = WNW == 1 ? wave : (wave >> 1), wn = WNW == 1 ? 0 : (wave & 1);  // wave: tile rows 4 wrow .. 4 wrow + 3; channels 96 wn ..
 
-    // tile id (n fastest so that consecutive workgroups share the halo slab in L2)
-    int bid = blockIdx.x;
-    const int pid_n = bid % a.ntn; bid /= a.ntn;
-    const int tw_i = bid % a.tiles_w; bid /= a.tiles_w;
-    const int th_i = bid % a.tiles_h;
-    const int t_out = bid / a.tiles_h;
-    const int h0 = th_i * TH, w0 = tw_i * TW, n0 = pid_n * TN;
-
 #if FVK_VARIANTS  // measurement build: with EPI_BIAS and a non-null out_f32, every workgroup's wave 0 stamps s_memtime at kernel entry, loop
-    // start, loop end and kernel end into out_f32 (as uint64 [workgroups][4]) — where a tile's time goes (scripts/conv3w_probe.py)
+    // start, loop end and tile end of its FIRST tile into out_f32 (as uint64 [workgroups][4]) — where a tile's time goes (scripts/conv3w_probe.py)
     unsigned long long stamp_[4] = {0, 0, 0, 0};
 #define C3W_STAMP(K) if (EPI == EPI_BIAS && a.out_f32) stamp_[K] = __builtin_readcyclecounter();
 #else
 #define C3W_STAMP(K)
 #endif
     C3W_STAMP(0)
+
+    // ---- tiles: PERSISTENT workgroups — workgroup b computes tiles b, b + gridDim.x, ... (n fastest in a tile id, so the tiles in flight on the
+    // chip are consecutive and share their halos / weights in L2).  The DMA stream does not stop at a tile boundary: the last slab's steps stage the
+    // NEXT tile's first slab and weight steps exactly as they would the next slab of the same tile, so only a workgroup's first tile pays the cold
+    // prologue burst (every CU fetching 81 KiB at once: 13 k cycles of a 98 k-cycle tile at 96 channels, profiles/r04b_conv3w_tile_probe.log).
+    struct Tile { int t_out, h0, w0, n0; };
+    auto decode = [&](int id) {
+        Tile t;
+        const int pid_n = id % a.ntn; id /= a.ntn;
+        const int tw_i = id % a.tiles_w; id /= a.tiles_w;
+        const int th_i = id % a.tiles_h;
+        t.t_out = id / a.tiles_h; t.h0 = th_i * TH; t.w0 = tw_i * TW; t.n0 = pid_n * TN;
+        return t;
+    };
+    int cur_id = (int)blockIdx.x;
+    Tile cur = decode(cur_id);
+
     // ---- staging: piece q = wave + 4 i; lane -> LDS row 16 q + (lane >> 2), chunk POSITION lane & 3 = source chunk (lane & 3) ^ 2 ((row >> 2) & 1) ----
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)a.in, 0, (unsigned)((long)a.ring * a.Hin * a.Win * a.Cin * 2), 0x00020000);
@@ -88,54 +97,78 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, (unsigned)((long)a.Cout * Ktot * 2), 0x00020000);
     const int chunk16 = ((lane & 3) ^ (2 * ((lane >> 4) & 1))) * 16;  // ((16 q + (lane >> 2)) >> 2) & 1 = (lane >> 4) & 1
     const int CinB = a.Cin * 2;
-    const int hb = h0 - 1, wb = w0 - 1;  // input coordinates of slab pixel (0, 0)
+    // Per-lane source offsets of the pieces of the tile being STAGED; a tile past the end gets OOB offsets (zero fill, no traffic).  A wave's
+    // surplus slot (piece index past the last piece: only the LAST slot of the later waves) re-issues the wave's previous piece — the same
+    // bytes to the same place, so the issue stream needs neither a branch nor a scratch region.
+    const bool x_dup = wave + 4 * (XS - 1) >= XPIECES, w_dup = wave + 4 * (WS - 1) >= WPIECES;   // wave-uniform
+    const int x_last = x_dup ? XS - 2 : XS - 1, w_last = w_dup ? WS - 2 : WS - 1;                // slot whose destination the last slot writes
     unsigned xvo_[XS];
+    auto set_xvo = [&](const Tile& t, bool live) {
+        const int hb = t.h0 - 1, wb = t.w0 - 1;  // input coordinates of slab pixel (0, 0)
 #pragma unroll
-    for (int i = 0; i < XS; ++i) {
-        const int p = (wave + 4 * i) * 16 + (lane >> 2);
-        const int hh = p / WW, ww = p - hh * WW;
-        const int h = hb + hh, w = wb + ww;
-        const bool ok = hh < HH && ww < WWV && (unsigned)h < (unsigned)a.Hin && (unsigned)w < (unsigned)a.Win;
-        xvo_[i] = ok ? (unsigned)((h * a.Win + w) * CinB) + chunk16 : OOB;
-    }
-    unsigned wvo_[WS];
-    int wdw_[WS];
+        for (int i = 0; i < XS; ++i) {
+            const int p = (wave + 4 * (i == XS - 1 ? x_last : i)) * 16 + (lane >> 2);
+            const int hh = p / WW, ww = p - hh * WW;
+            const int h = hb + hh, w = wb + ww;
+            const bool ok = live && hh < HH && ww < WWV && (unsigned)h < (unsigned)a.Hin && (unsigned)w < (unsigned)a.Win;
+            xvo_[i] = ok ? (unsigned)((h * a.Win + w) * CinB) + chunk16 : OOB;
+        }
+    };
+    unsigned wvo_[WS];   // weight pieces: they depend on the tile's n-tile only; the piece's dw tap offset is folded in
+    auto set_wvo = [&](int n0, bool live) {
 #pragma unroll
-    for (int j = 0; j < WS; ++j) {
-        const int q = wave + 4 * j;
-        const int dw = q / WT, tq = q - dw * WT;                 // tile tq of the dw block: wave half tq / 6, MFMA tile tq % 6
-        const int t6 = tq % 6, i = lane >> 2;
-        const int n = n0 + 96 * (tq / 6) + 32 * (t6 >> 1) + 8 * (i >> 2) + (i & 3) + 4 * (t6 & 1);   // MFMA row order (see the header)
-        wvo_[j] = (q < WPIECES && n < a.Cout) ? (unsigned)((long)n * Ktot * 2) + chunk16 : OOB;
-        wdw_[j] = q < WPIECES ? dw : 0;
-    }
+        for (int j = 0; j < WS; ++j) {
+            const int q = wave + 4 * (j == WS - 1 ? w_last : j);
+            const int dw = q / WT, tq = q - dw * WT;                 // tile tq of the dw block: wave half tq / 6, MFMA tile tq % 6
+            const int t6 = tq % 6, i = lane >> 2;
+            const int n = n0 + 96 * (tq / 6) + 32 * (t6 >> 1) + 8 * (i >> 2) + (i & 3) + 4 * (t6 & 1);   // MFMA row order (see the header)
+            wvo_[j] = (live && n < a.Cout) ? (unsigned)((long)n * Ktot * 2) + (unsigned)(dw * a.Cin * 2) + chunk16 : OOB;
+        }
+    };
+    set_xvo(cur, true);
+    set_wvo(cur.n0, true);
     const int cpt = a.Cin / 32;
     const int nslab = a.KT * cpt, nstep = nslab * 3;
     const unsigned frameB = (unsigned)(a.Hin * a.Win * CinB);
-    auto slot_of = [&](int dt) { int sl = a.ring_start + t_out + dt; return sl >= a.ring ? sl - a.ring : sl; };
-    // scalar issue state, advanced incrementally: next slab (xn_dt, xn_cc) = slab xn_s; weight step wn_u = (wn_dt, wn_cc, wn_dh)
-    int xn_dt = 0, xn_cc = 0, xn_s = 0;
-    int wn_dt = 0, wn_cc = 0, wn_dh = 0, wn_u = 0;
-    const unsigned dwB = (unsigned)(a.Cin * 2);
-#define C3W_ISSUE_X(I)  /* piece I of slab xn_s */                                                                  \
+    // Scalar issue state, advanced once per slab / per step and across tiles.  Slabs: tile xs_id (frame xs_t), slab xn_s = (xn_dt, xn_cc), source
+    // offset x_so, LDS buffer offset x_dst (alternates with every slab, tile boundaries included).  Weights: tile ws_id, step wn_u =
+    // (wn_dt, wn_cc, wn_dh), source offset w_so; ring slot = wn_dh (compile-time at every issue site).
+    auto slot_of = [&](int t_out, int dt) { int sl = a.ring_start + t_out + dt; return sl >= a.ring ? sl - a.ring : sl; };
+    int xs_id = cur_id, xs_t = cur.t_out, xn_dt = 0, xn_cc = 0, xn_s = 0;
+    unsigned x_so = (unsigned)slot_of(xs_t, 0) * frameB;
+    int x_dst = wave * 1024;                         // + piece slot * 4096; the other buffer: + SLAB
+    int ws_id = cur_id, wn_dt = 0, wn_cc = 0, wn_dh = 0, wn_u = 0;
+    unsigned w_so = 0;
+    const int w_dst = W_BASE + wave * 1024;          // + ring slot * WSTEP + piece slot * 4096
+#define C3W_ISSUE_X(I)  /* this wave's piece slot I of slab xn_s of tile xs_id */                                   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + x_dst + ((I) == XS - 1 ? x_last : (I)) * 4096), 16, xvo_[I], x_so, 0, 0);
+#define C3W_ADVANCE_X()                                                                                             \
     {                                                                                                               \
-        const bool live_ = xn_s < nslab;                                                                            \
-        const unsigned so_ = __builtin_amdgcn_readfirstlane(live_ ? (unsigned)slot_of(xn_dt) * frameB + (unsigned)xn_cc * 64u : 0u); \
-        const int q_ = wave + 4 * (I);                                                                              \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x_rsrc, (lds_void*)(smem + (q_ < XPIECES ? (xn_s & 1) * SLAB + q_ * 1024 : SCRATCH)), 16, \
-                                                 live_ ? xvo_[I] : OOB, so_, 0, 0);                                 \
+        x_dst = wave * 1024 + (x_dst >= SLAB ? 0 : SLAB);  /* the other slab buffer */                              \
+        x_so += 64u;                                                                                                \
+        if (++xn_cc == cpt) { xn_cc = 0; ++xn_dt; x_so = (unsigned)slot_of(xs_t, xn_dt) * frameB; }                 \
+        if (++xn_s == nslab) { /* the stream moves on to this workgroup's next tile */                              \
+            xn_s = 0; xn_dt = 0; xn_cc = 0;                                                                         \
+            xs_id += (int)gridDim.x;                                                                                \
+            const bool live_ = xs_id < ntiles;                                                                      \
+            const Tile nt_ = decode(live_ ? xs_id : 0);                                                             \
+            xs_t = nt_.t_out;                                                                                       \
+            set_xvo(nt_, live_);                                                                                    \
+            x_so = (unsigned)slot_of(xs_t, 0) * frameB;                                                             \
+        }                                                                                                           \
     }
-#define C3W_ADVANCE_X() { ++xn_s; if (++xn_cc == cpt) { xn_cc = 0; ++xn_dt; } }
-#define C3W_ISSUE_W(J, SLOT)  /* piece J of weight step wn_u into ring slot SLOT */                                 \
+#define C3W_ISSUE_W(J, SLOT)  /* this wave's piece slot J of weight step wn_u of tile ws_id into ring slot SLOT */  \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + w_dst + (SLOT) * WSTEP + ((J) == WS - 1 ? w_last : (J)) * 4096), 16, wvo_[J], w_so, 0, 0);
+#define C3W_ADVANCE_W()                                                                                             \
     {                                                                                                               \
-        const bool live_ = wn_u < nstep;                                                                            \
-        const unsigned so_ = __builtin_amdgcn_readfirstlane(                                                        \
-            live_ ? (unsigned)((((wn_dt * 3 + wn_dh) * 3) * a.Cin + wn_cc * 32) * 2) + (unsigned)wdw_[J] * dwB : 0u); \
-        const int q_ = wave + 4 * (J);                                                                              \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_void*)(smem + (q_ < WPIECES ? W_BASE + (SLOT) * WSTEP + q_ * 1024 : SCRATCH)), 16, \
-                                                 live_ ? wvo_[J] : OOB, so_, 0, 0);                                 \
+        if (++wn_dh == 3) { wn_dh = 0; if (++wn_cc == cpt) { wn_cc = 0; ++wn_dt; } }                                \
+        if (++wn_u == nstep) {                                                                                      \
+            wn_u = 0; wn_dt = 0; wn_cc = 0; wn_dh = 0;                                                              \
+            ws_id += (int)gridDim.x;                                                                                \
+            if (a.ntn > 1 || ws_id >= ntiles) set_wvo(decode(ws_id < ntiles ? ws_id : 0).n0, ws_id < ntiles);       \
+        }                                                                                                           \
+        w_so = (unsigned)((((wn_dt * 3 + wn_dh) * 3) * a.Cin + wn_cc * 32) * 2);                                    \
     }
-#define C3W_ADVANCE_W() { ++wn_u; if (++wn_dh == 3) { wn_dh = 0; if (++wn_cc == cpt) { wn_cc = 0; ++wn_dt; } } }
 
     // ---- fragment read addresses.  Pixel fragment (row r of the wave's 4, 16-column half h, tap (dh, dw)): slab pixel
     //      p = (4 wrow + r + dh) WW + 16 h + l15 + dw, chunk qk at position qk ^ 2 (((l15 + dw) >> 2) & 1): per-lane base per dw, the rest immediates.
@@ -153,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
     f32x4 acc[6][8];   // [weight tile T][pixel block pb = 2 r + h]: D[channel row 4 qk + e of tile T][pixel l15 of block pb]
     bf16x8 WF[3][6], XF[3][8];
 
-    // ---- prologue: slab 0, weight steps 0 and 1 in flight; accumulators zeroed under the flight time -----------------------------------
+    // ---- prologue (the workgroup's FIRST tile only): slab 0, weight steps 0 and 1 in flight ---------------------------------------------
 #pragma unroll
     for (int i = 0; i < XS; ++i) C3W_ISSUE_X(i)
     C3W_ADVANCE_X()
@@ -163,15 +196,6 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
 #pragma unroll
     for (int j = 0; j < WS; ++j) C3W_ISSUE_W(j, 1)
     C3W_ADVANCE_W()
-#pragma unroll
-    for (int t = 0; t < 6; ++t)
-#pragma unroll
-        for (int pb = 0; pb < 8; ++pb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[t][pb][e] = 0.f;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
 
     // fragment k (0..5: weight tile k; 6..13: pixel block k - 6) of the group (slab base XB, ring slot WSLOT, taps DH, DW) into register set RB
 #define C3W_READ(RB, K, XB, WSLOT, DH, DW)                                                                                              \
@@ -194,17 +218,6 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
 #define C3W_DMA0(K_) if ((K_) < WS) C3W_ISSUE_W((K_) < WS ? (K_) : 0, 2) else if ((K_) - WS < XS0) C3W_ISSUE_X((K_) - WS < XS0 ? (K_) - WS : 0)
 #define C3W_DMA1(K_) if ((K_) < WS) C3W_ISSUE_W((K_) < WS ? (K_) : 0, 0) else if ((K_) - WS < XS1) C3W_ISSUE_X((K_) - WS < XS1 ? XS0 + (K_) - WS : 0)
 #define C3W_DMA2(K_) if ((K_) < WS) C3W_ISSUE_W((K_) < WS ? (K_) : 0, 1)
-
-    unsigned xc_[3], xn_[3];  // fragment bases in the slab being read / the next one
-#pragma unroll
-    for (int dw = 0; dw < 3; ++dw) { xc_[dw] = xo_[dw]; xn_[dw] = xo_[dw] + SLAB; }
-    // prime: groups 0 and 1 of step 0 (slab 0, ring slot 0, dh = 0, dw = 0 / 1)
-#pragma unroll
-    for (int k = 0; k < 14; ++k) C3W_READ(0, k, xc_, 0, 0, 0)
-#pragma unroll
-    for (int k = 0; k < 14; ++k) C3W_READ(1, k, xc_, 0, 0, 1)
-    __builtin_amdgcn_sched_barrier(0);
-
     // A K-step u = (slab s, dh): groups dw = 0, 1, 2 from register sets 0, 1, 2.  The step barrier sits after group 0: everything this wave
     // issued in the previous step's second group (weights of step u + 1, slab pieces) has landed by then, and group 1 reads the NEXT step's
     // first fragments behind it.
@@ -218,7 +231,33 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
     C3W_ADVANCE_W()                                                                                                 \
     C3W_GROUP(2, 1, XNEXT_, ((DH) + 1) % 3, ((DH) + 1) % 3, 1, C3W_NO_DMA)
 
-    C3W_STAMP(1)
+    unsigned xc_[3], xn_[3];  // fragment bases in the slab being read / the next one (they swap with every slab, tile boundaries included)
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) { xc_[dw] = xo_[dw]; xn_[dw] = xo_[dw] + SLAB; }
+    const int ncol0w = wn * 96;
+    const int HW = a.H * a.W;
+    bool first = true;
+
+    while (true) {  // tile loop
+    // ---- accumulators zeroed (first tile: under the prologue's flight time), the tile's first pieces landed, groups 0 and 1 of step 0 read ------
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int pb = 0; pb < 8; ++pb)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][pb][e] = 0.f;
+    if (first) {  // (later tiles: slab 0 and weight step 0 were waited for at the previous tile's last step barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 14; ++k) C3W_READ(0, k, xc_, 0, 0, 0)
+#pragma unroll
+    for (int k = 0; k < 14; ++k) C3W_READ(1, k, xc_, 0, 0, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    if (first) { C3W_STAMP(1) }
+
     for (int s = 0; s < nslab; ++s) {
         // the per-slot weight bases are loop invariants: left visible, LICM hoists all 54 (slot, dw, tile) fragment addresses into registers of
         // their own (parked in AGPRs, one v_accvgpr_read per read) instead of one base + the instruction's 16-bit immediate
@@ -231,16 +270,9 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
 #pragma unroll
         for (int dw = 0; dw < 3; ++dw) { const unsigned t_ = xc_[dw]; xc_[dw] = xn_[dw]; xn_[dw] = t_; }
     }
-#undef C3W_STEP
-#undef C3W_GROUP
-#undef C3W_READ
-#undef C3W_ISSUE_X
-#undef C3W_ISSUE_W
-#undef C3W_ADVANCE_X
-#undef C3W_ADVANCE_W
-    // the trailing (never consumed) fragment reads and dummy pieces have retired before LDS is reused / the workgroup ends
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    C3W_STAMP(2)
+    // the trailing fragment reads (the next tile's first groups — re-read below once the epilogue has released its registers) have retired
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (first) { C3W_STAMP(2) }
     // the accumulators were written by asm MFMAs: the compiler knows no hazard distance to its own reads of them
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
@@ -250,8 +282,8 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
 
     // ---- epilogue, straight from the accumulators: lane (l15, qk) holds, for pixel l15 of block pb, channels ncol0 + 32 P + 8 qk + 0..7
     //      (tile 2P: + 0..3, tile 2P + 1: + 4..7).  Rounding points as vae_conv3.hip: y = bf16(acc + bias); bf16(residual + y); norm on the bf16 values.
-    const int ncol0 = n0 + wn * 96;
-    const int HW = a.H * a.W;
+    {
+    const int ncol0 = cur.n0 + ncol0w, h0 = cur.h0, w0 = cur.w0, t_out = cur.t_out;
     float bias8[3][8];
 #pragma unroll
     for (int P = 0; P < 3; ++P) {
@@ -298,21 +330,20 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
         ss[pb] = sq;
     }
 #if FVK_VARIANTS
-    if (EPI == EPI_BIAS && a.out_f32) {
+    if (first && EPI == EPI_BIAS && a.out_f32) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stores have been accepted
         C3W_STAMP(3)
         if (wave == 0 && lane == 0)
             for (int i = 0; i < 4; ++i) reinterpret_cast<unsigned long long*>(a.out_f32)[(long)blockIdx.x * 4 + i] = stamp_[i];
     }
 #endif
-    if (!fused) return;
+    if (fused) {
     // ---- fused RMS-norm (+SiLU) into the consumer conv's input ring: ref WanRMS_norm (wanvae.py:231-232) + SiLU (:418-419) on the bf16-rounded
     //      conv output: inv = sqrt(C) / max(||x||_2, 1e-12); out = bf16(silu(x * inv * gamma))
     if (WNW == 2) {
-        // the partner wave (same pixels, the other 96 channels) = wave ^ 1: swap partial sums through the (dead) slab region.  norm_out is a kernel
-        // argument, so all four waves reach the barriers.
-        __builtin_amdgcn_s_barrier();  // every wave is past its last fragment read: the slab region is free
-        float* xch = reinterpret_cast<float*>(smem);
+        // the partner wave (same pixels, the other 96 channels) = wave ^ 1: swap partial sums through 2 KiB of LDS of their own (the slab and
+        // weight regions already hold the next tile's first pieces).  norm_out is a kernel argument, so all four waves reach the barriers.
+        float* xch = reinterpret_cast<float*>(smem + XCH);
         if (qk == 0) {
 #pragma unroll
             for (int pb = 0; pb < 8; ++pb) xch[(wave * 8 + pb) * 16 + l15] = ss[pb];
@@ -321,6 +352,8 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
         __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int pb = 0; pb < 8; ++pb) ss[pb] += xch[((wave ^ 1) * 8 + pb) * 16 + l15];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // (the next tile's epilogue writes the same words)
     }
     int slot = a.norm_slot0 + t_out;
     slot = slot >= a.norm_ring ? slot - a.norm_ring : slot;
@@ -328,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
     float gam[3][8];
 #pragma unroll
     for (int P = 0; P < 3; ++P) {
-        const float* gp = a.norm_gamma + wn * 96 + 32 * P + 8 * qk;
+        const float* gp = a.norm_gamma + ncol0w + 32 * P + 8 * qk;
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { gam[P][e] = g0[e]; gam[P][4 + e] = g1[e]; }
@@ -339,7 +372,7 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
         const int h = h0 + 4 * wrow + (pb >> 1), w = w0 + 16 * (pb & 1) + l15;
         if (h < a.H && w < a.W) {
             const float inv = sqrtC / fmaxf(sqrtf(ss[pb]), 1e-12f);
-            const long base = ((long)slot * HW + (long)h * a.W + w) * a.Cout + wn * 96 + 8 * qk;
+            const long base = ((long)slot * HW + (long)h * a.W + w) * a.Cout + ncol0w + 8 * qk;
 #pragma unroll
             for (int P = 0; P < 3; ++P) {
                 bf16x8 o;
@@ -354,20 +387,50 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a) {
             }
         }
     }
+    }  // fused
+    }  // epilogue
+    first = false;
+    cur_id += (int)gridDim.x;
+    if (cur_id >= ntiles) break;   // workgroup-uniform
+    cur = decode(cur_id);
+    }  // tile loop
+    // (a tile past the end was staged as zero-fill pieces: retire them before the workgroup's LDS is released)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef C3W_STEP
+#undef C3W_GROUP
+#undef C3W_READ
+#undef C3W_ISSUE_X
+#undef C3W_ISSUE_W
+#undef C3W_ADVANCE_X
+#undef C3W_ADVANCE_W
 #endif  // __HIP_DEVICE_COMPILE__
 }
+
+int fvk_vae_conv_tunable();  // vae_conv.hip: the "vae_conv_impl" measurement switch
 
 template <int WNW, int EPI>
 int launch3w(Conv3Args a, hipStream_t s) {
     constexpr int TH = WNW == 1 ? 16 : 8, TN = WNW * 96;
-    constexpr int LDS = 2 * ((TH + 2) * 40 / 16) * 1024 + 3 * (3 * TN / 16) * 1024 + 1024;
+    constexpr int LDS = 2 * ((TH + 2) * 40 / 16) * 1024 + 3 * (3 * TN / 16) * 1024 + (WNW == 2 ? 2048 : 0);
     static FvkLdsConfigured configured;
     if (int rc = fvk_config_lds(configured, (const void*)vae_conv3w_kernel<WNW, EPI>, LDS, "fvk_vae_conv_bf16 (3x3, one wave per SIMD)")) return rc;
     a.tiles_h = (a.H + TH - 1) / TH;
     a.tiles_w = (a.W + 31) / 32;
     a.ntn = (a.Cout + TN - 1) / TN;
     const long nwg = (long)a.T * a.tiles_h * a.tiles_w * a.ntn;
-    hipLaunchKernelGGL((vae_conv3w_kernel<WNW, EPI>), dim3((unsigned)nwg), dim3(256), LDS, s, a);
+    // persistent workgroups: one per CU (the 144-160 KiB of LDS admit one), each walking tiles b, b + grid, ...; "vae_conv_impl" 4 (measurement
+    // build) = one workgroup per tile, i.e. every tile pays its own cold prologue (A/B)
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    long grid = nwg < n_cu ? nwg : n_cu;
+#if FVK_VARIANTS
+    if (fvk_vae_conv_tunable() == 4) grid = nwg;
+#endif
+    hipLaunchKernelGGL((vae_conv3w_kernel<WNW, EPI>), dim3((unsigned)grid), dim3(256), LDS, s, a, (int)nwg);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }

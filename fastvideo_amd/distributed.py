@@ -417,11 +417,14 @@ class SequenceParallel:
         """First-call verdict of the pipelined exchange, identical on every rank: True iff EVERY rank's pipelined result equals its plain one bit
         for bit; on False the pipelined mode is switched off (with a warning) and callers use ``ref``."""
         self._overlap_checked = True
-        ok = torch.tensor([1 if torch.equal(o, ref) else 0], dtype=torch.int32, device="cpu" if self._stage_host else o.device)
+        same = torch.equal(o, ref)
+        ok = torch.tensor([1 if same else 0], dtype=torch.int32, device="cpu" if self._stage_host else o.device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=self.group)
         if int(ok.item()) != 1:
             import warnings
-            warnings.warn("fastvideo_amd: the pipelined sequence-parallel exchange disagreed with the plain exchange on its first call; "
+            d_ = (o.float() - ref.float()).abs()
+            warnings.warn("fastvideo_amd: the pipelined sequence-parallel exchange disagreed with the plain exchange on its first call "
+                          f"(rank {self.lay.rank}: {'equal here' if same else f'{int((d_ > 0).sum())} of {d_.numel()} elements differ, max {d_.max().item():.4g}, non-finite {int((~torch.isfinite(o.float())).sum())}'}); "
                           "falling back to the plain exchange (set FVK_SP_OVERLAP=0 to silence)")
             self.overlap = False
             return False

@@ -12,6 +12,9 @@ from fastvideo_amd import _lib, ops
 
 assert os.environ.get("FVK_PROBE_LIB") == "1"
 g = torch.Generator().manual_seed(0)
+IMPL = int(os.environ.get("VAE_CONV_IMPL", "0"))   # 4 = one workgroup per tile (every tile pays its cold prologue), 0 = persistent workgroups
+ops.set_tunable("vae_conv_impl", IMPL)
+print(f"vae_conv_impl {IMPL}")
 for (Cin, Cout, T, H, W, kt) in ((96, 96, 4, 480, 832, 3), (96, 96, 4, 480, 832, 1), (192, 192, 4, 240, 416, 3), (192, 192, 4, 240, 416, 1),
                                  (384, 384, 4, 120, 208, 3)):
     ring = T + kt - 1
@@ -21,7 +24,7 @@ for (Cin, Cout, T, H, W, kt) in ((96, 96, 4, 480, 832, 3), (96, 96, 4, 480, 832,
     out = torch.empty((T, H, W, Cout), dtype=torch.bfloat16, device="cuda")
     TH, TN = (16, 96) if Cout % 192 else (8, 192)
     nwg = T * ((H + TH - 1) // TH) * ((W + 31) // 32) * (Cout // TN)
-    probe = torch.zeros((nwg, 4), dtype=torch.int64, device="cuda")
+    probe = torch.zeros((nwg, 4), dtype=torch.int64, device="cuda")   # persistent launches fill the first min(nwg, CUs) rows: each workgroup's FIRST tile
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     for it in range(3):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -31,6 +34,7 @@ for (Cin, Cout, T, H, W, kt) in ((96, 96, 4, 480, 832, 3), (96, 96, 4, 480, 832,
         torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     st = probe.cpu().double()
+    st = st[st[:, 3] > 0]
     pro, loop, epi = (st[:, 1] - st[:, 0]), (st[:, 2] - st[:, 1]), (st[:, 3] - st[:, 2])
     nstep = kt * (Cin // 32) * 3
     span = (st[:, 3].max() - st[:, 0].min()).item()

@@ -63,26 +63,26 @@ def test_sp_forward_equals_sp1(world, golden_dir):
         assert err.max().item() < 0.1
 
 
-def _pipelined_model_forward(overlap_expected):
-    """A 6-head, 2-layer model on seeded weights (CPU generator: identical in every process), ragged token count; returns (y, sp.overlap)."""
+def _pipelined_model_forward(overlap_expected, heads=6, lat_shape=(1, 16, 5, 18, 30)):
+    """A 2-layer model on seeded weights (CPU generator: identical in every process), ragged token count; returns (y, sp.overlap, checked)."""
     from fastvideo_amd import wan_config as WC
     from fastvideo_amd.wan_dit import WanTransformer3DModelHip
-    cfg = WC.WanConfig("sp-pipe", 6, 128, 768, 2, text_dim=64)
+    cfg = WC.WanConfig("sp-pipe", heads, 128, 768, 2, text_dim=64)
     sd = WC.random_state_dict(cfg, seed=4, device="cpu")
     model = WanTransformer3DModelHip(sd, cfg.num_heads, device="cuda:0")
     g = torch.Generator().manual_seed(12)
-    lat = torch.randn((1, 16, 5, 18, 30), generator=g).bfloat16()    # 5 x 9 x 15 = 675 tokens: odd -> one zero-padding row on 2 ranks
+    lat = torch.randn(lat_shape, generator=g).bfloat16()    # default 5 x 9 x 15 = 675 tokens: odd -> one zero-padding row on 2 ranks
     ctx = torch.randn((1, 40, cfg.text_dim), generator=g).bfloat16()
     ys = [model(lat.cuda(), ctx.cuda(), torch.tensor([333.0]).cuda()).cpu() for _ in range(2)]   # second forward: the check is behind it
     assert torch.equal(ys[0], ys[1])
     return ys[0], model.sp.overlap, model.sp._overlap_checked
 
 
-def _worker_pipelined(rank, world, port, out_q):
+def _worker_pipelined(rank, world, port, out_q, heads=6, lat_shape=(1, 16, 5, 18, 30)):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FVK_SP_OVERLAP="1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        out = _pipelined_model_forward(True)
+        out = _pipelined_model_forward(True, heads, lat_shape)
         if rank == 0:
             out_q.put(out)
             out_q.close(); out_q.join_thread()
@@ -91,20 +91,22 @@ def _worker_pipelined(rank, world, port, out_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sp_pipelined_two_stream_exchange_equals_sp1(world):
+@pytest.mark.parametrize("world,heads,lat_shape", [(2, 6, (1, 16, 5, 18, 30)), (3, 6, (1, 16, 5, 18, 30)), (2, 12, (1, 16, 5, 42, 62))])
+def test_sp_pipelined_two_stream_exchange_equals_sp1(world, heads, lat_shape):
     """FVK_SP_OVERLAP=1 on the device path (round 4): the QK-norm / RoPE pass writes TWO head-chunk send buffers (fvk_qkv_norm_rope_pack2_bf16),
     both exchanges are issued up front, chunk B's attention runs on a second HIP stream, the output exchanges follow their chunks
     (fastvideo_amd/distributed.py: attention_packed_pipelined).  6 heads: world 2 -> 3 heads per group (chunks of 2 + 1), world 3 -> 2 per group.
-    The forward must equal SP = 1 bit for bit, and the mode must have survived its own first-call check against the plain exchange."""
+    The third case is the bench's shape class: 12 heads on 2 ranks (6 per group: chunks of 3 + 3) on a 3 255-token latent — long key axes, i.e. the
+    one-wave-per-SIMD attention kernels.  The forward must equal SP = 1 bit for bit, and the mode must have survived its own first-call check
+    against the plain exchange."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    ref, ov, _ = _pipelined_model_forward(False)
+    ref, ov, _ = _pipelined_model_forward(False, heads, lat_shape)
     assert not ov
     ctx = mp.get_context("spawn")
     out_q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, out_q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, out_q, heads, lat_shape)) for r in range(world)]
     for p in procs:
         p.start()
     out, overlap_kept, checked = out_q.get(timeout=300)
