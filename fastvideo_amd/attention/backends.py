@@ -62,9 +62,65 @@ class HipDenseAttentionImpl(AttentionImpl):
             raise ValueError("HipDenseAttentionImpl: grouped-query attention is not supported")
         self.softmax_scale = head_size**-0.5 if softmax_scale is None else softmax_scale
 
+    @staticmethod
+    def _key_padding_mask(attn_mask, key) -> torch.Tensor:
+        """The reference's mask normalisation (``_normalize_attn_mask_for_sdpa``, sdpa.py:70-103) restricted to what a KEY-PADDING mask is:
+        bool / integer [B, Skv] (or [B, 1, 1, Skv] / [B, 1, Skv]), True / non-zero = attend; a floating mask must hold only 0 and -inf.
+        Shorter masks are front-padded with "attend" exactly as the reference does (:88-92).  Returns bool [B, Skv].  Masks that differ per
+        query row or per head are refused (the Wan / FastWan pipelines only ever pass tokenizer padding masks)."""
+        B, Skv = key.shape[0], key.shape[1]
+        m = attn_mask.to(device=key.device)
+        if m.dim() == 4:
+            if m.shape[1] != 1 or m.shape[2] != 1:
+                raise NotImplementedError(f"HipDenseAttentionImpl: only key-padding masks [B, 1, 1, Skv] are supported, got {tuple(m.shape)}")
+            m = m[:, 0, 0]
+        elif m.dim() == 3:
+            if m.shape[1] != 1:
+                raise NotImplementedError(f"HipDenseAttentionImpl: only key-padding masks [B, 1, Skv] are supported, got {tuple(m.shape)}")
+            m = m[:, 0]
+        elif m.dim() != 2:
+            raise ValueError(f"Unsupported attention mask shape for SDPA: {tuple(attn_mask.shape)}")
+        if m.dtype.is_floating_point:
+            if not bool(((m == 0) | (m == float("-inf"))).all()):
+                raise NotImplementedError("HipDenseAttentionImpl: additive masks other than 0 / -inf are not supported")
+            m = m == 0
+        elif m.dtype != torch.bool:
+            m = m != 0
+        if m.shape[-1] > Skv:
+            raise ValueError(f"Invalid attention mask length for SDPA: expected at most {Skv}, got {m.shape[-1]}")
+        if m.shape[-1] < Skv:
+            m = torch.nn.functional.pad(m, (Skv - m.shape[-1], 0), value=True)
+        if m.shape[0] == 1 and B > 1:
+            m = m.expand(B, Skv)
+        if m.shape[0] != B:
+            raise ValueError(f"attention mask batch {m.shape[0]} != {B}")
+        return m
+
+    def _forward_key_padding(self, query, key, value, mask):
+        """Key-padding mask [B, Skv] (sdpa.py:134-147; flash_attn.py:279-330's varlen branch): every batch element attends to its valid keys
+        only.  The kernels take a key COUNT, so a sample whose valid keys are a prefix (padding at the end: the tokenizer case) runs in place
+        on ``key[b, :n]``; a mask with holes compacts that sample's K / V rows first (one gather pass).  One launch per sample; the counts
+        come to the host once per call (one synchronisation — this is not the Wan T2V hot path, which passes no mask).  A sample with no valid
+        key yields NaN rows in the reference (softmax over an empty set); refused here."""
+        B = query.shape[0]
+        counts = mask.sum(dim=1).tolist()
+        prefix = (mask.to(torch.int8).diff(dim=1) <= 0).all(dim=1).tolist()   # no False -> True transition: valid keys first
+        out = torch.empty_like(query)
+        for b in range(B):
+            n = int(counts[b])
+            if n == 0:
+                raise ValueError(f"HipDenseAttentionImpl: sample {b} has no valid key (the reference's softmax would return NaN rows)")
+            if prefix[b]:
+                kb, vb = key[b:b + 1, :n], value[b:b + 1, :n]
+            else:
+                idx = torch.nonzero(mask[b], as_tuple=False).flatten().to(torch.int32)
+                kb = ops.gather_rows(key[b:b + 1], n, src_index=idx)
+                vb = ops.gather_rows(value[b:b + 1], n, src_index=idx)
+            ops.attn_dense(query[b:b + 1], kb, vb, scale=self.softmax_scale, layout="bshd", out=out[b:b + 1])
+        return out
+
     def forward(self, query, key, value, attn_metadata=None):
-        if attn_metadata is not None and getattr(attn_metadata, "attn_mask", None) is not None:
-            raise NotImplementedError("HipDenseAttentionImpl: attention masks are not supported")
+        attn_mask = getattr(attn_metadata, "attn_mask", None) if attn_metadata is not None else None
         # ref: FlashAttentionImpl.forward (flash_attn.py:255-266): non-half activations that leak into attention are cast through
         # bf16 for the kernel and restored on output (the reference's own tests run fp32 tensors through this backend)
         orig_dtype = query.dtype
@@ -73,7 +129,10 @@ class HipDenseAttentionImpl(AttentionImpl):
                 raise RuntimeError(f"HipDenseAttentionImpl: unsupported dtype {orig_dtype} (bf16, or fp32 cast through bf16)")
             query, key, value = query.to(torch.bfloat16), key.to(torch.bfloat16), value.to(torch.bfloat16)
         _require_bf16_cuda(query, key, value)
-        out = ops.attn_dense(query, key, value, scale=self.softmax_scale, layout="bshd")
+        if attn_mask is not None:
+            out = self._forward_key_padding(query, key, value, self._key_padding_mask(attn_mask, key))
+        else:
+            out = ops.attn_dense(query, key, value, scale=self.softmax_scale, layout="bshd")
         return out if out.dtype == orig_dtype else out.to(orig_dtype)
 
 

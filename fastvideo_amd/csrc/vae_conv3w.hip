@@ -28,6 +28,8 @@
 #include "fvk_common.h"
 #include "vae_conv3_args.h"
 
+int fvk_vae_conv_tunable();  // vae_conv.hip: the "vae_conv_impl" measurement switch
+
 namespace {
 
 using fvkc3::Conv3Args;
@@ -405,8 +407,6 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
 #undef C3W_ADVANCE_W
 #endif  // __HIP_DEVICE_COMPILE__
 }
-
-int fvk_vae_conv_tunable();  // vae_conv.hip: the "vae_conv_impl" measurement switch
 
 template <int WNW, int EPI>
 int launch3w(Conv3Args a, hipStream_t s) {

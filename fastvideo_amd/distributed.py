@@ -88,17 +88,15 @@ class SequenceParallel:
         # production runs use backend "nccl" = RCCL, which takes device pointers directly)
         self._stage_host = P > 1 and dist.get_backend(group) == "gloo"
         # Pipelined exchange (attention_packed_pipelined): a rank's head group is split in two chunks; both input exchanges are issued
-        # asynchronously up front, chunk A's attention runs on the caller's stream and chunk B's on a SECOND HIP stream (each chunk is a full
-        # pass over the keys on its own part of the grid — 128 + 64 workgroups at SP = 8 co-run on the 256 CUs instead of queueing behind
-        # one another), and chunk A's output exchange rides under chunk B's attention.  What it can save inside ONE batch-1 forward is bounded:
-        # every op of a DiT layer depends on the previous one, so the critical path is still exchange #1 (all of it) -> attention ->
-        # exchange #2 of the LAST chunk; only the first chunk's share of exchange #2 (~1/6 of a layer's exchange time) is hidden.  Hence OPT-IN
-        # (FVK_SP_OVERLAP=1) until an 8-GPU node has measured it; the default is the plain single-collective exchange.  Heads are
-        # independent in attention, so the result is the plain exchange's bit for bit — checked on the first call (all-reduced verdict);
-        # any rank seeing a difference switches every rank back to the plain exchange.
+        # asynchronously up front, so chunk B's all-to-all rides under chunk A's attention and chunk A's output exchange under chunk B's.
+        # What it can save inside ONE batch-1 forward is bounded: every op of a DiT layer depends on the previous one, so the critical path
+        # is still exchange #1 (all of it) -> attention -> exchange #2 of the LAST chunk; only the first chunk's share of exchange #2 (~1/6 of
+        # a layer's exchange time) is hidden, and two attention launches in stream order split the grid (192 workgroups at SP = 8 become
+        # 128 + 64).  Hence OPT-IN (FVK_SP_OVERLAP=1) until an 8-GPU node has measured it; the default is the plain single-collective
+        # exchange.  Heads are independent in attention, so the result is the plain exchange's bit for bit — checked on the first call
+        # (all-reduced verdict); any rank seeing a difference switches every rank back to the plain exchange.
         self.overlap = P > 1 and os.environ.get("FVK_SP_OVERLAP") == "1"
         self._overlap_checked = False
-        self._side_stream = None
         # bench.py's exchange accounting: set ``stats`` to a dict to collect, per exchange kind, the bytes this rank sends to OTHER
         # ranks and HIP-event pairs around the collective on the caller's stream (None = nothing recorded, nothing extra on the stream)
         self.stats = None
@@ -371,46 +369,34 @@ class SequenceParallel:
 
     def attention_packed_pipelined(self, sends, S: int, attn_fn, head_dim: int = 128):
         """The pipelined form of ``attention_packed``: ``sends`` = the two head-chunk send buffers of ``ops.qkv_norm_rope_pack(heads_a=...)``
-        ([P, Sl, 3, Wa], [P, Sl, 3, Wb]).  Both exchanges are issued up front; chunk A runs on the caller's stream, chunk B on a second HIP
-        stream; each chunk's output exchange is issued as soon as its attention is; the caller's stream then waits for both and assembles
-        [Sl, H, D] (heads in the un-chunked order).  CPU / gloo: the same order of operations without streams (tests)."""
-        import contextlib
+        ([P, Sl, 3, Wa], [P, Sl, 3, Wb]).  Both input exchanges are issued asynchronously up front (RCCL runs them on the process group's own
+        stream; ``wait()`` only orders the compute stream), chunk B's exchange rides under chunk A's attention, each chunk's output exchange is
+        issued as soon as its attention is and chunk A's rides under chunk B's attention; the compute stream then waits for both and assembles
+        [Sl, H, D] (heads in the un-chunked order).  ONE compute stream: running chunk B's attention on a second HIP stream was built and
+        withdrawn in round 4 — on the one-GPU box (two ranks sharing cuda:0, host-staged gloo) two consecutive forwards then differed in
+        their last bits at long key axes although each chunk only touches its own buffers; until that is understood on real RCCL the chunks
+        stay in stream order.  CPU / gloo: the same order of operations (tests)."""
         L = self.lay
         Sl = sends[0].shape[1]
-        on_dev = sends[0].is_cuda
-        main = torch.cuda.current_stream() if on_dev else None
-        if on_dev and self._side_stream is None:
-            self._side_stream = torch.cuda.Stream()
-        streams = [main, self._side_stream] if on_dev else [None, None]
-        if on_dev:
-            self._side_stream.wait_stream(main)   # the side stream starts behind everything issued so far (the pack kernel, the allocator's reuse)
         pend = [self.exchange_rows_async(s_) for s_ in sends]
         outs = []
         o_in, o_out = self._o_splits(Sl)
-        for st, send, done in zip(streams, sends, pend):
-            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-                t0 = self._tick()
-                recv = done()
-                self._tock(t0, "exchange1", send.numel() * send.element_size() * (L.P - 1) // L.P)
-                if st is not None and st is not main:
-                    recv.record_stream(st)
-                q_blk, k_all, v_all = self.views_of(recv, head_dim)
-                o_blk = attn_fn(q_blk, k_all, v_all, S).contiguous()
-                outs.append((o_blk.shape[1], self._a2a_async(o_blk, o_in, o_out, L.G * Sl), o_blk, recv, st))
+        for send, done in zip(sends, pend):
+            t0 = self._tick()
+            recv = done()
+            self._tock(t0, "exchange1", send.numel() * send.element_size() * (L.P - 1) // L.P)
+            q_blk, k_all, v_all = self.views_of(recv, head_dim)
+            o_blk = attn_fn(q_blk, k_all, v_all, S).contiguous()
+            outs.append((o_blk.shape[1], self._a2a_async(o_blk, o_in, o_out, L.G * Sl), o_blk, recv))
         hg = sum(o[0] for o in outs)
         out = sends[0].new_empty((Sl, L.G, hg, head_dim))
         a = 0
-        for hc, done, o_blk, _recv, st in outs:
+        for hc, done, o_blk, _recv in outs:
             t0 = self._tick()
             res = done()
             self._tock(t0, "exchange2", (L.G - 1) * Sl * hc * head_dim * o_blk.element_size())
-            if st is not None and st is not main:
-                res.record_stream(main)
-                o_blk.record_stream(main)
             out[:, :, a:a + hc] = res.reshape(L.G, Sl, hc, head_dim).permute(1, 0, 2, 3)
             a += hc
-        if on_dev:
-            main.wait_stream(self._side_stream)
         return out.reshape(Sl, L.G * hg, head_dim)
 
     def pipelined_agrees(self, o: torch.Tensor, ref: torch.Tensor) -> bool:

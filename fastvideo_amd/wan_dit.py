@@ -578,8 +578,8 @@ class WanTransformer3DModelHip:
                                                                sp.lay.G, sp.lay.U, head_dim=D, seq_len=S, eps=self.eps, pos_offset=pos0, **kw)
                     hg = sp.lay.heads_per_group
                     if sp.overlap and hg >= 2:
-                        # FVK_SP_OVERLAP=1: two head chunks (the larger first), their exchanges asynchronous, their attention launches on two
-                        # HIP streams (distributed.py: attention_packed_pipelined); the first call is checked against the plain exchange
+                        # FVK_SP_OVERLAP=1: two head chunks (the larger first), their exchanges asynchronous
+                        # (distributed.py: attention_packed_pipelined); the first call is checked against the plain exchange
                         o = sp.attention_packed_pipelined(pack(heads_a=(hg + 1) // 2), S, fn, head_dim=D).reshape(Sl, d)
                         if not sp._overlap_checked:
                             ref = sp.attention_packed(pack(), S, fn, head_dim=D).reshape(Sl, d)

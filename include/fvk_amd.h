@@ -108,8 +108,8 @@ int fvk_qkv_norm_rope_pack_bf16(const void* q, const void* k, const void* v, con
                                 const float* sin, void* send, int Sl, int width, int head_dim, int seq_len, int pos_offset,
                                 long in_stride, int G, int U, float eps, void* stream);
 /* The same pass writing TWO send buffers — the first `heads_a` heads of every head group into send_a [G*U, Sl, 3, heads_a*head_dim], the rest into
- * send_b [G*U, Sl, 3, (heads/G - heads_a)*head_dim] — for the pipelined exchange (two head chunks whose all-to-alls and attention launches overlap
- * on two HIP streams, fastvideo_amd/distributed.py: attention_packed_pipelined).  Heads are independent in attention, so the chunks' outputs are
+ * send_b [G*U, Sl, 3, (heads/G - heads_a)*head_dim] — for the pipelined exchange (two head chunks: chunk B's all-to-all overlaps chunk A's attention,
+ * chunk A's output exchange chunk B's attention; fastvideo_amd/distributed.py: attention_packed_pipelined).  Heads are independent in attention, so the chunks' outputs are
  * the un-chunked output's columns bit for bit. */
 int fvk_qkv_norm_rope_pack2_bf16(const void* q, const void* k, const void* v, const void* wq, const void* wk, const float* cos,
                                  const float* sin, void* send_a, void* send_b, int heads_a, int Sl, int width, int head_dim, int seq_len,

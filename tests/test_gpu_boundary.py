@@ -76,6 +76,49 @@ def test_dense_impl_on_strided_chunks_and_fp32_inputs():
         impl.forward(q.cpu(), k.cpu(), v.cpu(), None)
 
 
+def test_dense_impl_key_padding_masks():
+    """Key-padding masks through ``attn_metadata.attn_mask`` (SDPAImpl.forward + ``_normalize_attn_mask_for_sdpa``, sdpa.py:70-147; the varlen
+    branch of flash_attn.py:279-330): [B, Skv] bool / int64 tokenizer masks, the [B, 1, 1, Skv] form, a 0 / -inf additive mask, a SHORTER
+    mask (front-padded with "attend", :88-92), padding at the end (in place, a key count) and a mask with holes (compacted rows) — against
+    torch SDPA in fp32 with the same mask.  Per-query / per-head masks are refused with the reason."""
+    import types
+    import torch.nn.functional as F
+    from fastvideo_amd.attention import HipDenseAttentionBackend
+    B, Sq, Skv, H, D = 2, 300, 700, 3, 128
+    impl = HipDenseAttentionBackend.get_impl_cls()(num_heads=H, head_size=D, causal=False, softmax_scale=D**-0.5, num_kv_heads=H)
+    q, k, v = rnd((B, Sq, H, D), 1).to(DEV), rnd((B, Skv, H, D), 2).to(DEV), rnd((B, Skv, H, D), 3).to(DEV)
+    tail = torch.ones((B, Skv), dtype=torch.bool)
+    tail[1, 413:] = False                                  # sample 1: padding at the end (sample 0: nothing masked)
+    holes = tail.clone()
+    holes[0, 5:77] = False
+    holes[0, 600] = False
+    holes[1, ::3] = False
+
+    def ref(mask_bool):
+        m4 = mask_bool[:, None, None, :]
+        return F.scaled_dot_product_attention(q.float().cpu().transpose(1, 2), k.float().cpu().transpose(1, 2), v.float().cpu().transpose(1, 2),
+                                              attn_mask=m4, scale=D**-0.5).transpose(1, 2)
+
+    md = lambda m: types.SimpleNamespace(attn_mask=m)
+    for name, mask in (("tail", tail), ("holes", holes)):
+        r = ref(mask)
+        for form, m in (("bool [B,Skv]", mask), ("int64", mask.long()), ("[B,1,1,Skv]", mask[:, None, None, :].to(DEV)),
+                        ("additive 0/-inf", torch.zeros((B, Skv)).masked_fill(~mask, float("-inf")))):
+            _attn_check(impl.forward(q, k, v, md(m)), r, f"key-padding mask {name}, {form}")
+    # a shorter mask covers the LAST keys; the keys in front of it are attended (front-pad, sdpa.py:88-92)
+    short = torch.ones((B, 500), dtype=torch.bool)
+    short[0, 450:] = False
+    full = torch.cat([torch.ones((B, 200), dtype=torch.bool), short], 1)
+    _attn_check(impl.forward(q, k, v, md(short)), ref(full), "short mask, front-padded")
+    assert torch.equal(impl.forward(q, k, v, md(torch.ones((B, Skv), dtype=torch.bool))), impl.forward(q, k, v, None))   # all-true == no mask
+    with pytest.raises(NotImplementedError, match="key-padding"):
+        impl.forward(q, k, v, md(torch.ones((B, 1, Sq, Skv), dtype=torch.bool)))
+    with pytest.raises(ValueError, match="no valid key"):
+        impl.forward(q, k, v, md(torch.zeros((B, Skv), dtype=torch.bool)))
+    with pytest.raises(ValueError, match="expected at most"):
+        impl.forward(q, k, v, md(torch.ones((B, Skv + 1), dtype=torch.bool)))
+
+
 def test_vsa_impl_tile_forward_untile_matches_oracle():
     """``HipVideoSparseAttentionImpl`` driven exactly as ``DistributedAttention_VSA.forward`` drives the reference impl
     (layer.py:214-240): qkvg stacked on the batch axis -> preprocess_qkv (tile) -> chunk(4) -> forward -> postprocess_output."""

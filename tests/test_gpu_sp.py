@@ -92,9 +92,9 @@ def _worker_pipelined(rank, world, port, out_q, heads=6, lat_shape=(1, 16, 5, 18
 
 
 @pytest.mark.parametrize("world,heads,lat_shape", [(2, 6, (1, 16, 5, 18, 30)), (3, 6, (1, 16, 5, 18, 30)), (2, 12, (1, 16, 5, 42, 62))])
-def test_sp_pipelined_two_stream_exchange_equals_sp1(world, heads, lat_shape):
+def test_sp_pipelined_exchange_equals_sp1(world, heads, lat_shape):
     """FVK_SP_OVERLAP=1 on the device path (round 4): the QK-norm / RoPE pass writes TWO head-chunk send buffers (fvk_qkv_norm_rope_pack2_bf16),
-    both exchanges are issued up front, chunk B's attention runs on a second HIP stream, the output exchanges follow their chunks
+    both exchanges are issued up front, the output exchanges follow their chunks
     (fastvideo_amd/distributed.py: attention_packed_pipelined).  6 heads: world 2 -> 3 heads per group (chunks of 2 + 1), world 3 -> 2 per group.
     The third case is the bench's shape class: 12 heads on 2 ranks (6 per group: chunks of 3 + 3) on a 3 255-token latent — long key axes, i.e. the
     one-wave-per-SIMD attention kernels.  The forward must equal SP = 1 bit for bit, and the mode must have survived its own first-call check

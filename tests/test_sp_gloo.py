@@ -128,7 +128,7 @@ def _worker_packed_pipelined(rank, world, port, H, S, D, q, k, v, out_q):
 @pytest.mark.parametrize("world,H", [(2, 4), (4, 6), (8, 12), (3, 9)])
 def test_packed_pipelined_exchange_equals_single_process(world, H):
     """attention_packed_pipelined (round 4: two head chunks, both input exchanges issued up front, each chunk's output exchange issued behind its
-    attention; on the device the second chunk runs on a second HIP stream) == the plain packed exchange == the single-process result, on plain
+    attention) == the plain packed exchange == the single-process result, on plain
     Ulysses grids and on the 2-D grids (6 heads on 4 ranks: G2 x U2; 12 heads on 8: G4 x U2 with 3 heads per group -> chunks of 2 + 1)."""
     S, D = 77, 16
     g = torch.Generator().manual_seed(0)
