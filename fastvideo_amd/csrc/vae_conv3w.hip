@@ -40,7 +40,7 @@ using fvkc3::OOB;
 #define C3W_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 
 template <int WNW, int EPI>
-__global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int ntiles) {
+__global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int ntiles, int stagger) {
 #if defined(__HIP_DEVICE_COMPILE__)
     constexpr int TH = WNW == 1 ? 16 : 8, TW = 32;      // workgroup tile in pixels (4 waves x 4 rows, or 2 row groups x 2 channel halves)
     constexpr int TN = WNW * 96;                        // output channels per workgroup
@@ -91,6 +91,14 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
     };
     int cur_id = (int)blockIdx.x;
     Tile cur = decode(cur_id);
+    if (stagger > 0) {
+        // Phase stagger (persistent launches with many tiles per workgroup): all tiles take the same time, so the 256 workgroups would run in
+        // lockstep for the whole launch and hit their epilogues together — 25-50 MB of stores in a few microseconds, more than HBM takes, every
+        // tile.  Delaying workgroup b by ((b >> 3) & 15) sixteenths of a tile time ONCE spreads the bursts over the tile for the rest of the launch
+        // (b & 7 is the XCD: every XCD gets all sixteen phases).
+        const unsigned long long t0_ = __builtin_readcyclecounter(), wait_ = (unsigned long long)(((unsigned)blockIdx.x >> 3) & 15u) * (unsigned)stagger;
+        while (__builtin_readcyclecounter() - t0_ < wait_) __builtin_amdgcn_s_sleep(16);
+    }
 
     // ---- staging: piece q = wave + 4 i; lane -> LDS row 16 q + (lane >> 2), chunk POSITION lane & 3 = source chunk (lane & 3) ^ 2 ((row >> 2) & 1) ----
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -427,10 +435,14 @@ int launch3w(Conv3Args a, hipStream_t s) {
         n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
     long grid = nwg < n_cu ? nwg : n_cu;
+    int stagger = 0;
 #if FVK_VARIANTS
     if (fvk_vae_conv_tunable() == 4) grid = nwg;
+    // 5: phase stagger on (a sixteenth of an estimated tile time per phase unit: ~2 830 cycles per K-step + ~20 000 of prologue / epilogue),
+    // for launches that give every workgroup at least four tiles
+    if (fvk_vae_conv_tunable() == 5 && nwg >= 4 * grid) stagger = (a.KT * (a.Cin / 32) * 3 * 2830 + 20000) / 16;
 #endif
-    hipLaunchKernelGGL((vae_conv3w_kernel<WNW, EPI>), dim3((unsigned)grid), dim3(256), LDS, s, a, (int)nwg);
+    hipLaunchKernelGGL((vae_conv3w_kernel<WNW, EPI>), dim3((unsigned)grid), dim3(256), LDS, s, a, (int)nwg, stagger);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
