@@ -20,12 +20,10 @@
 //     taps are fragment reads of one staged slab at pixel offsets 0, 1, 2 (brute-forced over the ds_read_b128 lane groups of
 //     guides/MI355X_MICROARCH.md; the 8-wave kernel's swizzle (R >> 2) & 3 is 2-way conflicted in this shape).  Halo rows are pitched 40
 //     pixels (34 used) so that a row step (2560 B) leaves the swizzle bit alone;
-//   * the MFMA's A operand is the PIXEL fragment and B the weight fragment, and weight rows are staged in the order that makes weight row l15 of tile
-//     T the wave's channel 6 l15 + T: lane (l15, g) then holds six CONSECUTIVE output channels of four pixels, the sixteen lanes of a lane group a
-//     pixel's 192 contiguous bytes — the epilogue stores 12 B per lane straight from the accumulators, whole contiguous pixel rows per instruction
-//     (bias / residual / fused RMS-norm + SiLU in registers: the row sum of squares is a 6-term lane sum + four cross-lane adds) — no LDS staging
-//     passes (the 8-wave kernel's fused norm: three LDS passes over a wave-private tile).  (First version: weights as A — a lane held 8 consecutive
-//     channels of ONE pixel, 16-B stores 192 B apart across consecutive lanes: ~100 cycles per KiB stored.)
+//   * weight rows are staged in MFMA order (LDS row 16 T + i of a dw block = channel 32 (T >> 1) + 8 (i >> 2) + (i & 3) + 4 (T & 1)), which leaves lane
+//     (pixel l15, g) with EIGHT consecutive output channels per tile pair: the epilogue stores 16 B per lane straight from the accumulators
+//     (bias / residual / fused RMS-norm + SiLU in registers: the row sum of squares is a 24-term lane sum + two cross-lane adds) — no LDS
+//     staging passes (the 8-wave kernel's fused norm: three LDS passes over a wave-private tile).
 // ref: WanCausalConv3d.forward (fastvideo/models/vaes/wanvae.py:198-207), WanResidualBlock (:418-431, :462), WanRMS_norm (:231-232).
 #include "fvk_common.h"
 #include "vae_conv3_args.h"
@@ -38,8 +36,6 @@ using fvkc3::Conv3Args;
 using fvkc3::EPI_BIAS;
 using fvkc3::EPI_RESIDUAL;
 using fvkc3::OOB;
-
-struct __attribute__((aligned(4))) B12 { unsigned x, y, z; };   // six bf16 = one lane's share of a pixel (global_load / store_dwordx3)
 
 #define C3W_MFMA(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 
@@ -135,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
             const int q = wave + 4 * (j == WS - 1 ? w_last : j);
             const int dw = q / WT, tq = q - dw * WT;                 // tile tq of the dw block: wave half tq / 6, MFMA tile tq % 6
             const int t6 = tq % 6, i = lane >> 2;
-            const int n = n0 + 96 * (tq / 6) + 6 * i + t6;   // LDS row i of tile t6 = channel 6 i + t6 of the wave's 96 (see the header)
+            const int n = n0 + 96 * (tq / 6) + 32 * (t6 >> 1) + 8 * (i >> 2) + (i & 3) + 4 * (t6 & 1);   // MFMA row order (see the header)
             wvo_[j] = (live && n < a.Cout) ? (unsigned)((long)n * Ktot * 2) + (unsigned)(dw * a.Cin * 2) + chunk16 : OOB;
         }
     };
@@ -197,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) wv_[sl] = (unsigned)(W_BASE + sl * WSTEP + (wn * 6) * 1024 + l15 * 64 + ((qk ^ (2 * ((l15 >> 2) & 1))) << 4));
 
-    f32x4 acc[6][8];   // [weight tile T][pixel block pb = 2 r + h]: D[pixel 4 qk + e of block pb][weight row l15 of tile T = channel 6 l15 + T]
+    f32x4 acc[6][8];   // [weight tile T][pixel block pb = 2 r + h]: D[channel row 4 qk + e of tile T][pixel l15 of block pb]
     bf16x8 WF[3][6], XF[3][8];
 
     // ---- prologue (the workgroup's FIRST tile only): slab 0, weight steps 0 and 1 in flight ---------------------------------------------
@@ -221,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
     // 3k the k-th fragment of the group two ahead is read into set RB_; DMA_(k) fills issue slot k (after MFMA 3k + 1), 16 slots.
 #define C3W_GROUP(B_, RB_, XB_, WSLOT_, DH_, DW_, DMA_)                                                             \
     _Pragma("unroll") for (int i_ = 0; i_ < 48; ++i_) {                                                             \
-        C3W_MFMA(acc[i_ >> 3][i_ & 7], XF[B_][i_ & 7], WF[B_][i_ >> 3]);                                            \
+        C3W_MFMA(acc[i_ >> 3][i_ & 7], WF[B_][i_ >> 3], XF[B_][i_ & 7]);                                            \
         if (i_ % 3 == 0 && i_ / 3 < 14) C3W_READ(RB_, i_ / 3, XB_, WSLOT_, DH_, DW_)                                \
         if (i_ % 3 == 1) { DMA_(i_ / 3) }                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
@@ -294,57 +290,54 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
 #pragma unroll
         for (int pb = 0; pb < 8; ++pb) asm volatile("" : "+a"(acc[t][pb]));
 
-    // ---- epilogue, straight from the accumulators.  The MFMA's A operand is the PIXEL fragment and B the weight fragment, so lane (l15, qk) holds,
-    //      for the four pixels 4 qk + e of block pb, weight row l15 of every tile T — and weight row l15 of tile T is channel 6 l15 + T: SIX
-    //      CONSECUTIVE channels per lane, the sixteen lanes l15 = a pixel's 192 contiguous bytes.  Every store instruction therefore writes whole
-    //      contiguous pixel rows (12 B per lane, consecutive lanes consecutive bytes) instead of 64 scattered 16-B pieces (the transposed
-    //      assignment measured ~100 cycles per KiB stored: 9.5 k cycles of a 98 k-cycle tile, profiles/r04b_conv3w_tile_probe.log).
-    //      Rounding points as vae_conv3.hip: y = bf16(acc + bias); bf16(residual + y); norm on the bf16 values.
+    // ---- epilogue, straight from the accumulators: lane (l15, qk) holds, for pixel l15 of block pb, channels ncol0 + 32 P + 8 qk + 0..7
+    //      (tile 2P: + 0..3, tile 2P + 1: + 4..7).  Rounding points as vae_conv3.hip: y = bf16(acc + bias); bf16(residual + y); norm on the bf16 values.
     {
-    const int h0 = cur.h0, w0 = cur.w0, t_out = cur.t_out;
-    const int cl = cur.n0 + ncol0w + 6 * l15;   // this lane's first output channel
-    const bool cok = cl < a.Cout;               // (Cout is a multiple of 96: a lane's six channels are in or out together)
-    float bias6[6];
-    {
-        bf16_t bb[6];
-        if (a.bias && cok) *reinterpret_cast<B12*>(bb) = *reinterpret_cast<const B12*>(a.bias + cl);
+    const int ncol0 = cur.n0 + ncol0w, h0 = cur.h0, w0 = cur.w0, t_out = cur.t_out;
+    float bias8[3][8];
 #pragma unroll
-        for (int e = 0; e < 6; ++e) bias6[e] = (a.bias && cok) ? (float)bb[e] : 0.f;
+    for (int P = 0; P < 3; ++P) {
+        const int n = ncol0 + 32 * P + 8 * qk;
+        if (a.bias && n < a.Cout) {
+            const bf16x8 bv = ld_bf16x8(a.bias + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[P][e] = (float)bv[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[P][e] = 0.f;
+        }
     }
     const bool fused = a.norm_out != nullptr;
-    B12 yv[8][4];
-    float ss[8][4];
+    bf16x8 yv[8][3];
+    float ss[8];
 #pragma unroll
     for (int pb = 0; pb < 8; ++pb) {
-        const int h = h0 + 4 * wrow + (pb >> 1);
+        const int h = h0 + 4 * wrow + (pb >> 1), w = w0 + 16 * (pb & 1) + l15;
+        const bool inside = h < a.H && w < a.W;
+        const long hw = (long)h * a.W + w;
+        float sq = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int w = w0 + 16 * (pb & 1) + 4 * qk + e;
-            const bool inside = h < a.H && w < a.W && cok;
-            const long hw = (long)h * a.W + w;
-            bf16_t y[6];
+        for (int P = 0; P < 3; ++P) {
+            const int n = ncol0 + 32 * P + 8 * qk;
+            bf16x8 y;
 #pragma unroll
-            for (int T = 0; T < 6; ++T) y[T] = (bf16_t)(acc[T][pb][e] + bias6[T]);
-            if (inside) {
+            for (int e = 0; e < 8; ++e) y[e] = (bf16_t)((e < 4 ? acc[2 * P][pb][e] : acc[2 * P + 1][pb][e - 4]) + bias8[P][e]);
+            if (inside && n < a.Cout) {
                 if (EPI == EPI_RESIDUAL) {
-                    bf16_t res[6];
-                    *reinterpret_cast<B12*>(res) = *reinterpret_cast<const B12*>(a.residual + (long)t_out * a.res_fs + hw * a.Cout + cl);
+                    const bf16x8 res = ld_bf16x8(a.residual + (long)t_out * a.res_fs + hw * a.Cout + n);
 #pragma unroll
-                    for (int T = 0; T < 6; ++T) y[T] = (bf16_t)((float)res[T] + (float)y[T]);
+                    for (int e = 0; e < 8; ++e) y[e] = (bf16_t)((float)res[e] + (float)y[e]);
                 }
-                if (!fused || a.write_raw) *reinterpret_cast<B12*>(a.out + (long)t_out * a.out_fs + hw * a.Cout + cl) = *reinterpret_cast<const B12*>(y);
+                if (!fused || a.write_raw) st_bf16x8(a.out + (long)t_out * a.out_fs + hw * a.Cout + n, y);
             }
-            yv[pb][e] = *reinterpret_cast<const B12*>(y);
-            float sq = 0.f;
+            yv[pb][P] = y;
 #pragma unroll
-            for (int T = 0; T < 6; ++T) sq += (float)y[T] * (float)y[T];
-            // the pixel's 96 channels of this wave live in the sixteen lanes of its lane group
-            sq += __shfl_xor(sq, 1, 64);
-            sq += __shfl_xor(sq, 2, 64);
-            sq += __shfl_xor(sq, 4, 64);
-            sq += __shfl_xor(sq, 8, 64);
-            ss[pb][e] = sq;
+            for (int e = 0; e < 8; ++e) sq += (float)y[e] * (float)y[e];
         }
+        // the pixel's 96 channels of this wave live in the four lanes l15 + 16 g
+        sq += __shfl_xor(sq, 16, 64);
+        sq += __shfl_xor(sq, 32, 64);
+        ss[pb] = sq;
     }
 #if FVK_VARIANTS
     if (first && EPI == EPI_BIAS && a.out_f32) {
@@ -361,46 +354,46 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
         // the partner wave (same pixels, the other 96 channels) = wave ^ 1: swap partial sums through 2 KiB of LDS of their own (the slab and
         // weight regions already hold the next tile's first pieces).  norm_out is a kernel argument, so all four waves reach the barriers.
         float* xch = reinterpret_cast<float*>(smem + XCH);
-        if (l15 == 0) {
+        if (qk == 0) {
 #pragma unroll
-            for (int pb = 0; pb < 8; ++pb)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xch[((wave * 8 + pb) * 4 + e) * 4 + qk] = ss[pb][e];
+            for (int pb = 0; pb < 8; ++pb) xch[(wave * 8 + pb) * 16 + l15] = ss[pb];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the writes have left this wave before the barrier
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int pb = 0; pb < 8; ++pb)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ss[pb][e] += xch[(((wave ^ 1) * 8 + pb) * 4 + e) * 4 + qk];
+        for (int pb = 0; pb < 8; ++pb) ss[pb] += xch[((wave ^ 1) * 8 + pb) * 16 + l15];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // (the next tile's epilogue writes the same words)
     }
     int slot = a.norm_slot0 + t_out;
     slot = slot >= a.norm_ring ? slot - a.norm_ring : slot;
     slot = slot >= a.norm_ring ? slot - a.norm_ring : slot;
-    float gam[6];
+    float gam[3][8];
 #pragma unroll
-    for (int T = 0; T < 6; ++T) gam[T] = a.norm_gamma[ncol0w + 6 * l15 + T];
+    for (int P = 0; P < 3; ++P) {
+        const float* gp = a.norm_gamma + ncol0w + 32 * P + 8 * qk;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gam[P][e] = g0[e]; gam[P][4 + e] = g1[e]; }
+    }
     const float sqrtC = sqrtf((float)a.Cout);
 #pragma unroll
     for (int pb = 0; pb < 8; ++pb) {
-        const int h = h0 + 4 * wrow + (pb >> 1);
+        const int h = h0 + 4 * wrow + (pb >> 1), w = w0 + 16 * (pb & 1) + l15;
+        if (h < a.H && w < a.W) {
+            const float inv = sqrtC / fmaxf(sqrtf(ss[pb]), 1e-12f);
+            const long base = ((long)slot * HW + (long)h * a.W + w) * a.Cout + ncol0w + 8 * qk;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int w = w0 + 16 * (pb & 1) + 4 * qk + e;
-            if (h < a.H && w < a.W) {
-                const float inv = sqrtC / fmaxf(sqrtf(ss[pb][e]), 1e-12f);
-                bf16_t yy[6], o[6];
-                *reinterpret_cast<B12*>(yy) = yv[pb][e];
+            for (int P = 0; P < 3; ++P) {
+                bf16x8 o;
 #pragma unroll
-                for (int T = 0; T < 6; ++T) {
-                    float r_ = (float)yy[T] * inv * gam[T];
+                for (int e = 0; e < 8; ++e) {
+                    float r_ = (float)yv[pb][P][e] * inv * gam[P][e];
                     // x * sigmoid(x) with the hardware reciprocal (1 ulp; the result is rounded to bf16), as vae_conv3.hip / vae_norm12_kernel
                     if (a.norm_silu) r_ = r_ * __builtin_amdgcn_rcpf(1.0f + __expf(-r_));
-                    o[T] = (bf16_t)r_;
+                    o[e] = (bf16_t)r_;
                 }
-                *reinterpret_cast<B12*>(a.norm_out + ((long)slot * HW + (long)h * a.W + w) * a.Cout + ncol0w + 6 * l15) = *reinterpret_cast<const B12*>(o);
+                st_bf16x8(a.norm_out + base + 32 * P, o);
             }
         }
     }
