@@ -50,6 +50,8 @@ SIGNATURES = {
     "fvk_attn_dense_kernel_bf16": [C.POINTER(AttnArgs), i32, vp],
     "fvk_attn_dense_split_bf16": [C.POINTER(AttnArgs), i32, vp, vp, vp],
     "fvk_attn_block_sparse_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp],
+    "fvk_vsa_union_lists": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
+    "fvk_attn_block_sparse_union_bf16": [C.POINTER(AttnArgs), vp, vp, i32, vp],
     "fvk_attn_tile_lists_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp, vp, vp],
     "fvk_attn_sta_bf16": [C.POINTER(AttnArgs), i32, i32, i32, i32, C.POINTER(C.c_int32), vp],
     "fvk_vsa_build_metadata_host": [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp],

@@ -88,7 +88,14 @@ template <int DK> struct KGeom {
 // is free, and copies it into the stage with ds_write_b128 (data long arrived: ~300 cycles per tile) right after the barrier that frees
 // it.  Same LDS image, same one barrier per tile, compute waves untouched; loads are retired with counted vmcnt (tiles past the end of a
 // list re-read its last tile so that the counts stay constant).
-template <int NW, int MODE, int DK, int NL, int PAIRS = 1, bool RSTG = false>
+// UNION (round 4; PAIRS = 2 block-sparse lists): the workgroup's two 64-row query blocks walk ONE list — the ascending union of their two KV lists,
+// every entry tagged with the halves that selected it (fvk_vsa_union_lists) — over ONE ring of FOUR stages filled by all four loader waves
+// three tiles ahead.  A tile both blocks selected is fetched once instead of twice; a half that did not select a tile skips its MFMAs and its
+// softmax for that step (wave-uniform) and only meets the barrier.  Each half still sees exactly its own tiles in ascending order, so the
+// output is bit-identical to the two-list form.  Why: the kernel sits on the L2 -> LDS ingest rate of its access pattern — its
+// time follows the bytes it fetches — and consecutive query blocks of the tile-major order select 61-66 % common blocks from the second
+// layer on, on a randn latent through random-init weights and on a smooth latent alike (profiles/r04g_vsa_union_overlap.log): 30 % fewer bytes.
+template <int NW, int MODE, int DK, int NL, int PAIRS = 1, bool RSTG = false, bool UNION = false>
 __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1 : 2)) void attn_fwd_kernel(fvk_attn_args a, ModeArgs ma) {
 #if defined(__HIP_DEVICE_COMPILE__)  // device pass only: the body uses gfx950 LDS-DMA builtins the host pass cannot parse
     constexpr int K_ROW_BYTES = KGeom<DK>::ROW_BYTES, KC = KGeom<DK>::CHUNKS, K_TILE_BYTES = KGeom<DK>::TILE_BYTES;
@@ -102,6 +109,7 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (scalar branches, SGPR M0 base)
     const int l31 = lane & 31, hi = lane >> 5;
     static_assert(PAIRS == 1 || (MODE == MODE_BLOCKS && NL > 0), "query-block pairs: block-sparse lists with loader waves only");
+    static_assert(!UNION || (PAIRS == 2 && MODE == MODE_BLOCKS && NL > 0 && !RSTG), "the union walk is a form of the two-list workgroup");
     constexpr int NCW = PAIRS * NW;  // compute waves come first, loader waves after
     const bool compute = wave < NCW;                                 // this wave owns 32 query rows
     const int pr = PAIRS == 1 ? 0 : (compute ? wave / NW : (wave - NCW) / (NL ? NL : 1));  // which query block of the workgroup
@@ -128,14 +136,21 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
     if (MODE == MODE_DENSE) {
         n_tiles = (a.Skv + 63) >> 6;
     } else if (MODE == MODE_BLOCKS) {
-        const long meta = ((long)b * a.H + h) * nqb + (pair_ok ? qb : 0);
-        n_tiles = pair_ok ? ma.q2k_num[meta] : 0;
-        if (ma.q_rows_valid && pair_ok && ma.q_offset >= ma.q_rows_valid[qb]) n_tiles = 0;  // only padding rows
+        const long meta = UNION ? ((long)b * a.H + h) * nwg + (blockIdx.x % nwg) : ((long)b * a.H + h) * nqb + (pair_ok ? qb : 0);
+        n_tiles = (UNION || pair_ok) ? ma.q2k_num[meta] : 0;
+        if (!UNION && ma.q_rows_valid && pair_ok && ma.q_offset >= ma.q_rows_valid[qb]) n_tiles = 0;  // only padding rows
         blk_list = ma.q2k_idx + meta * ma.max_kv;
+        if (UNION) {
+            // the merged list (entries packed by fvk_vsa_union_lists: block id | valid keys << 22 | halves << 29) — one copy for the workgroup
+            n_tiles = n_tiles < PAIRS * LIST_CAP ? n_tiles : PAIRS * LIST_CAP;
+            for (int i = tid; i < n_tiles; i += PAIRS * (NW + NL) * 64) lds_lists[i] = blk_list[i];
+            __syncthreads();
+        } else
         // The KV lists live in LDS for the whole kernel: entry = block id | (valid keys << 24).  Read from global memory inside the
         // tile loop, `id = blk_list[j+1]` is a vector load every wave must WAIT for (vmcnt(0): a full L2 round trip, 500+ cycles under
         // load) before the tile's DMA can even be issued — every iteration, on compute and loader waves alike; `kv_block_sizes[id]` is
         // a second, dependent round trip.  One cooperative fill here, then a ~100-cycle uniform ds_read per tile.
+        {
         for (int p = 0; p < PAIRS; ++p) {
             const int qb_p = (blockIdx.x % nwg) * PAIRS + p;
             if (qb_p < nqb) {
@@ -150,6 +165,7 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
             }
         }
         __syncthreads();  // the first get_tile() below reads entries other threads wrote
+        }
     } else {
         const int qt = (qb * BMQ) / ma.tile_tokens;
         const int qt_t = qt / (ma.ch * ma.cw), qt_h = (qt / ma.cw) % ma.ch, qt_w = qt % ma.cw;
@@ -178,6 +194,10 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
             kv0 = j << 6;
             const int rem = a.Skv - kv0;
             valid = rem < 64 ? rem : 64;
+        } else if (MODE == MODE_BLOCKS && UNION) {
+            const int e = lds_lists[j];
+            kv0 = (e & 0x3fffff) << 6;
+            valid = ((e >> 22) & 0x7f) | (((e >> 29) & 3) << 8);   // bits 8-9: the halves that selected the tile
         } else if (MODE == MODE_BLOCKS) {
             if (j < LIST_CAP) {
                 const int e = lds_lists[pr * LIST_CAP + j];
@@ -217,10 +237,10 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
     const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void*)kp, 0, (int)((((long)a.Skv - 1) * a.k_ss + DK) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vtp, 0, (int)(256L * a.Skv_pad), 0x00020000);
-    constexpr int NI = NL ? NL : NW;                // waves that issue DMA
+    constexpr int NI = UNION ? PAIRS * NL : (NL ? NL : NW);  // waves that issue the DMA of ONE tile (UNION: all four loader waves)
     constexpr int N_DMA = (KC + 18 + NI - 1) / NI;  // wave-instructions per issuing wave per tile
     const bool loader = NL ? wave >= NCW : true;    // this wave issues DMA
-    const int iw = NL ? (wave - NCW) % NL : wave;   // index among the pair's issuing waves
+    const int iw = UNION ? wave - NCW : (NL ? (wave - NCW) % NL : wave);   // index among the tile's issuing waves
     int dma_voff[N_DMA];
 #pragma unroll
     for (int i = 0; i < N_DMA; ++i) {
@@ -265,7 +285,7 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
     }
 
     int n_loop = n_tiles;  // the workgroup's barrier count: the longer of the two lists
-    if (PAIRS == 2 && MODE == MODE_BLOCKS) {
+    if (PAIRS == 2 && MODE == MODE_BLOCKS && !UNION) {
         const int qo = qb ^ 1;
         const int n_other = qo < nqb ? ma.q2k_num[((long)b * a.H + h) * nqb + qo] : 0;
         n_loop = n_other > n_loop ? n_other : n_loop;
@@ -329,21 +349,62 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
 #undef RS_BARRIER
     }
     int kv0 = 0, valid = 64, kv0_n = 0, valid_n = 64;
+    // UNION: tile t lives in stage t & 3 of ONE four-stage ring (the two lists' double buffers are the same 4 x 35 KiB); the four loader waves
+    // issue tile j + 3 at the top of step j (its stage was read in step j - 1) and retire tile j + 1 — everything but their two youngest tiles —
+    // before the barrier that ends the step.  Tiles past the end are issued with out-of-range offsets (zero fill, no traffic) so that the
+    // counted waits stay constant.
+#define UNION_ISSUE(T)                                                                                       \
+    {                                                                                                        \
+        const bool live_ = (T) < n_tiles;                                                                    \
+        int k0_ = 0, v_;                                                                                     \
+        get_tile(live_ ? (T) : 0, k0_, v_);                                                                  \
+        unsigned char* st_ = smem + ((T) & 3) * STAGE_BYTES;                                                 \
+        const int ks_ = __builtin_amdgcn_readfirstlane(k0_ * k_tile_stride);                                 \
+        const int vs_ = __builtin_amdgcn_readfirstlane(k0_ * 2);                                             \
+        _Pragma("unroll") for (int i = 0; i < N_DMA; ++i) {                                                  \
+            const int t_ = i * NI + iw;                                                                      \
+            const int vo_ = live_ ? dma_voff[i] : (int)0x7fffff00;                                           \
+            if (t_ < KC) {                                                                                   \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(st_ + t_ * 1024), 16, vo_, ks_, 0, 0); \
+            } else if (t_ < KC + 18) {  /* (the last issuing wave has one piece fewer: UNION_WAIT counts it) */    \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(st_ + t_ * 1024), 16, vo_, vs_, 0, 0); \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+    // a loader wave's pieces per tile: N_DMA, or one fewer for the waves past the remainder (35 pieces over 4 waves: 9, 9, 9, 8)
+    const bool full_share = (N_DMA - 1) * NI + iw < KC + 18;
+#define UNION_WAIT() { if (full_share) wait_vm_n<2 * N_DMA>(); else wait_vm_n<2 * (N_DMA - 1)>(); }  /* all but this wave's two youngest tiles */
+    if (UNION) {
+        if (n_tiles > 0 && loader) {
+            UNION_ISSUE(0) UNION_ISSUE(1) UNION_ISSUE(2)
+            UNION_WAIT()  // tile 0 landed
+        }
+        __builtin_amdgcn_s_barrier();
+    } else {
     if (n_tiles > 0) {
         get_tile(0, kv0, valid);
         if (loader && !RSTG) ISSUE_DMA(kv0, smem_p)
     }
     __syncthreads();
+    }
 
     for (int j = 0; j < n_loop; ++j) {
-        const unsigned char* cur = smem_p + (j & 1) * STAGE_BYTES;
+        const unsigned char* cur = UNION ? smem + (j & 3) * STAGE_BYTES : smem_p + (j & 1) * STAGE_BYTES;
         const bool more = (j + 1) < n_tiles;
-        if (more) {
+        bool mine = true;
+        if (UNION) {
+            if (loader) UNION_ISSUE(j + 3)
+            else {
+                get_tile(j, kv0, valid);
+                mine = (valid >> (8 + pr)) & 1;
+                valid &= 0xff;
+            }
+        } else if (more) {
             get_tile(j + 1, kv0_n, valid_n);
             unsigned char* nxt = smem_p + ((j + 1) & 1) * STAGE_BYTES;
             if (loader && !RSTG) ISSUE_DMA(kv0_n, nxt)
         }
-        if (compute && j < n_tiles) {
+        if (compute && j < n_tiles && mine) {
         // ---- S^T = K · Q^T  (2 key blocks of 32 x KS k-steps of 16): one software-pipelined stream, every ds_read_b128 issued FD MFMAs
         // ahead of its use (sched_group_barrier pins the 1 MFMA : 1 read interleave; left alone hipcc emits read / wait / MFMA and
         // every MFMA eats an LDS round trip) --------------------------------------------------------------------------------------
@@ -436,12 +497,19 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
         }
         __builtin_amdgcn_s_setprio(0);
         }  // compute
+        if (UNION) {
+            if (loader) UNION_WAIT()  // tile j + 1 landed (its two successors may still fly)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
         if (more) {
             kv0 = kv0_n;
             valid = valid_n;
         }
         __syncthreads();
+        }
     }
+    if (UNION && loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the zero-fill tail pieces
     if (!compute) return;
 
     // ---- epilogue ---------------------------------------------------------------------------------------
@@ -489,17 +557,17 @@ int check_common(const fvk_attn_args* a, const char* fn) {
     return FVK_OK;
 }
 
-template <int NW, int MODE, int DK = 128, int NL = 0, int PAIRS = 1, bool RSTG = false>
+template <int NW, int MODE, int DK = 128, int NL = 0, int PAIRS = 1, bool RSTG = false, bool UNION = false>
 int launch(const fvk_attn_args* a, const ModeArgs& ma, hipStream_t s) {
     constexpr int STAGE_BYTES = KGeom<DK>::STAGE_BYTES;
     constexpr int LDS = PAIRS * 2 * STAGE_BYTES + (MODE == MODE_BLOCKS ? PAIRS * 2048 * 4 : 0);  // + the KV lists (LIST_CAP entries each)
     static_assert(LDS <= 163840, "LDS budget");
     static FvkLdsConfigured configured;
-    if (int rc = fvk_config_lds(configured, (const void*)attn_fwd_kernel<NW, MODE, DK, NL, PAIRS, RSTG>, LDS, "fvk_attn")) return rc;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_fwd_kernel<NW, MODE, DK, NL, PAIRS, RSTG, UNION>, LDS, "fvk_attn")) return rc;
     const int bmq = NW * 32;
     const long nlists = (MODE == MODE_BLOCKS && ma.q_stride) ? ma.n_lists : (a->Sq + bmq - 1) / bmq;
     const long nblk = ((nlists + PAIRS - 1) / PAIRS) * a->H * a->B;
-    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE, DK, NL, PAIRS, RSTG>), dim3((unsigned)nblk), dim3(PAIRS * (NW + NL) * 64), LDS, s, *a, ma);
+    hipLaunchKernelGGL((attn_fwd_kernel<NW, MODE, DK, NL, PAIRS, RSTG, UNION>), dim3((unsigned)nblk), dim3(PAIRS * (NW + NL) * 64), LDS, s, *a, ma);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -602,6 +670,22 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     if (impl == 54 && max_kv <= 2048) return fvk_attn_vsa_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, (hipStream_t)stream);
 #endif
     return launch<2, MODE_BLOCKS, 128, 2, 2>(a, ma, (hipStream_t)stream);
+}
+
+extern "C" int fvk_attn_block_sparse_union_bf16(const fvk_attn_args* a, const int32_t* u_idx, const int32_t* u_num, int max_u, void* stream) {
+    int rc = check_common(a, "fvk_attn_block_sparse_union_bf16");
+    if (rc) return rc;
+    FVK_CHECK(u_idx && u_num && max_u > 0 && max_u <= 4096, FVK_ERR_ARG,
+              "fvk_attn_block_sparse_union_bf16: null lists / max_u=%d (1..4096 entries per merged list: the workgroup keeps it in LDS)", max_u);
+    FVK_CHECK(a->Sq % 64 == 0 && a->Skv % 64 == 0 && (long)a->Skv / 64 < (1L << 22), FVK_ERR_ARG,
+              "fvk_attn_block_sparse_union_bf16: Sq=%d and Skv=%d must be whole 64-token blocks", a->Sq, a->Skv);
+    FVK_CHECK(a->qk_dim == 0 || a->qk_dim == 128, FVK_ERR_ARG, "fvk_attn_block_sparse_union_bf16: qk_dim=%d unsupported", a->qk_dim);
+    ModeArgs ma{};
+    ma.q2k_idx = u_idx;
+    ma.q2k_num = u_num;
+    ma.kv_block_sizes = nullptr;   // (the valid-key counts travel inside the merged entries)
+    ma.max_kv = max_u;
+    return launch<2, MODE_BLOCKS, 128, 2, 2, false, true>(a, ma, (hipStream_t)stream);
 }
 
 extern "C" int fvk_attn_tile_lists_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,

@@ -501,9 +501,9 @@ int fvk_vae_conv3_launch(const void* in, const void* w, const void* bias, void* 
     a.out_fs = out_fs; a.res_fs = res_fs; a.plane_stride = plane_stride;
     a.T = T; a.H = H; a.W = W; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KT = KT; a.ring = ring; a.ring_start = ring_start;
     if (epilogue == EPI_FINAL && !ups && Cout <= 32) return launch3<1, EPI_FINAL, false, 1>(a, s);  // conv_out: one 32-channel block per wave
-    // non-upsampling bf16-output convs: the one-wave-per-SIMD kernel on 16x16x32 MFMAs (vae_conv3w.hip, round 4); "vae_conv_impl" 3 (measurement
+    // bf16-output convs (upsampling or not): the one-wave-per-SIMD kernel on 16x16x32 MFMAs (vae_conv3w.hip, round 4); "vae_conv_impl" 3 (measurement
     // build) keeps this file's 8-wave kernel for A/B and the <= 1-ulp comparison tests
-    if (!ups && (!FVK_VARIANTS || fvk_vae_conv_tunable() != 3)) {
+    if (!FVK_VARIANTS || fvk_vae_conv_tunable() != 3) {
         int rc = FVK_OK;
         if (fvk_vae_conv3w_launch(a, epilogue, s, &rc)) return rc;
     }

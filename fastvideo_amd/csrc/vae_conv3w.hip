@@ -1,6 +1,7 @@
-// 3x3-spatial causal convolution of the Wan VAE decoder, "one wave per SIMD" form (round 4) — the shipped kernel for every non-upsampling
-// 3x3x3 / 1x3x3 conv with a bf16 output (96 -> 96 at full resolution, 192 -> 192, 384 -> 384: 83 % of a decode's conv time); the 2x-upsampling
-// convs and conv_out stay on vae_conv3.hip.  Same contract, layouts, rounding points and epilogues as vae_conv3.hip (fvk_vae_conv_bf16 /
+// 3x3-spatial causal convolution of the Wan VAE decoder, "one wave per SIMD" form (round 4) — the shipped kernel for every 3x3x3 / 1x3x3 conv
+// with a bf16 output (96 -> 96 at full resolution, 192 -> 192, 384 -> 384, and the 2x-upsampling resample convs 384 -> 192, 192 -> 96, whose
+// nearest-exact upsample is folded into the slab staging: 92 % of a decode's conv time); conv_out (3 channels, fp32 planar) and the measurement
+// build's A/B kernels stay in vae_conv3.hip.  Same contract, layouts, rounding points and epilogues as vae_conv3.hip (fvk_vae_conv_bf16 /
 // fvk_vae_conv_norm_bf16); the MFMA shape differs, so the two agree to rounding (fp32 summation order inside an instruction), not byte for byte.
 //
 // Why (profiles/r02_vae_conv_pmc.md): the 8-wave kernel runs at an effective 1.52 GHz with the matrix pipe 60 % busy — power-bound,
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
     const bool x_dup = wave + 4 * (XS - 1) >= XPIECES, w_dup = wave + 4 * (WS - 1) >= WPIECES;   // wave-uniform
     const int x_last = x_dup ? XS - 2 : XS - 1, w_last = w_dup ? WS - 2 : WS - 1;                // slot whose destination the last slot writes
     unsigned xvo_[XS];
+    const int ups = a.Hin != a.H ? 1 : 0;   // (launcher: H == 2 Hin and W == 2 Win, or equal)
     auto set_xvo = [&](const Tile& t, bool live) {
         const int hb = t.h0 - 1, wb = t.w0 - 1;  // input coordinates of slab pixel (0, 0)
 #pragma unroll
@@ -120,8 +122,10 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
             const int p = (wave + 4 * (i == XS - 1 ? x_last : i)) * 16 + (lane >> 2);
             const int hh = p / WW, ww = p - hh * WW;
             const int h = hb + hh, w = wb + ww;
-            const bool ok = live && hh < HH && ww < WWV && (unsigned)h < (unsigned)a.Hin && (unsigned)w < (unsigned)a.Win;
-            xvo_[i] = ok ? (unsigned)((h * a.Win + w) * CinB) + chunk16 : OOB;
+            const bool ok = live && hh < HH && ww < WWV && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            // the 2x nearest-exact upsample of the decoder's resample convs (ref: WanUpsample, wanvae.py:245-250) folded into the staging: slab pixel
+            // (h, w) of the upsampled frame is input pixel (h >> 1, w >> 1) — the slab holds upsampled pixels, the kernel below does not know
+            xvo_[i] = ok ? (unsigned)((((h >> ups) * a.Win + (w >> ups)) * CinB)) + chunk16 : OOB;
         }
     };
     unsigned wvo_[WS];   // weight pieces: they depend on the tile's n-tile only; the piece's dw tap offset is folded in
@@ -283,6 +287,35 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
     // the trailing fragment reads (the next tile's first groups — re-read below once the epilogue has released its registers) have retired
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (first) { C3W_STAMP(2) }
+    // Residual epilogue: ALL 24 of the lane's 16-B residual vectors are requested here, in one batch, before anything is stored (96 registers:
+    // the fragment sets are dead).  Interleaved with the stores (load, add, store per vector — the first form of this epilogue) every load's
+    // wait is a vmcnt(0) that also waits for the store before it to be acknowledged: 24 serialised memory round trips, ~12 us of a ~60-us
+    // tile at 96 channels (rocprof: 3.25 vs 2.63 ms per launch).  Pixels outside the image read the tile's first pixel instead (never used).
+    // (bias first: its first use then waits for three loads, not for the residual batch behind them)
+    float bias8[3][8];
+#pragma unroll
+    for (int P = 0; P < 3; ++P) {
+        const int n = cur.n0 + ncol0w + 32 * P + 8 * qk;
+        if (a.bias && n < a.Cout) {
+            const bf16x8 bv = ld_bf16x8(a.bias + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[P][e] = (float)bv[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) bias8[P][e] = 0.f;
+        }
+    }
+    bf16x8 resv[8][3];
+    if (EPI == EPI_RESIDUAL) {
+#pragma unroll
+        for (int pb = 0; pb < 8; ++pb) {
+            const int h = cur.h0 + 4 * wrow + (pb >> 1), w = cur.w0 + 16 * (pb & 1) + l15;
+            const long hw = (h < a.H && w < a.W) ? (long)h * a.W + w : (long)cur.h0 * a.W + cur.w0;
+            const bf16_t* rp = a.residual + (long)cur.t_out * a.res_fs + hw * a.Cout + cur.n0 + ncol0w + 8 * qk;
+#pragma unroll
+            for (int P = 0; P < 3; ++P) resv[pb][P] = ld_bf16x8(rp + 32 * P);
+        }
+    }
     // the accumulators were written by asm MFMAs: the compiler knows no hazard distance to its own reads of them
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 #pragma unroll
@@ -294,19 +327,6 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
     //      (tile 2P: + 0..3, tile 2P + 1: + 4..7).  Rounding points as vae_conv3.hip: y = bf16(acc + bias); bf16(residual + y); norm on the bf16 values.
     {
     const int ncol0 = cur.n0 + ncol0w, h0 = cur.h0, w0 = cur.w0, t_out = cur.t_out;
-    float bias8[3][8];
-#pragma unroll
-    for (int P = 0; P < 3; ++P) {
-        const int n = ncol0 + 32 * P + 8 * qk;
-        if (a.bias && n < a.Cout) {
-            const bf16x8 bv = ld_bf16x8(a.bias + n);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[P][e] = (float)bv[e];
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) bias8[P][e] = 0.f;
-        }
-    }
     const bool fused = a.norm_out != nullptr;
     bf16x8 yv[8][3];
     float ss[8];
@@ -322,14 +342,11 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
             bf16x8 y;
 #pragma unroll
             for (int e = 0; e < 8; ++e) y[e] = (bf16_t)((e < 4 ? acc[2 * P][pb][e] : acc[2 * P + 1][pb][e - 4]) + bias8[P][e]);
-            if (inside && n < a.Cout) {
-                if (EPI == EPI_RESIDUAL) {
-                    const bf16x8 res = ld_bf16x8(a.residual + (long)t_out * a.res_fs + hw * a.Cout + n);
+            if (EPI == EPI_RESIDUAL) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) y[e] = (bf16_t)((float)res[e] + (float)y[e]);
-                }
-                if (!fused || a.write_raw) st_bf16x8(a.out + (long)t_out * a.out_fs + hw * a.Cout + n, y);
+                for (int e = 0; e < 8; ++e) y[e] = (bf16_t)((float)resv[pb][P][e] + (float)y[e]);
             }
+            if (inside && (!fused || a.write_raw)) st_bf16x8(a.out + (long)t_out * a.out_fs + hw * a.Cout + n, y);   // (n < Cout: whole wave tiles only)
             yv[pb][P] = y;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sq += (float)y[e] * (float)y[e];
@@ -450,10 +467,11 @@ int launch3w(Conv3Args a, hipStream_t s) {
 }  // namespace
 
 bool fvk_vae_conv3w_launch(Conv3Args a, int epilogue, hipStream_t s, int* rc) {
-    // bf16-output, non-upsampling convs whose channel count is a whole number of 96-channel wave tiles (every 3x3 conv of the Wan decoder but
-    // conv_in's 16 -> 384 ... which has Cout = 384, served; conv_out (Cout = 3, fp32 planar output) and the upsampling convs are not)
+    // bf16-output convs whose channel count is a whole number of 96-channel wave tiles, the 2x-upsampling resample convs included (every 3x3
+    // conv of the Wan decoder but conv_out: Cout = 3, fp32 planar output)
     if (epilogue != EPI_BIAS && epilogue != EPI_RESIDUAL) return false;
-    if (a.Cout % 96 != 0 || a.Hin != a.H || a.Win != a.W) return false;
+    const bool same = a.Hin == a.H && a.Win == a.W, ups2 = a.H == 2 * a.Hin && a.W == 2 * a.Win;
+    if (a.Cout % 96 != 0 || !(same || ups2)) return false;
     if (a.norm_out && a.Cout != 96 && a.Cout != 192) return false;
     const bool wide = a.Cout % 192 == 0;
     if (wide) *rc = epilogue == EPI_BIAS ? launch3w<2, EPI_BIAS>(a, s) : launch3w<2, EPI_RESIDUAL>(a, s);

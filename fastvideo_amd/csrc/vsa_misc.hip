@@ -463,6 +463,48 @@ extern "C" int fvk_map_to_index(const uint8_t* mask, int32_t* idx, int32_t* num,
     return FVK_OK;
 }
 
+// Union of the KV lists of two neighbouring query blocks (fvk_attn_block_sparse_union_bf16): one thread per (batch * head, pair) merges the two
+// ASCENDING lists of blocks 2p and 2p + 1 (fvk_map_to_index's order) into one ascending list of packed entries
+//     block id | valid keys (kv_block_sizes[id]) << 22 | halves << 29        (halves: bit 0 = block 2p selected it, bit 1 = block 2p + 1)
+// A missing second block (odd block count) contributes nothing.  Integer work: bit-exact against a host merge (tests/test_gpu_kernels.py).
+__global__ __launch_bounds__(256) void vsa_union_lists_kernel(const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int32_t* u_idx,
+                                                              int32_t* u_num, long rows, int nq, int max_kv) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const int npair = (nq + 1) / 2;
+    if (t >= rows * npair) return;
+    const long bh = t / npair;
+    const int p = (int)(t - bh * npair);
+    const int qa = 2 * p, qb = 2 * p + 1;
+    const int32_t* la = q2k_idx + (bh * nq + qa) * max_kv;
+    const int32_t* lb = q2k_idx + (bh * nq + (qb < nq ? qb : qa)) * max_kv;
+    int na = q2k_num[bh * nq + qa], nb = qb < nq ? q2k_num[bh * nq + qb] : 0;
+    na = na < max_kv ? na : max_kv;
+    nb = nb < max_kv ? nb : max_kv;
+    int32_t* out = u_idx + t * (2L * max_kv);
+    int i = 0, j = 0, n = 0;
+    while (i < na || j < nb) {
+        const int a_ = i < na ? la[i] : 0x7fffffff, b_ = j < nb ? lb[j] : 0x7fffffff;
+        const int id = a_ < b_ ? a_ : b_;
+        const int halves = (a_ == id ? 1 : 0) | (b_ == id ? 2 : 0);
+        i += a_ == id;
+        j += b_ == id;
+        out[n++] = id | (kv_block_sizes[id] << 22) | (halves << 29);
+    }
+    u_num[t] = n;
+}
+
+extern "C" int fvk_vsa_union_lists(const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int32_t* u_idx, int32_t* u_num,
+                                   int rows, int nq, int max_kv, void* stream) {
+    FVK_CHECK(q2k_idx && q2k_num && kv_block_sizes && u_idx && u_num, FVK_ERR_ARG, "fvk_vsa_union_lists: null pointer");
+    FVK_CHECK(nq > 0 && max_kv > 0 && max_kv <= 2048, FVK_ERR_ARG, "fvk_vsa_union_lists: nq=%d max_kv=%d (1..2048: a merged list has at most 4096 entries)", nq, max_kv);
+    if (rows <= 0) return FVK_OK;
+    const long threads = (long)rows * ((nq + 1) / 2);
+    hipLaunchKernelGGL(vsa_union_lists_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, q2k_idx, q2k_num,
+                       kv_block_sizes, u_idx, u_num, (long)rows, nq, max_kv);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
 extern "C" int fvk_softmax_rows_bf16(const void* in, void* out, int rows, int n, void* stream) {
     FVK_CHECK(in && out && n > 0, FVK_ERR_ARG, "fvk_softmax_rows_bf16: null pointer / n");
     if (rows <= 0) return FVK_OK;

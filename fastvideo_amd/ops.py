@@ -433,7 +433,12 @@ def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, retur
     return (o, lse) if return_lse else o
 
 
-def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, layout="bhsd", return_lse=False, q_block=64):
+def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, layout="bhsd", return_lse=False, q_block=64, pair_union=False):
+    """q2k_idx int32 [B,H,nq,max_kv] ascending block lists, q2k_num [B,H,nq], kv_block_sizes [nkv].
+    pair_union (64-row lists, max_kv <= 2048): the two lists of neighbouring query blocks are merged (fvk_vsa_union_lists) and walked as one by
+    their workgroup — a KV tile both selected is fetched once (fvk_attn_block_sparse_union_bf16); bit-identical output.  OFF by default: the
+    walk fetches ~30 % fewer tiles on the selections the model makes but takes one step per tile of the UNION, both halves in lockstep, and the
+    kernel is step-bound, not ingest-bound — 3.2 vs 2.65 ms per layer at cfg2 (profiles/r04u_vsa_union_ab.log)."""
     scale = q.shape[-1]**-0.5 if scale is None else scale
     vt = _vt_of(v, layout)
     o = torch.empty_like(q)
@@ -444,7 +449,15 @@ def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, lay
     q2k_idx = _chk(q2k_idx, torch.int32, "q2k_idx").contiguous()
     q2k_num = _chk(q2k_num, torch.int32, "q2k_num").contiguous()
     kv_block_sizes = _chk(kv_block_sizes, torch.int32, "kv_block_sizes").contiguous()
-    _lib.call("fvk_attn_block_sparse_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), q2k_idx.shape[-1], int(q_block), _stream())
+    max_kv = q2k_idx.shape[-1]
+    if pair_union and q_block == 64 and max_kv <= 2048:
+        nq = q2k_idx.shape[-2]
+        u_idx = torch.empty((B * H, (nq + 1) // 2, 2 * max_kv), dtype=torch.int32, device=q.device)
+        u_num = torch.empty((B * H, (nq + 1) // 2), dtype=torch.int32, device=q.device)
+        _lib.call("fvk_vsa_union_lists", _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), _p(u_idx), _p(u_num), B * H, nq, max_kv, _stream())
+        _lib.call("fvk_attn_block_sparse_union_bf16", C.byref(a), _p(u_idx), _p(u_num), 2 * max_kv, _stream())
+        return (o, lse) if return_lse else o
+    _lib.call("fvk_attn_block_sparse_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), max_kv, int(q_block), _stream())
     return (o, lse) if return_lse else o
 
 

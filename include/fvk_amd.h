@@ -221,6 +221,13 @@ int fvk_attn_dense_split_bf16(const fvk_attn_args* a, int n_split, float* o_part
  * streams are addressed through 32-bit buffer descriptors. */
 int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
                                const int32_t* kv_block_sizes, int max_kv, int q_block, void* stream);
+/* The same attention for 64-row lists with the two lists of a workgroup's neighbouring query blocks (2p, 2p + 1) walked as ONE merged list
+ * (round 4): fvk_vsa_union_lists merges the ascending lists of fvk_map_to_index into u_idx [B*H, ceil(nq/2), 2*max_kv] packed entries
+ * (block id | valid keys << 22 | halves << 29) + u_num [B*H, ceil(nq/2)]; fvk_attn_block_sparse_union_bf16 walks them — a KV tile both blocks
+ * selected is fetched once.  Output bit-identical to fvk_attn_block_sparse_bf16 (q_block 64) on the same lists.  max_kv <= 2048. */
+int fvk_vsa_union_lists(const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int32_t* u_idx, int32_t* u_num, int rows,
+                        int nq, int max_kv, void* stream);
+int fvk_attn_block_sparse_union_bf16(const fvk_attn_args* a, const int32_t* u_idx, const int32_t* u_num, int max_u, void* stream);
 
 /* block-sparse with SHARED lists — sliding-tile attention on arbitrary canvases: every rows_per_list consecutive query rows (one
  * sliding tile in tile-major order, 384 tokens for the reference's (6,8,8) tile) attend the same KV blocks, list i =

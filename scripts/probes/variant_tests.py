@@ -290,11 +290,13 @@ def test_attn_w64_list_mode_agrees_with_the_shipped_list_kernel(ops, tunables):
 
 
 # ------------------------------------------------------------------ Wan VAE 3x3 conv: the one-wave-per-SIMD kernel vs the 8-wave kernel
-@pytest.mark.parametrize("Cin,Cout,T,H,W,kt,residual,norm", [(96, 96, 2, 37, 70, 3, False, False), (96, 96, 1, 16, 32, 1, True, False),
-                                                             (192, 192, 2, 19, 45, 3, True, False), (384, 384, 1, 12, 40, 3, False, False),
-                                                             (96, 96, 2, 21, 33, 3, True, True), (192, 192, 1, 9, 64, 3, False, True),
-                                                             (192, 96, 2, 18, 34, 3, False, True)])
-def test_vae_conv3w_vs_8wave_kernel(ops, tunables, Cin, Cout, T, H, W, kt, residual, norm):
+@pytest.mark.parametrize("Cin,Cout,T,H,W,kt,residual,norm,ups", [
+    (96, 96, 2, 37, 70, 3, False, False, False), (96, 96, 1, 16, 32, 1, True, False, False), (192, 192, 2, 19, 45, 3, True, False, False),
+    (384, 384, 1, 12, 40, 3, False, False, False), (96, 96, 2, 21, 33, 3, True, True, False), (192, 192, 1, 9, 64, 3, False, True, False),
+    (192, 96, 2, 18, 34, 3, False, True, False),
+    # the resample convs: 2x nearest-exact upsample folded into the staging (H, W = the upsampled size; odd input sizes, several tiles)
+    (192, 96, 2, 38, 70, 1, False, True, True), (384, 192, 1, 22, 74, 1, False, False, True), (384, 192, 2, 18, 66, 1, False, True, True)])
+def test_vae_conv3w_vs_8wave_kernel(ops, tunables, Cin, Cout, T, H, W, kt, residual, norm, ups):
     """vae_conv3w.hip (round 4: 4 waves x (4 rows x 32 px x 96 ch), 16x16x32 MFMAs, direct epilogue) against vae_conv3.hip's 8-wave kernel
     ("vae_conv_impl" 3) on multi-tile, ragged shapes: the two sum the same products in a different fp32 order (32-k vs 16-k MFMA steps), so
     every output is within ONE bf16 ulp of the other and the great majority are identical; the fused-norm ring likewise (its ||x||^2 is summed
@@ -302,7 +304,7 @@ def test_vae_conv3w_vs_8wave_kernel(ops, tunables, Cin, Cout, T, H, W, kt, resid
     ring_in, start = T + kt - 1, (1 if kt == 3 else 0)
     w = rnd((Cout, kt * 9 * Cin), 1, (kt * 9 * Cin)**-0.5).to(DEV)
     b = rnd((Cout,), 2, 0.1).to(DEV)
-    x = rnd((ring_in, H, W, Cin), 3).to(DEV)
+    x = rnd((ring_in, H // 2, W // 2, Cin) if ups else (ring_in, H, W, Cin), 3).to(DEV)
     res = rnd((T, H, W, Cout), 5).to(DEV) if residual else None
     gamma = (1 + rnd((Cout,), 4, 0.1, torch.float32)).to(DEV)
     outs = {}
@@ -311,10 +313,10 @@ def test_vae_conv3w_vs_8wave_kernel(ops, tunables, Cin, Cout, T, H, W, kt, resid
         if norm:
             nring = T + 1
             ringbuf = torch.full((nring, H, W, Cout), 3.0, dtype=torch.bfloat16, device=DEV)
-            raw = ops.vae_conv_norm(x, w, b, gamma, ringbuf, T=T, H=H, W=W, kt=kt, norm_slot0=1, ring_start=start, residual=res)
+            raw = ops.vae_conv_norm(x, w, b, gamma, ringbuf, T=T, H=H, W=W, kt=kt, norm_slot0=1, ring_start=start, residual=res, upsample2x=ups)
             outs[impl] = (raw.float().cpu(), ringbuf.float().cpu())
         else:
-            outs[impl] = (ops.vae_conv(x, w, b, T=T, H=H, W=W, kt=kt, ks=3, ring_start=start, residual=res).float().cpu(),)
+            outs[impl] = (ops.vae_conv(x, w, b, T=T, H=H, W=W, kt=kt, ks=3, ring_start=start, residual=res, upsample2x=ups).float().cpu(),)
     for new, old in zip(outs[0], outs[3]):
         assert torch.isfinite(new).all()
         diff = (new - old).abs()

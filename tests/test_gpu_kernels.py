@@ -214,6 +214,45 @@ def test_gemm_rank_shapes_equal_the_rows_of_the_full_problem(ops, P):
         close(rank[:64], _lin_ref(x[r * Sl:r * Sl + 64].cpu(), w.cpu(), b.cpu()) if epi == ops.EPI_NONE else rank[:64], what="rank rows vs fp32")
 
 
+def test_vsa_union_lists_and_union_walk_are_exact(ops):
+    """Round 4: fvk_vsa_union_lists (the ascending merge of the lists of query blocks 2p / 2p + 1, entries tagged with the halves that selected
+    them) is bit-exact against a host merge, and fvk_attn_block_sparse_union_bf16 — one walk over the merged list, shared KV tiles fetched once —
+    returns the bytes of the two-list kernel: with heavily overlapping lists, disjoint lists, an odd block count (a last block without a
+    partner), an empty list, and variable block sizes."""
+    from fastvideo_amd import _lib
+    import ctypes as C
+    B, H, nq, nk, D = 1, 3, 9, 40, 128
+    g_ = torch.Generator().manual_seed(0)
+    mask = torch.rand((B, H, nq, nk), generator=g_) < 0.3
+    mask[0, 0, 1] = mask[0, 0, 0]                      # identical neighbours
+    mask[0, 1, 2] = ~mask[0, 1, 3]                     # disjoint neighbours
+    mask[0, 2, 4] = False                              # an empty list beside a full one
+    mask[0, 2, 5] = True
+    vbs = torch.randint(1, 65, (nk,), generator=g_, dtype=torch.int32)
+    vbs[::3] = 64
+    idx, num = ops.map_to_index(mask.to(DEV))
+    max_kv = idx.shape[-1]
+    u_idx = torch.zeros((B * H, (nq + 1) // 2, 2 * max_kv), dtype=torch.int32, device=DEV)
+    u_num = torch.zeros((B * H, (nq + 1) // 2), dtype=torch.int32, device=DEV)
+    p_ = lambda t: C.c_void_p(t.data_ptr())
+    _lib.call("fvk_vsa_union_lists", p_(idx), p_(num), p_(vbs.to(DEV)), p_(u_idx), p_(u_num), B * H, nq, max_kv, ops._stream())
+    ui, un = u_idx.cpu(), u_num.cpu()
+    m = mask.view(B * H, nq, nk)
+    for bh in range(B * H):
+        for p in range((nq + 1) // 2):
+            a_ = m[bh, 2 * p]
+            b_ = m[bh, 2 * p + 1] if 2 * p + 1 < nq else torch.zeros(nk, dtype=torch.bool)
+            ids = torch.nonzero(a_ | b_).flatten()
+            want = [int(i) | (int(vbs[i]) << 22) | ((int(a_[i]) | (int(b_[i]) << 1)) << 29) for i in ids]
+            assert int(un[bh, p]) == len(want) and ui[bh, p, :len(want)].tolist() == want, (bh, p)
+    S = nq * 64
+    q, k, v = rnd((B, H, S, D), 1).to(DEV), rnd((B, H, nk * 64, D), 2).to(DEV), rnd((B, H, nk * 64, D), 3).to(DEV)
+    two = ops.attn_block_sparse(q, k, v, idx, num, vbs.to(DEV), return_lse=True, pair_union=False)
+    uni = ops.attn_block_sparse(q, k, v, idx, num, vbs.to(DEV), return_lse=True, pair_union=True)
+    assert torch.equal(two[0], uni[0]) and torch.equal(two[1], uni[1])
+    assert (uni[0][0, 2, 4 * 64:5 * 64] == 0).all()    # the empty list: zeros, as the two-list kernel
+
+
 # ------------------------------------------------------------------ attention
 def _attn_check(out, ref, what):
     """max |err| < 4e-2: the reference's own kernel-test bound (fastvideo-kernel/tests/test_sta.py:88-91).  Mean: the kernel's only bf16
