@@ -505,18 +505,21 @@ def attn_sta(q, k, v, canvas_tiles, tile_tokens, windows, scale=None, layout="bh
 
 def attn_dense_wide(q, k, v, scale=None):
     """Single-head attention with head_dim 384 (the Wan VAE mid block, ref: wanvae.py:479-507).
-    q, k, v: bf16 [S, 384] views with unit column stride (e.g. the three column blocks of a fused [S, 1152] projection)."""
+    q, k, v: bf16 [S, 384] or [T, S, 384] views with unit column stride (e.g. the three column blocks of a fused [.., S, 1152] projection);
+    a leading T = independent frames, ONE launch for all of them (a frame alone is 147 workgroups on 256 CUs)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _chk(t, BF16, n)
-    S, D = q.shape
-    if D != 384:
-        raise RuntimeError(f"attn_dense_wide: head_dim {D} != 384")
+    if q.dim() == 2:
+        return attn_dense_wide(q[None], k[None], v[None], scale)[0]
+    T, S, D = q.shape
+    if D != 384 or k.shape != q.shape or v.shape != q.shape:
+        raise RuntimeError(f"attn_dense_wide: q/k/v {tuple(q.shape)} {tuple(k.shape)} {tuple(v.shape)}: want three [T, S, 384] tensors")
     scale = D**-0.5 if scale is None else scale
-    v4 = v.as_strided((1, S, 3, 128), (0, v.stride(0), 128, 1))
+    v4 = v.as_strided((T, S, 3, 128), (v.stride(0), v.stride(1), 128, 1))
     vt = v_transpose(v4)
-    o = torch.empty((S, D), dtype=BF16, device=q.device)
-    a = _attn_args(q.as_strided((1, S, 1, D), (0, q.stride(0), 0, 1)), k.as_strided((1, S, 1, D), (0, k.stride(0), 0, 1)), vt,
-                   o.view(1, S, 1, D), scale, "bshd", qk_dim=384)
+    o = torch.empty((T, S, D), dtype=BF16, device=q.device)
+    a = _attn_args(q.as_strided((T, S, 1, D), (q.stride(0), q.stride(1), 0, 1)), k.as_strided((T, S, 1, D), (k.stride(0), k.stride(1), 0, 1)), vt,
+                   o.view(T, S, 1, D), scale, "bshd", qk_dim=384)
     _lib.call("fvk_attn_dense_bf16", C.byref(a), _stream())
     return o
 

@@ -249,13 +249,11 @@ class WanVaeDecoderHip:
         n = torch.empty((T, H * W, C), dtype=BF16, device=x.device)
         ops.vae_rmsnorm_silu(x, a["g"], n, HW=H * W, slot0=0, silu=False)
         qkv = ops.gemm(n.view(T * H * W, C), a["qkv_w"], a["qkv_b"]).view(T, H * W, 3 * C)
-        o = torch.empty((T, H * W, C), dtype=BF16, device=x.device)
-        for t in range(T):
-            q, k, v = qkv[t, :, :C], qkv[t, :, C:2 * C], qkv[t, :, 2 * C:]
-            if C == 384:
-                o[t] = ops.attn_dense_wide(q, k, v)
-            else:
-                o[t] = ops.attn_dense(q[None, :, None], k[None, :, None], v[None, :, None]).reshape(H * W, C)
+        q, k, v = qkv[:, :, :C], qkv[:, :, C:2 * C], qkv[:, :, 2 * C:]   # the frames are the batch: one launch per pass, not one per frame
+        if C == 384:
+            o = ops.attn_dense_wide(q, k, v)
+        else:
+            o = ops.attn_dense(q[:, :, None], k[:, :, None], v[:, :, None]).reshape(T, H * W, C)
         o = ops.gemm(o.view(T * H * W, C), a["proj_w"], a["proj_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x.view(T * H * W, C))
         return o.view(T, H, W, C)
 

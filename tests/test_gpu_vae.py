@@ -127,6 +127,17 @@ def test_mid_block_attention_head_dim_384(ops, S):
     assert err.mean() < 3e-3 and err.max() < 4e-2, (err.mean().item(), err.max().item())  # fastvideo-kernel/tests/test_sta.py:88-91
 
 
+def test_mid_block_attention_frames_in_one_launch(ops):
+    """The decoder passes the pass's frames as the batch of ONE launch (WanAttentionBlock folds t into the batch too, wanvae.py:486-489): every
+    frame's rows are the bytes the frame gets alone."""
+    T, S = 3, 520
+    g = rnd((T, S, 1152), 2).cuda().bfloat16()
+    o = ops.attn_dense_wide(g[:, :, :384], g[:, :, 384:768], g[:, :, 768:])
+    assert o.shape == (T, S, 384)
+    for t in range(T):
+        assert torch.equal(o[t], ops.attn_dense_wide(g[t, :, :384], g[t, :, 384:768], g[t, :, 768:]))
+
+
 def _decode_check(sd, z, y_ref, max_tol):
     from fastvideo_amd.wan_vae import WanVaeDecoderHip
     dec = WanVaeDecoderHip(sd, device="cuda")
