@@ -48,7 +48,15 @@ def test_bench_two_ranks_shared_gpu(overlap):
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == "strong" and j["higher_is_better"] is True
     assert j["value"] > 0 and abs(j["value"] - 32760 / (j["ms_per_step"] * 1e-3)) / j["value"] < 1e-3
     assert "INVALID" in j and "share one GPU" in j["INVALID"]
-    assert "sp2" in j["config"]["parallelism"] and ("pipelined" in j["config"]["parallelism"]) == (overlap == "1")
+    par = j["config"]["parallelism"]
+    assert "sp2" in par
+    if overlap == "1" and "pipelined" not in par:
+        # the designed fall-back: the first pipelined call is compared bit for bit with the plain exchange on every rank, and two PROCESSES
+        # time-slicing one GPU (this harness only) show rare last-bit differences between repeated forwards even with the plain exchange
+        # (profiles/r04e_sp_pipe_debug.log) — then the line must say "plain exchange" and the warning must have been printed
+        assert "plain exchange" in par and "falling back to the plain exchange" in r.stderr, r.stderr[-2000:]
+    else:
+        assert ("pipelined" in par) == (overlap == "1")
     ex = j["exchange"]
     assert ex["backend"] == "gloo" and ex["rccl_ranks"] == 0
     kinds = ex["per_kind"]
