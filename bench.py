@@ -166,6 +166,28 @@ def attention_traffic_from_profiles(kernel="attn_w16"):
     return best if best else (None, f"no PMC pass for the current {kernel}.hip (run KERNEL={kernel} scripts/pmc_traffic.sh)", None)
 
 
+def conv_traffic_from_profiles():
+    """HBM-side bytes per launch of vae_conv3w_kernel at its two dominant shapes, from the newest committed counter pass
+    (profiles/*conv3w_traffic*.json, scripts/conv_pmc_traffic.sh) whose recorded sha256 equals vae_conv3w.hip in the tree; else None + why.
+    The conv family's roofline object averages launches of MANY shapes, so there is no single per-launch figure: `traffic` stays null there and
+    the per-shape numbers ride beside it."""
+    import glob
+    import hashlib
+    src = os.path.join(ROOT, "fastvideo_amd", "csrc", "vae_conv3w.hip")
+    cur = hashlib.sha256(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*conv3w_traffic*.json"))):
+        try:
+            j = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        if j.get("kernel_source_sha256") == cur and j.get("shapes"):
+            best = ({k: {a: v[a] for a in ("traffic_bytes_per_launch", "algorithmic_bytes_per_launch", "traffic_over_algorithmic",
+                                           "without_fetch_correction_over_algorithmic") if a in v}
+                     for k, v in j["shapes"].items()}, os.path.basename(f))
+    return best if best else (None, "no counter pass for the current vae_conv3w.hip (run scripts/conv_pmc_traffic.sh)")
+
+
 def vae_cpu_baseline(latent_shape, budget_frames=2):
     """CPU baseline of the VAE stage on a bounded sample: the reference's own ``AutoencoderKLWan.decode`` (fp32 on the host — the
     CPU has no bf16 autocast speed-up to offer) on the first ``budget_frames`` latent frames at the full spatial size, when a reference tree is present (live or
@@ -304,6 +326,7 @@ def measure_vae(latent_shape, steps, warmup, frames_per_pass=4):
     ms = elapsed / steps * 1e3
     fl = vae_decode_flops(*latent_shape[2:])
     frames = y.shape[2]
+    tr_shapes, tr_src = conv_traffic_from_profiles()
     return {"metric": f"Wan2.1 VAE decode, latent {list(latent_shape)} -> pixels {list(y.shape)} (one decode per step)",
             "value": round(frames / (elapsed / steps), 2), "unit": "pixel-frames/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
             "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -314,7 +337,8 @@ def measure_vae(latent_shape, steps, warmup, frames_per_pass=4):
                        "frames_per_pass": frames_per_pass},
             "step_tflops": round(fl / (ms * 1e-3) / 1e12, 1), "step_frac_of_bf16_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": dict(bound="mfma", kernel=dom, achieved=round(achieved, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                             frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None, flops_per_launch=fl_d / n_d,
+                             frac=round(achieved / PEAK_BF16_TFLOPS, 4), traffic=None, traffic_by_shape=tr_shapes, traffic_source=tr_src,
+                             flops_per_launch=fl_d / n_d,
                              mean_launch_ms=round(ms_d / n_d, 4), launches=n_d, share_of_step=round(ms_d / ms, 3),
                              other_kernels={k: dict(ms=round(v[1], 2), tflops=round(v[0] / (v[1] * 1e-3) / 1e12, 1), launches=v[2])
                                             for k, v in groups.items() if k != dom}),

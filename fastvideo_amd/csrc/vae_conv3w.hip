@@ -77,17 +77,28 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
 #endif
     C3W_STAMP(0)
 
-    // ---- tiles: PERSISTENT workgroups — workgroup b computes tiles b, b + gridDim.x, ... (n fastest in a tile id, so the tiles in flight on the
-    // chip are consecutive and share their halos / weights in L2).  The DMA stream does not stop at a tile boundary: the last slab's steps stage the
-    // NEXT tile's first slab and weight steps exactly as they would the next slab of the same tile, so only a workgroup's first tile pays the cold
-    // prologue burst (every CU fetching 81 KiB at once: 13 k cycles of a 98 k-cycle tile at 96 channels, profiles/r04b_conv3w_tile_probe.log).
+    // ---- tiles: PERSISTENT workgroups — workgroup b computes the tiles of linear ids b, b + gridDim.x, ...  The DMA stream does not stop at a
+    // tile boundary: the last slab's steps stage the NEXT tile's first slab and weight steps exactly as they would the next slab of the same
+    // tile, so only a workgroup's first tile pays the cold prologue burst (every CU fetching 81 KiB at once: 13 k cycles of a 98 k-cycle tile at
+    // 96 channels, profiles/r04b_conv3w_tile_probe.log).
+    // Linear id -> tile, XCD-AWARE.  Workgroup b runs on XCD b & 7 (round-robin dispatch; gridDim.x is a multiple of 8 whenever a workgroup has
+    // more than one tile), and every XCD has its own L2.  An output frame reads three input frames, so the tile (s, t) of spatial position s
+    // shares two thirds of its input with (s, t +- 1): the tiles are ordered spatial-major with t FASTEST (m = s T + t), that sequence is cut
+    // into 8 contiguous runs, and XCD x walks run x — the 32 tiles an XCD has in flight are then ~2 spatial positions x 16 frames, every input
+    // slab is fetched into that XCD's L2 once and hit by the other two frames' tiles.  (The first form — n, w, h, t with t slowest, consecutive
+    // ids on different XCDs — fetched every input frame three times: 2.6 x the algorithmic HBM bytes, profiles/r04z_conv3w_traffic.json.)
     struct Tile { int t_out, h0, w0, n0; };
+    const int id_base = ntiles >> 3, id_rem = ntiles & 7;
     auto decode = [&](int id) {
         Tile t;
-        const int pid_n = id % a.ntn; id /= a.ntn;
-        const int tw_i = id % a.tiles_w; id /= a.tiles_w;
-        const int th_i = id % a.tiles_h;
-        t.t_out = id / a.tiles_h; t.h0 = th_i * TH; t.w0 = tw_i * TW; t.n0 = pid_n * TN;
+        const int x = id & 7, j = id >> 3;
+        const int m = x * id_base + (x < id_rem ? x : id_rem) + j;   // XCD x owns ids x, x + 8, ...: id_base (+ 1 if x < id_rem) of them
+        int sp = m / a.T;
+        t.t_out = m - sp * a.T;
+        const int pid_n = sp % a.ntn; sp /= a.ntn;
+        const int tw_i = sp % a.tiles_w;
+        const int th_i = sp / a.tiles_w;
+        t.h0 = th_i * TH; t.w0 = tw_i * TW; t.n0 = pid_n * TN;
         return t;
     };
     int cur_id = (int)blockIdx.x;
