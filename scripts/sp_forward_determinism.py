@@ -77,7 +77,7 @@ def worker(rank, world, port, heads, lat_shape, overlap, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FVK_SP_OVERLAP=str(overlap))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     outs, sp = forward_traces(heads, lat_shape)
-    if rank == 0:
+    if rank == int(os.environ.get("RANK_SAVE", "0")):   # whose traces are compared (the final output y is the same tensor on every rank)
         torch.save((outs, sp.overlap), f"/tmp/sp_det_{port}.pt")
         q.put("done")
     dist.barrier(); dist.destroy_process_group()
@@ -102,6 +102,7 @@ if __name__ == "__main__":
     outs, ov = torch.load(f"/tmp/sp_det_{port}.pt", weights_only=False)
     print(f"world {world} heads {heads} overlap requested {overlap} kept {ov} GEMM_IMPL={os.environ.get('GEMM_IMPL')}")
     if os.environ.get("HOOK"):
+        print("  y vs SP = 1:", [f"fwd{i}: {int((outs[i]['y'] != ref[0]['y']).sum())} differ" for i in range(3)], "(rank", os.environ.get("RANK_SAVE", "0"), "traces)")
         for k in outs[0]:
             print(f"  {k:28s}", [f"fwd{i} vs fwd0: {int((outs[i][k] != outs[0][k]).sum())} of {outs[0][k].numel()} differ" for i in (1, 2)])
             for i in (1, 2):
