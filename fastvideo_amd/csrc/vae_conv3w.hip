@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256, 1) void vae_conv3w_kernel(Conv3Args a, int nti
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef __attribute__((address_space(3))) void lds_void;
 
+    FVK_CLAIM_WHOLE_REGISTER_FILE();
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

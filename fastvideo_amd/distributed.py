@@ -373,10 +373,10 @@ class SequenceParallel:
         stream; ``wait()`` only orders the compute stream), chunk B's exchange rides under chunk A's attention, each chunk's output exchange is
         issued as soon as its attention is and chunk A's rides under chunk B's attention; the compute stream then waits for both and assembles
         [Sl, H, D] (heads in the un-chunked order).  ONE compute stream: running chunk B's attention on a second HIP stream was built and
-        withdrawn in round 4 when consecutive forwards differed on the one-GPU box (two ranks sharing cuda:0, host-staged gloo).  That
-        difference was later traced to the harness, not to the streams (with several processes time-slicing one GPU a forward
-        in four carries a few wrong values in one kernel's output, with the plain exchange too), so the two-stream form is the next thing
-        to re-instate — on real RCCL, where it can also be timed.  CPU / gloo: the same order of operations (tests)."""
+        withdrawn in round 4 when consecutive forwards differed on the one-GPU box.  The cause was found later and is fixed (a
+        small kernel's wave sharing a SIMD with a gemm_w1 wave got wrong packed-fp32 results; the one-wave-per-SIMD kernels now claim the
+        whole register file), so the two-stream form is the next thing to re-instate — on real RCCL, where it can also be timed.
+        CPU / gloo: the same order of operations (tests)."""
         L = self.lay
         Sl = sends[0].shape[1]
         pend = [self.exchange_rows_async(s_) for s_ in sends]

@@ -214,6 +214,38 @@ def test_gemm_rank_shapes_equal_the_rows_of_the_full_problem(ops, P):
         close(rank[:64], _lin_ref(x[r * Sl:r * Sl + 64].cpu(), w.cpu(), b.cpu()) if epi == ops.EPI_NONE else rank[:64], what="rank rows vs fp32")
 
 
+def test_small_kernel_beside_gemm_w1_on_another_stream(ops):
+    """Regression test of round 4's co-residency bug (profiles/r04z_pk_f32_beside_mfma.log): while gemm_w1 ran on another stream, a wave
+    of the QK-norm / RoPE / pack pass that shared a SIMD with one of its waves (gemm_w1 left 104 of 512 registers free) got wrong packed-fp32
+    results — 192 of 200 launches.  The one-wave-per-SIMD 16x16x32 kernels now claim the whole register file; the pass beside gemm_w1, gemm_w1n
+    and conv3w must reproduce its stand-alone bytes every time."""
+    g_ = torch.Generator().manual_seed(5)
+    Sl, d, D = 338, 768, 128
+    qkv = torch.randn((Sl, 3 * d), generator=g_).bfloat16().to(DEV)
+    wq, wk = (1 + 0.1 * torch.randn(d, generator=g_)).bfloat16().to(DEV), (1 + 0.1 * torch.randn(d, generator=g_)).bfloat16().to(DEV)
+    ang = torch.rand((2 * Sl, D), generator=g_) * 6.28
+    cos, sin = torch.cos(ang).float().to(DEV), torch.sin(ang).float().to(DEV)
+    A, B = torch.randn((8192, 4096), generator=g_).bfloat16().to(DEV), torch.randn((4096, 4096), generator=g_).bfloat16().to(DEV)
+    An, Bn = torch.randn((4095, 1536), generator=g_).bfloat16().to(DEV), torch.randn((1536, 1536), generator=g_).bfloat16().to(DEV)   # gemm_w1n's shape class
+    xc = torch.randn((6, 240, 416, 96), generator=g_).bfloat16().to(DEV)
+    wc, bc = (torch.randn((96, 27 * 96), generator=g_) * (27 * 96)**-0.5).bfloat16().to(DEV), torch.zeros(96).bfloat16().to(DEV)
+    pack = lambda: ops.qkv_norm_rope_pack(qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:], wq, wk, cos, sin, 2, 1, head_dim=D, seq_len=2 * Sl)
+    ref = pack().clone()
+    torch.cuda.synchronize()
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for name, load in (("gemm_w1", lambda: ops.gemm(A, B)), ("gemm_w1n", lambda: ops.gemm(An, Bn)),
+                       ("conv3w", lambda: ops.vae_conv(xc, wc, bc, T=4, H=240, W=416, kt=3, ks=3))):
+        outs = []
+        for _ in range(120):
+            with torch.cuda.stream(sa):
+                keep = load()
+            with torch.cuda.stream(sb):
+                outs.append(pack())
+        torch.cuda.synchronize()
+        bad = sum(0 if torch.equal(o, ref) else 1 for o in outs)
+        assert bad == 0, f"{bad} of {len(outs)} launches of the norm / RoPE / pack pass beside {name} differ from the stand-alone result"
+
+
 def test_vsa_union_lists_and_union_walk_are_exact(ops):
     """Round 4: fvk_vsa_union_lists (the ascending merge of the lists of query blocks 2p / 2p + 1, entries tagged with the halves that selected
     them) is bit-exact against a host merge, and fvk_attn_block_sparse_union_bf16 — one walk over the merged list, shared KV tiles fetched once —

@@ -73,11 +73,10 @@ def _pipelined_model_forward(overlap_expected, heads=6, lat_shape=(1, 16, 5, 18,
     g = torch.Generator().manual_seed(12)
     lat = torch.randn(lat_shape, generator=g).bfloat16()    # default 5 x 9 x 15 = 675 tokens: odd -> one zero-padding row on 2 ranks
     ctx = torch.randn((1, 40, cfg.text_dim), generator=g).bfloat16()
-    # Three forwards are returned.  On this harness — several PROCESSES time-slicing ONE GPU, host-staged gloo — about one forward in four of a
-    # run carries a handful of grossly wrong values in one kernel's output (traced in round 4, scripts/sp_forward_determinism.py HOOK=1: single
-    # dwords of a few lanes of the QK-norm / RoPE pass of one layer — the pattern of a load result lost around a wave context switch — with the
-    # PLAIN exchange as much as with the pipelined one; never in a single process, never with a synchronisation between the kernels, i.e. never in
-    # the one-process-per-GPU deployment).  The forwards are therefore compared to the DiT tolerance each and bit for bit as a set.
+    # Three forwards are returned and ALL must equal SP = 1 bit for bit.  (Round 4: several processes time-slicing one GPU exposed a real bug —
+    # a wave of the QK-norm / RoPE pass sharing a SIMD with a gemm_w1 wave of another process got wrong packed-fp32 results, about one forward in
+    # four; fixed by FVK_CLAIM_WHOLE_REGISTER_FILE in the one-wave-per-SIMD kernels, DESIGN §5, profiles/r04z_pk_f32_beside_mfma.log.  This test
+    # is the regression test of that fix in its natural habitat.)
     ys = [model(lat.cuda(), ctx.cuda(), torch.tensor([333.0]).cuda()).cpu() for _ in range(3)]
     return ys, model.sp.overlap, model.sp._overlap_checked
 
@@ -108,29 +107,20 @@ def test_sp_pipelined_exchange_equals_sp1(world, heads, lat_shape):
     refs, ov, _ = _pipelined_model_forward(False, heads, lat_shape)
     ref = refs[0]
     assert not ov and all(torch.equal(ref, r) for r in refs[1:])
-    for attempt in range(2):
-        ctx = mp.get_context("spawn")
-        out_q = ctx.Queue()
-        port = _free_port()
-        procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, out_q, heads, lat_shape)) for r in range(world)]
-        for p in procs:
-            p.start()
-        out, overlap_kept, checked = out_q.get(timeout=300)
-        for p in procs:
-            p.join(timeout=120)
-            assert p.exitcode == 0
-        for i, o in enumerate(out):   # every forward is the SP = 1 result to the DiT bound ...
-            err = (o.float() - ref.float()).abs()
-            assert (err <= 1e-1 + 1e-2 * ref.float().abs()).all() and err.mean().item() < 5e-3, f"pipelined SP={world}, forward {i}: max {err.max().item():.4g}"
-        exact = [torch.equal(o, ref) for o in out]
-        # ... and bit for bit in at least one of the three (see _pipelined_model_forward on the shared-GPU harness's own noise; one retry).  The
-        # first-call self-check compares bit for bit too, so under that noise it may legitimately have fallen back to the plain exchange: the
-        # attempt then proves nothing about the pipelined path and is repeated
-        if checked and overlap_kept and any(exact):
-            return
-    assert checked and overlap_kept, "the pipelined exchange disagreed with the plain exchange on its first call and was switched off (twice)"
-    assert any(exact), (f"pipelined SP={world}: no forward equals SP = 1 bit for bit ({exact}); elements differing: "
-                        f"{[int((o != ref).sum()) for o in out]} of {ref.numel()}")
+    ctx = mp.get_context("spawn")
+    out_q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, out_q, heads, lat_shape)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out, overlap_kept, checked = out_q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert checked and overlap_kept, "the pipelined exchange disagreed with the plain exchange on its first call and was switched off"
+    for i, o in enumerate(out):
+        assert torch.equal(o, ref), (f"pipelined SP={world}, forward {i}: {int((o != ref).sum())} of {ref.numel()} elements differ from SP = 1, "
+                                     f"max {(o.float() - ref.float()).abs().max().item():.4g}")
 
 
 def _worker_sparse(rank, world, port, fx_path, mode, out_q, quant=None):
