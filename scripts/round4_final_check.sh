@@ -16,3 +16,4 @@ timeout 900 python bench.py > "$OUT/bench.log" 2> "$OUT/bench.err"; echo "bench 
 timeout 400 python bench.py --attention vsa --no-vae --no-cpu-baseline --no-cfg-step > "$OUT/bench_vsa.log" 2> "$OUT/bench_vsa.err"; echo "vsa rc=$?"; tail -1 "$OUT/bench_vsa.log" | cut -c1-700
 bash scripts/prof.sh r4final 2>&1 | grep -v "distribution\|at::native" | tail -14 | cut -c1-200
 bash scripts/conv_pmc_traffic.sh r4final 2>&1 | grep -i "rc=\|traffic_over\|without_fetch"
+KERNEL=attn_w16 bash scripts/pmc_traffic.sh r4final 2>&1 | grep -i "rc=\|traffic_bytes\|effective_clock\|mfma_busy"
