@@ -16,6 +16,12 @@ SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.
 PROBE_DIR = os.path.join(HERE, "..", "scripts", "probes")
 PROBE_SOURCES = ["attn_pp.hip", "attn_vsa.hip"]
 PROBE_LIB = os.path.join(PROBE_DIR, "libfvk_probe.so")
+# The files of the SMALL kernels (norm / RoPE / pack, gathers, quantisers, scheduler step, post-processing: few registers, so their waves can
+# share a SIMD with another kernel's) are compiled WITHOUT packed-fp32 VALU instructions: round 4 found v_pk_mul_f32 / v_pk_add_f32 results of
+# such a wave wrong while a foreign MFMA stream ran on its SIMD (profiles/r04z_pk_f32_beside_mfma.log).  The known aggressors now
+# claim the whole register file; this is the second fence, for neighbours we do not control.  Same arithmetic (two scalar operations instead of
+# one packed one), and these kernels are HBM-bound.  (The host pass prints "not a recognized feature" for the flag: filtered below.)
+NO_PACKED_FP32 = ("norm_mod.hip", "vsa_misc.hip", "fp8.hip", "sched_step.hip", "vae_post.hip")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 FLAGS += os.environ.get("FVK_EXTRA_FLAGS", "").split()  # measurement builds only (e.g. -DFVK_ST_ABL=1 timing ablations)
 
@@ -75,6 +81,8 @@ def _build_locked(verbose: bool, probe: bool = False) -> str:
             # its 64-chunk iteration must be FULLY unrolled (every register-array index a constant): above clang's default budget for
             # `#pragma unroll`, silently left as a loop otherwise — with the wave's whole register struct in scratch
             extra += ["-mllvm", "-pragma-unroll-threshold=100000"]
+        if src in NO_PACKED_FP32:
+            extra += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
         if probe:
             extra += ["-DFVK_PROBE_BUILD=1", "-I", CSRC]
         cmd = [cc, *FLAGS, *extra, "-c", path, "-o", obj]
@@ -83,6 +91,7 @@ def _build_locked(verbose: bool, probe: bool = False) -> str:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        out = "\n".join(ln for ln in out.splitlines() if "'-packed-fp32-ops' is not a recognized feature" not in ln)
         if verbose and out.strip():
             print(out)
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]

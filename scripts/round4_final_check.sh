@@ -15,5 +15,7 @@ timeout 300 python -c "import __graft_entry__ as G; G.smoke(); print('smoke ok')
 timeout 900 python bench.py > "$OUT/bench.log" 2> "$OUT/bench.err"; echo "bench rc=$?"; tail -1 "$OUT/bench.log" | cut -c1-3000
 timeout 400 python bench.py --attention vsa --no-vae --no-cpu-baseline --no-cfg-step > "$OUT/bench_vsa.log" 2> "$OUT/bench_vsa.err"; echo "vsa rc=$?"; tail -1 "$OUT/bench_vsa.log" | cut -c1-700
 bash scripts/prof.sh r4final 2>&1 | grep -v "distribution\|at::native" | tail -14 | cut -c1-200
-bash scripts/conv_pmc_traffic.sh r4final 2>&1 | grep -i "rc=\|traffic_over\|without_fetch"
-KERNEL=attn_w16 bash scripts/pmc_traffic.sh r4final 2>&1 | grep -i "rc=\|traffic_bytes\|effective_clock\|mfma_busy"
+for rep in 1 2 3 4 5; do   # the two-rank shared-GPU bench with the pipelined exchange: must keep "pipelined" every time
+  FVK_BENCH_SHARED_GPU=1 FVK_SP_OVERLAP=1 timeout 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $((29600+rep)) bench.py --gpus 2 --steps 2 --warmup 1 --layers 2 > "$OUT/b2_$rep.log" 2> "$OUT/b2_$rep.err"
+  echo "two-rank rep $rep rc=$? $(tail -1 "$OUT/b2_$rep.log" | python -c "import sys,json; print(json.loads(sys.stdin.read())['config']['parallelism'][-60:])")  $(grep -o "rank [0-9]: [^;]*differ[^;]*" "$OUT/b2_$rep.err" | head -2 | tr '\n' ' ')"
+done
