@@ -545,7 +545,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     lay = model.sp.lay
     par = "sp1" if world == 1 else (f"sp{world} 2-D Ulysses (head groups {lay.G} x query blocks {lay.U}), "
-                                    f"{'pipelined (2 head chunks, asynchronous exchanges)' if model.sp.overlap else 'plain'} exchange")
+                                    f"{('pipelined (2 head chunks, asynchronous exchanges' + (', two streams)' if model.sp.overlap_streams == 2 else ')')) if model.sp.overlap else 'plain'} exchange")
     out = {
         "metric": "DiT-step latent-tokens/s, Wan2.1-T2V-1.3B 81fx480p (one DiT forward per step)" if args.config == "cfg2" else
                   f"DiT-step latent-tokens/s, BASELINE {args.config} (one DiT forward per step)",

@@ -92,10 +92,12 @@ class SequenceParallel:
         # What it can save inside ONE batch-1 forward is bounded: every op of a DiT layer depends on the previous one, so the critical path
         # is still exchange #1 (all of it) -> attention -> exchange #2 of the LAST chunk; only the first chunk's share of exchange #2 (~1/6 of
         # a layer's exchange time) is hidden, and two attention launches in stream order split the grid (192 workgroups at SP = 8 become
-        # 128 + 64).  Hence OPT-IN (FVK_SP_OVERLAP=1) until an 8-GPU node has measured it; the default is the plain single-collective
+        # 128 + 64; FVK_SP_OVERLAP=2 runs the second chunk on a second HIP stream instead).  Hence OPT-IN (FVK_SP_OVERLAP=1 / 2) until an 8-GPU node has measured it; the default is the plain single-collective
         # exchange.  Heads are independent in attention, so the result is the plain exchange's bit for bit — checked on the first call
         # (all-reduced verdict); any rank seeing a difference switches every rank back to the plain exchange.
-        self.overlap = P > 1 and os.environ.get("FVK_SP_OVERLAP") == "1"
+        self.overlap = P > 1 and os.environ.get("FVK_SP_OVERLAP") in ("1", "2")
+        self.overlap_streams = 2 if os.environ.get("FVK_SP_OVERLAP") == "2" else 1   # "2": chunk B's attention on a second HIP stream
+        self._side_stream = None
         self._overlap_checked = False
         # bench.py's exchange accounting: set ``stats`` to a dict to collect, per exchange kind, the bytes this rank sends to OTHER
         # ranks and HIP-event pairs around the collective on the caller's stream (None = nothing recorded, nothing extra on the stream)
@@ -372,30 +374,47 @@ class SequenceParallel:
         ([P, Sl, 3, Wa], [P, Sl, 3, Wb]).  Both input exchanges are issued asynchronously up front (RCCL runs them on the process group's own
         stream; ``wait()`` only orders the compute stream), chunk B's exchange rides under chunk A's attention, each chunk's output exchange is
         issued as soon as its attention is and chunk A's rides under chunk B's attention; the compute stream then waits for both and assembles
-        [Sl, H, D] (heads in the un-chunked order).  ONE compute stream: running chunk B's attention on a second HIP stream was built and
-        withdrawn in round 4 when consecutive forwards differed on the one-GPU box.  The cause was found later and is fixed (a
-        small kernel's wave sharing a SIMD with a gemm_w1 wave got wrong packed-fp32 results; the one-wave-per-SIMD kernels now claim the
-        whole register file), so the two-stream form is the next thing to re-instate — on real RCCL, where it can also be timed.
+        [Sl, H, D] (heads in the un-chunked order).  ``FVK_SP_OVERLAP=1``: ONE compute stream (the chunks' attention launches in stream
+        order); ``=2``: chunk B's receive + attention + output exchange on a second HIP stream, so the two chunk launches share the chip
+        instead of each running a half-empty grid.  (The two-stream form was withdrawn mid-round-4 when consecutive forwards differed on the
+        one-GPU box; the cause — a small kernel's wave sharing a SIMD with a gemm_w1 wave, DESIGN §5 — is fixed, and the form is back, bit-identical
+        in the GPU tests; which of the two pays is a question for real xGMI.)
         CPU / gloo: the same order of operations (tests)."""
+        import contextlib
         L = self.lay
         Sl = sends[0].shape[1]
+        two = self.overlap_streams == 2 and sends[0].is_cuda
+        main = torch.cuda.current_stream() if two else None
+        if two:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            self._side_stream.wait_stream(main)   # the side stream starts behind everything issued so far (the pack pass, the allocator's reuse)
+        streams = [main, self._side_stream] if two else [None, None]
         pend = [self.exchange_rows_async(s_) for s_ in sends]
         outs = []
         o_in, o_out = self._o_splits(Sl)
-        for send, done in zip(sends, pend):
-            t0 = self._tick()
-            recv = done()
-            self._tock(t0, "exchange1", send.numel() * send.element_size() * (L.P - 1) // L.P)
-            q_blk, k_all, v_all = self.views_of(recv, head_dim)
-            o_blk = attn_fn(q_blk, k_all, v_all, S).contiguous()
-            outs.append((o_blk.shape[1], self._a2a_async(o_blk, o_in, o_out, L.G * Sl), o_blk, recv))
+        for st, send, done in zip(streams, sends, pend):
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                t0 = self._tick()
+                recv = done()
+                self._tock(t0, "exchange1", send.numel() * send.element_size() * (L.P - 1) // L.P)
+                if st is not None and st is not main:
+                    recv.record_stream(st)
+                q_blk, k_all, v_all = self.views_of(recv, head_dim)
+                o_blk = attn_fn(q_blk, k_all, v_all, S).contiguous()
+                outs.append((o_blk.shape[1], self._a2a_async(o_blk, o_in, o_out, L.G * Sl), o_blk, recv, st))
         hg = sum(o[0] for o in outs)
         out = sends[0].new_empty((Sl, L.G, hg, head_dim))
         a = 0
-        for hc, done, o_blk, _recv in outs:
+        for hc, done, o_blk, _recv, st in outs:
             t0 = self._tick()
+            if st is not None and st is not main:
+                main.wait_stream(st)      # the side stream's attention (and its output exchange's staging) before the caller's stream reads them
             res = done()
             self._tock(t0, "exchange2", (L.G - 1) * Sl * hc * head_dim * o_blk.element_size())
+            if st is not None and st is not main:
+                res.record_stream(main)
+                o_blk.record_stream(main)
             out[:, :, a:a + hc] = res.reshape(L.G, Sl, hc, head_dim).permute(1, 0, 2, 3)
             a += hc
         return out.reshape(Sl, L.G * hg, head_dim)

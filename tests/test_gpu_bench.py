@@ -33,7 +33,7 @@ CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
                  "data", "config", "roofline")
 
 
-@pytest.mark.parametrize("overlap", ["0", "1"])
+@pytest.mark.parametrize("overlap", ["0", "1", "2"])
 def test_bench_two_ranks_shared_gpu(overlap):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -50,7 +50,7 @@ def test_bench_two_ranks_shared_gpu(overlap):
     assert "INVALID" in j and "share one GPU" in j["INVALID"]
     par = j["config"]["parallelism"]
     assert "sp2" in par
-    assert ("pipelined" in par) == (overlap == "1"), (par, r.stderr[-1500:])   # (the first-call self-check must not have fallen back)
+    assert ("pipelined" in par) == (overlap != "0") and ("two streams" in par) == (overlap == "2"), (par, r.stderr[-1500:])   # (the first-call self-check must not have fallen back)
     ex = j["exchange"]
     assert ex["backend"] == "gloo" and ex["rccl_ranks"] == 0
     kinds = ex["per_kind"]

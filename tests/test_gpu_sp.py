@@ -81,8 +81,8 @@ def _pipelined_model_forward(overlap_expected, heads=6, lat_shape=(1, 16, 5, 18,
     return ys, model.sp.overlap, model.sp._overlap_checked
 
 
-def _worker_pipelined(rank, world, port, out_q, heads=6, lat_shape=(1, 16, 5, 18, 30)):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FVK_SP_OVERLAP="1")
+def _worker_pipelined(rank, world, port, out_q, heads=6, lat_shape=(1, 16, 5, 18, 30), mode="1"):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FVK_SP_OVERLAP=mode)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         out = _pipelined_model_forward(True, heads, lat_shape)
@@ -94,8 +94,9 @@ def _worker_pipelined(rank, world, port, out_q, heads=6, lat_shape=(1, 16, 5, 18
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])   # 1: the chunks' attention launches in stream order; 2: chunk B on a second HIP stream
 @pytest.mark.parametrize("world,heads,lat_shape", [(2, 6, (1, 16, 5, 18, 30)), (3, 6, (1, 16, 5, 18, 30)), (2, 12, (1, 16, 5, 42, 62))])
-def test_sp_pipelined_exchange_equals_sp1(world, heads, lat_shape):
+def test_sp_pipelined_exchange_equals_sp1(world, heads, lat_shape, mode):
     """FVK_SP_OVERLAP=1 on the device path (round 4): the QK-norm / RoPE pass writes TWO head-chunk send buffers (fvk_qkv_norm_rope_pack2_bf16),
     both exchanges are issued up front, the output exchanges follow their chunks
     (fastvideo_amd/distributed.py: attention_packed_pipelined).  6 heads: world 2 -> 3 heads per group (chunks of 2 + 1), world 3 -> 2 per group.
@@ -110,7 +111,7 @@ def test_sp_pipelined_exchange_equals_sp1(world, heads, lat_shape):
     ctx = mp.get_context("spawn")
     out_q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, out_q, heads, lat_shape)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, out_q, heads, lat_shape, mode)) for r in range(world)]
     for p in procs:
         p.start()
     out, overlap_kept, checked = out_q.get(timeout=300)
@@ -119,7 +120,7 @@ def test_sp_pipelined_exchange_equals_sp1(world, heads, lat_shape):
         assert p.exitcode == 0
     assert checked and overlap_kept, "the pipelined exchange disagreed with the plain exchange on its first call and was switched off"
     for i, o in enumerate(out):
-        assert torch.equal(o, ref), (f"pipelined SP={world}, forward {i}: {int((o != ref).sum())} of {ref.numel()} elements differ from SP = 1, "
+        assert torch.equal(o, ref), (f"pipelined (mode {mode}) SP={world}, forward {i}: {int((o != ref).sum())} of {ref.numel()} elements differ from SP = 1, "
                                      f"max {(o.float() - ref.float()).abs().max().item():.4g}")
 
 
