@@ -42,6 +42,7 @@ loads = (("nothing", None), ("fvk attention, 1024 keys (attn_pp2: 8 waves, 32x32
          ("fvk block-sparse attention (attn_fwd: 32x32x16, loader waves)", lambda: ops.attn_block_sparse(q4, q4, q4, bidx, bnum, bvbs, layout="bshd")),
          ("fvk gemm K = 4160 (gemm_ph: 2 waves per SIMD, 32x32x16)", lambda: ops.gemm(A2, B2)), ("torch bf16 matmul", lambda: A @ B), ("fvk gemm (gemm_w1)", lambda: ops.gemm(A, B)),
          ("fvk dense attention (8192 tokens, 12 heads)", lambda: ops.attn_dense(q4, q4, q4, layout="bshd")),
+         ("fvk dense attention, attn_w64 (488 registers, 32x32x16)", lambda: ops.attn_dense(q4, q4, q4, layout="bshd", kernel=ops.ATTN_KERNEL_W64, key_splits=1)),
          ("fvk vae conv 96->96 (conv3w)", lambda: ops.vae_conv(xc, wc, bc, T=8, H=240, W=416, kt=3, ks=3)),
          ("torch elementwise fp32 (256 MB)", lambda: xe * 1.5 + 2.0))
 sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
