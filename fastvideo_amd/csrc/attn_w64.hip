@@ -357,6 +357,7 @@ __global__ __launch_bounds__(256, 1) void attn_w64_kernel(fvk_attn_args a, int n
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BMQ = 256;
+    FVK_CLAIM_WHOLE_REGISTER_FILE();   // (488 of 512 registers used: nothing real fits beside it anyway; claimed for the rule's sake, fvk_common.h)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
