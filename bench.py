@@ -254,11 +254,8 @@ def measure_cfg_step(model, cfg, latent, ctx, steps=4, warmup=1):
             x, x16 = loop.step(i, x, x16, ctx, neg)
         torch.cuda.synchronize()
         model.attn_events = []
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         for i in range(warmup, warmup + steps):
-            if i == warmup + steps - 1:
-                e0.record()
             x, x16 = loop.step(i, x, x16, ctx, neg)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
@@ -376,7 +373,7 @@ def main():
                     help="fp8 linear path (BASELINE config 5's GEMM dtype); the contract line is the default bf16 run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-power-trace", action="store_true", help="do not sample socket power / shader clock (amdsmi, 20 Hz, a host thread) "
-                    "during the timed region (the `power` object)")
+                    "over an untimed repeat of the K steps after the timed region (the `power` object)")
     ap.add_argument("--no-cfg-step", action="store_true", help="skip the `cfg_step` sub-object (the full classifier-free-guidance denoising step: "
                     "2 forwards + fused CFG / UniPC tail, measured after the timed region)")
     ap.add_argument("--no-vae", action="store_true", help="skip the `vae` sub-object (VAE decode of the same latent, measured after the timed region)")
@@ -451,7 +448,17 @@ def main():
     model.attn_events = []
     if world > 1:
         model.sp.stats = {}  # per-exchange bytes + HIP-event pairs on the compute stream (fastvideo_amd/distributed.py)
-    sampler, power_err = None, None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = model(latent, ctx, ts)
+    sync()
+    elapsed = time.perf_counter() - t0
+    events, model.attn_events = model.attn_events, None
+    if not torch.isfinite(y.float()).all():
+        raise SystemExit("non-finite output")
+    # socket power / shader clock: a SEPARATE, untimed repeat of the same K steps straight after the timed region (the 20-Hz host
+    # sampling thread shares the GIL with the launch loop, so it must not run inside the region `value` is computed from)
+    power = None
     if rank == 0 and not args.no_power_trace:
         try:  # scripts/power_trace.py: a host thread reading socket power + shader clock at 20 Hz (measurement only; never required)
             import importlib.util
@@ -459,29 +466,26 @@ def main():
             pt = importlib.util.module_from_spec(spec)
             spec.loader.exec_module(pt)
             sampler = pt.PowerSampler(20.0, local_rank).start()
+            tp0, wall0 = time.perf_counter(), time.time()
+            for _ in range(args.steps):
+                model(latent, ctx, ts)
+            torch.cuda.synchronize()
+            wall1, tp1 = time.time(), time.perf_counter()
+            if not sampler.available:
+                sampler.stop()
+                power = {"error": "no power / clock source readable", "sampler_errors": sampler.errors[:4]}
+            else:
+                samples = sampler.stop()
+                power = pt.summarize(samples, wall0, wall1, sampler.src.name)
+                power["what"] = ("socket power and shader clock of this GPU sampled by a host thread (scripts/power_trace.py) over an UNTIMED repeat "
+                                 "of the K steps straight after the timed region; a MEASURED clock, unlike roofline.clock_from_profiled_cycles_ghz")
+                power["ms_per_step_while_sampling"] = round((tp1 - tp0) * 1e3 / args.steps, 3)
+                if sampler.errors:
+                    power["sampler_errors"] = sampler.errors[:4]
         except Exception as ex:  # noqa: BLE001
-            sampler, power_err = None, repr(ex)[:200]
-    t0 = time.perf_counter()
-    wall0 = time.time()
-    for _ in range(args.steps):
-        y = model(latent, ctx, ts)
-    sync()
-    elapsed = time.perf_counter() - t0
-    wall1 = time.time()
-    power = {"error": power_err} if power_err else None
-    if sampler is not None and not sampler.available:
-        sampler.stop()
-        power = {"error": "no power / clock source readable", "sampler_errors": sampler.errors[:4]}
-    elif sampler is not None:
-        samples = sampler.stop()
-        power = pt.summarize(samples, wall0, wall1, sampler.src.name if sampler.available else None)
-        power["what"] = ("socket power and shader clock of this GPU sampled by a host thread over the K timed steps (scripts/power_trace.py); "
-                         "a MEASURED clock, unlike roofline.clock_from_profiled_cycles_ghz")
-        if sampler.errors:
-            power["sampler_errors"] = sampler.errors[:4]
-    events, model.attn_events = model.attn_events, None
-    if not torch.isfinite(y.float()).all():
-        raise SystemExit("non-finite output")
+            power = {"error": repr(ex)[:200]}
+    if world > 1:
+        dist.barrier()
     if world > 1:
         t = torch.tensor([elapsed], device="cpu" if shared else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -496,7 +500,7 @@ def main():
         flops_launch = sum(4.0 * sq_ * skv_ * h_ * cfg.head_dim for _, _, sq_, skv_, h_ in events) / len(events)
         ran = model.dense_kernel_ran or "attn_w16"       # what the last self-attention launch actually ran (wan_dit._dense_attn)
         dense_kernel = "attn_w64" if ran == "attn_w64" else "attn_pp2" if ran == "attn_pp2" else "attn_w16"
-        kname = (f"{ran}_kernel (dense self-attention: 4 waves x 64 query rows, one wave per SIMD, "
+        kname = (f"{dense_kernel}_kernel{ran[len(dense_kernel):]} (dense self-attention: 4 waves x 64 query rows, one wave per SIMD, "
                  f"{'32x32x16' if dense_kernel == 'attn_w64' else '16x16x32'} MFMAs, 64-key sub-tiles software-pipelined in the wave)"
                  if dense_kernel != "attn_pp2" else "attn_pp2_kernel (dense self-attention, short key axis: 8-wave ping-pong kernel)")
     else:

@@ -33,9 +33,27 @@ def hipcc() -> str:
     return exe
 
 
+def _flag_stamp(probe: bool) -> str:
+    """What the library was built WITH: the flag list (FVK_EXTRA_FLAGS included) and this file (the per-file extras — unroll thresholds, the
+    no-packed-fp32 fence — live in its code).  Stored beside the library; a library whose stamp differs is stale even if it is newer than every
+    source (a flag-only change such as the packed-fp32 fence must not be skipped silently)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(repr((FLAGS, NO_PACKED_FP32, SOURCES, PROBE_SOURCES if probe else None)).encode())
+    with open(os.path.abspath(__file__).replace(".pyc", ".py"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build(probe: bool = False) -> bool:
     lib = PROBE_LIB if probe else LIB
     if not os.path.exists(lib):
+        return True
+    try:
+        with open(lib + ".flags") as f:
+            if f.read().strip() != _flag_stamp(probe):
+                return True
+    except OSError:
         return True
     t = os.path.getmtime(lib)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f != "build"] + [os.path.join(HERE, "..", "include", "fvk_amd.h")]
@@ -105,6 +123,8 @@ def _build_locked(verbose: bool, probe: bool = False) -> str:
     except OSError as e:
         os.remove(lib)
         raise RuntimeError(f"built library does not load: {e}") from e
+    with open(lib + ".flags", "w") as f:
+        f.write(_flag_stamp(probe) + "\n")
     return lib
 
 

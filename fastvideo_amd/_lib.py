@@ -46,6 +46,7 @@ SIGNATURES = {
     "fvk_v_transpose_gather_bf16": [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp],
     "fvk_gemm_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i32, vp, vp, i32, vp],
     "fvk_gemm_bf16_batched": [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i64, i32, f32, vp],
+    "fvk_gemm_vt_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, vp],
     "fvk_attn_dense_bf16": [C.POINTER(AttnArgs), vp],
     "fvk_attn_dense_kernel_bf16": [C.POINTER(AttnArgs), i32, vp],
     "fvk_attn_dense_split_bf16": [C.POINTER(AttnArgs), i32, vp, vp, vp],

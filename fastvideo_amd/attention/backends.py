@@ -81,9 +81,12 @@ class HipDenseAttentionImpl(AttentionImpl):
         elif m.dim() != 2:
             raise ValueError(f"Unsupported attention mask shape for SDPA: {tuple(attn_mask.shape)}")
         if m.dtype.is_floating_point:
-            if not bool(((m == 0) | (m == float("-inf"))).all()):
-                raise NotImplementedError("HipDenseAttentionImpl: additive masks other than 0 / -inf are not supported")
-            m = m == 0
+            # additive masks: 0 = attend; -inf, or the "large negative" HF pipelines write instead (finfo.min of the mask dtype, anything
+            # <= finfo.min / 2), = masked — after softmax both are exactly zero weight.  Any other value is a bias, not a padding mask
+            masked = m <= torch.finfo(m.dtype).min / 2
+            if not bool(((m == 0) | masked).all()):
+                raise NotImplementedError("HipDenseAttentionImpl: additive masks other than 0 / -inf (or finfo.min) are not supported")
+            m = ~masked
         elif m.dtype != torch.bool:
             m = m != 0
         if m.shape[-1] > Skv:
@@ -101,7 +104,8 @@ class HipDenseAttentionImpl(AttentionImpl):
         only.  The kernels take a key COUNT, so a sample whose valid keys are a prefix (padding at the end: the tokenizer case) runs in place
         on ``key[b, :n]``; a mask with holes compacts that sample's K / V rows first (one gather pass).  One launch per sample; the counts
         come to the host once per call (one synchronisation — this is not the Wan T2V hot path, which passes no mask).  A sample with no valid
-        key yields NaN rows in the reference (softmax over an empty set); refused here."""
+        key yields NaN rows in the reference (softmax over an empty set); refused here.  Self-attention (Sq == Skv): padded QUERY rows come
+        back as zeros, as from the reference's flash_attn_no_pad; cross-attention (every query valid): all rows computed."""
         B = query.shape[0]
         counts = mask.sum(dim=1).tolist()
         prefix = (mask.to(torch.int8).diff(dim=1) <= 0).all(dim=1).tolist()   # no False -> True transition: valid keys first
@@ -117,6 +121,10 @@ class HipDenseAttentionImpl(AttentionImpl):
                 kb = ops.gather_rows(key[b:b + 1], n, src_index=idx)
                 vb = ops.gather_rows(value[b:b + 1], n, src_index=idx)
             ops.attn_dense(query[b:b + 1], kb, vb, scale=self.softmax_scale, layout="bshd", out=out[b:b + 1])
+        if query.shape[1] == key.shape[1]:
+            # self-attention: flash_attn_no_pad unpads q with the SAME mask and pad_input returns ZERO rows for the padded queries
+            # (flash_attn.py:322-330); torch SDPA would compute them.  This backend answers to the name FLASH_ATTN: zeros.
+            out.masked_fill_(~mask[:, :, None, None], 0)
         return out
 
     def forward(self, query, key, value, attn_metadata=None):

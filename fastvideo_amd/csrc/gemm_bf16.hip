@@ -217,6 +217,28 @@ extern "C" int fvk_gemm_bf16(const void* x, const void* w, const void* bias, voi
     return gemm_impl(x, w, bias, out, M, N, K, lda, ldc, epilogue, residual, gate, rows_per_batch, 1.0f, 1, 0, 0, 0, stream);
 }
 
+// V^T = Wv · X^T + bias, written in the attention kernels' V^T layout (include/fvk_amd.h).  A plain GEMM with the operand roles exchanged:
+// "x" = the V projection's weight rows (M = d output channels), "w" = the token rows (N = S), out row stride S_pad — on gemm_w1.hip, whose w
+// staging applies the key permutation for free (a per-lane source-row term of the LDS-DMA address) and whose direct epilogue adds the
+// per-row bias and zeroes the padding columns.  The MFMA sees the same two fragments as the fused QKV GEMM, as B / A instead of A / B.
+extern "C" int fvk_gemm_vt_bf16(const void* wv, const void* x, const void* bias, void* vt, int B, int S, int d, int K, long ldx,
+                                long x_bstride, int S_pad, void* stream) {
+    FVK_CHECK(wv && x && vt, FVK_ERR_ARG, "fvk_gemm_vt_bf16: null pointer");
+    FVK_CHECK(B >= 1 && B <= 65535 && S > 0 && d > 0 && d % 128 == 0, FVK_ERR_ARG, "fvk_gemm_vt_bf16: bad B=%d S=%d d=%d (d: whole 128-channel heads)", B, S, d);
+    FVK_CHECK(S % 8 == 0 && S_pad % 64 == 0 && S_pad >= S && S_pad <= (S + 255) / 256 * 256, FVK_ERR_ARG,
+              "fvk_gemm_vt_bf16: S=%d must be a multiple of 8 and S_pad=%d a multiple of 64 in [S, round_up(S, 256)]", S, S_pad);
+    FVK_CHECK(K > 0 && ldx >= K && ldx % 8 == 0 && x_bstride % 8 == 0, FVK_ERR_ARG, "fvk_gemm_vt_bf16: bad K=%d ldx=%ld x_bstride=%ld", K, ldx, x_bstride);
+    GemmArgs a{(const bf16_t*)wv, (const bf16_t*)x, (const bf16_t*)bias, (bf16_t*)vt, nullptr, nullptr,
+               d, S, K, (long)K, (long)S_pad, d, 0, 0, 1.0f, 0L, x_bstride, (long)d * S_pad};
+    a.w_row_perm = 1;
+    a.n_store = S_pad;
+    // the w operand's row pitch is K in gemm_w1.hip (weights are dense [N, K]): the token rows must be dense too
+    FVK_CHECK(ldx == K, FVK_ERR_ARG, "fvk_gemm_vt_bf16: token rows must be dense (ldx=%ld != K=%d)", ldx, K);
+    FVK_CHECK(fvk::gemm_pp_eligible(a) && fvk::gemm_w1_eligible(a), FVK_ERR_ARG,
+              "fvk_gemm_vt_bf16: shape / alignment not served (needs K %% 128 == 0, d > 128, 16-byte aligned operands): d=%d S=%d K=%d", d, S, K);
+    return fvk::gemm_w1_vt_launch(a, B, (hipStream_t)stream);
+}
+
 extern "C" int fvk_gemm_bf16_batched(const void* x, const void* w, void* out, int batch, int M, int N, int K, long lda, long ldc,
                                      long x_bstride, long w_bstride, long out_bstride, int epilogue, float epi_scalar,
                                      void* stream) {

@@ -23,7 +23,13 @@ struct GemmArgs {
     const float* scale_a;
     const float* scale_b;
     int scale_a_rowwise, scale_b_rowwise;
+    // V^T form (fvk_gemm_vt_bf16, gemm_w1.hip only, epilogue FVK_EPI_VT): the w operand's rows (tokens) are staged with bits 2 and 3 of their
+    // row index swapped — output column p then holds token swap(p), the key order of the attention kernels' V^T layout — and columns are
+    // stored up to n_store (>= N: the zero padding of V^T)
+    int w_row_perm, n_store;
 };
+
+constexpr int FVK_EPI_VT = 5;  // internal: y = bf16(acc + bias[m]) for columns whose token exists, 0 for padding columns (see w_row_perm)
 
 // gemm_pp.hip
 bool gemm_pp_eligible(const GemmArgs& a);
@@ -37,6 +43,7 @@ int gemm_ph_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
 // gemm_w1.hip (gemm_ph's tile and unit FIFO with four 128 x 128 waves, one per SIMD; gemm_impl 5)
 bool gemm_w1_eligible(const GemmArgs& a);
 int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s);
+int gemm_w1_vt_launch(GemmArgs a, int batch, hipStream_t s);  // epilogue FVK_EPI_VT (V^T form: a.w_row_perm, a.n_store)
 // gemm_w1n.hip (round 4): the same arithmetic (byte-identical results) on a 256 x 128 workgroup tile, for problems whose 256 x 256 grid would
 // leave half the chip idle (per-rank shapes under sequence parallelism); gemm_impl 6 forces it, 14 forbids it
 bool gemm_w1n_eligible(const GemmArgs& a, int epilogue);

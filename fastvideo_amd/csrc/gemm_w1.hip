@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         const int c = (lane & 7) ^ (4 * (i & 1) + (r >> 1));
         const int cw = DIRECT ? (lane & 7) ^ (((r >> 1) & 1) | (i << 1)) : c;
         xv[i] = (int)((long)(8 * i + r) * xld) + c * 16;
-        wv[i] = (int)((long)(8 * i + r) * wld) + cw * 16;
+        // V^T form: LDS row R of a w unit takes SOURCE row swap23(R) (bits 2 and 3 of the row index exchanged; row0 is a multiple of 32, so the
+        // exchange stays inside the wave's 32 rows) — the swizzle is a function of the LDS row and does not change
+        const int rw = a.w_row_perm ? (((8 * i + r) & ~12) | ((r & 4) << 1) | ((i & 1) << 2)) : 8 * i + r;
+        wv[i] = (int)((long)rw * wld) + cw * 16;
     }
     const int d_x0 = row0 * ROWB, d_x1 = (row0 + 64) * ROWB;
     const int d_w0 = XREG + row0 * ROWB, d_w1 = XREG + (row0 + 64) * ROWB;
@@ -434,6 +437,13 @@ int launch_var(const GemmArgs& a, int epilogue, int batch, hipStream_t s) {
         case FVK_EPI_DIV: return launch<FVK_EPI_DIV, VAR>(a, batch, s);
         default: return launch<FVK_EPI_RESIDUAL_GATE, VAR>(a, batch, s);
     }
+}
+
+// V^T = Wv · X^T in the attention kernels' key order (fvk_gemm_vt_bf16): the shipped configuration only (direct epilogue: VAR 15)
+int gemm_w1_vt_launch(GemmArgs a, int batch, hipStream_t s) {
+    a.ntm = (a.M + TM - 1) / TM;
+    a.ntn = (a.N + TN - 1) / TN;
+    return launch<FVK_EPI_VT, 15>(a, batch, s);
 }
 
 bool gemm_w1_fp8_eligible(const GemmArgs& a) {

@@ -26,6 +26,10 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
     const int ncol = n0 + wn * (32 * NP) + 8 * g;  // + 32 P
     const int mrow = m0 + wm * 128 + l15;    // + 16 mb
     constexpr bool RG = EPI == FVK_EPI_RESIDUAL_GATE;
+    // V^T form (fvk_gemm_vt_bf16): the bias belongs to the output ROW (a V channel), output column p holds token swap23(p) (GemmArgs::w_row_perm)
+    // and the columns whose token does not exist (p's token >= N, up to n_store) are the zero padding of V^T
+    constexpr bool VT = EPI == fvk::FVK_EPI_VT;
+    const int n_lim = VT ? a.n_store : a.N;
     // gate rows (one per rows_per_batch output rows; rows_per_batch >= 128 here — gemm_w1_launch sends finer gates to the LDS-bounce variant):
     // the wave's 128 rows see at most TWO of them, loaded once per column group; row m takes the second one from `bnd` on
     const int mf = m0 + wm * 128;
@@ -53,7 +57,7 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
         float b8[8], sb8[FP8 ? 8 : 1], gt0[RG ? 8 : 1], gt1[RG ? 8 : 1];
         if (RG && P < NP - 1) load_res(P + 1);
         __builtin_amdgcn_sched_barrier(0);  // (no further hoisting: two groups of residual vectors in flight, not four)
-        if (a.bias && n < a.N) {
+        if (!VT && a.bias && n < a.N) {
             const bf16x8 bv = ld_bf16x8(a.bias + n);
 #pragma unroll
             for (int e = 0; e < 8; ++e) b8[e] = (float)bv[e];
@@ -91,6 +95,14 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
                     const float y0 = (float)(bf16_t)((e < 4 ? acc[2 * P][mb][e] : acc[2 * P + 1][mb][e - 4]) * (sa * sb8[e]));
                     y[e] = a.bias ? (bf16_t)(y0 + b8[e]) : (bf16_t)y0;
                 }
+            } else if constexpr (VT) {
+                const float br = (a.bias && m < a.M) ? (float)a.bias[m] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int tok = (n & ~8) | (e & 3) | ((e & 4) << 1) | ((n & 8) >> 1);  // swap23(n + e): n is a multiple of 8
+                    const float v = (e < 4 ? acc[2 * P][mb][e] : acc[2 * P + 1][mb][e - 4]) + br;
+                    y[e] = tok < a.N ? (bf16_t)v : (bf16_t)0.f;
+                }
             } else {
 #pragma unroll
                 for (int e = 0; e < 4; e += 2) {  // (pairs: v_pk_add_f32 — the same sums)
@@ -100,7 +112,7 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
                     y[4 + e] = (bf16_t)hi[0]; y[5 + e] = (bf16_t)hi[1];
                 }
             }
-            if (m < a.M && n < a.N) {
+            if (m < a.M && n < n_lim) {
                 if (EPI == FVK_EPI_GELU_TANH) {
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {  // pairs: packed fp32 arithmetic (this epilogue runs with the matrix pipe idle)

@@ -69,11 +69,21 @@ def _check_bf16(*ts):
             raise RuntimeError(f"fastvideo_amd kernels are bf16 only, got {t.dtype}")
 
 
+def _check_cuda(*ts):
+    """Called after the argument checks, right before an op is dispatched: said here in one line — the dispatcher's own refusal of a CPU
+    tensor is a page long."""
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError("fastvideo_amd: q / k / v must be ROCm device tensors (the HIP path has no CPU fallback)")
+
+
 def block_sparse_attn_from_indices(q, k, v, q2k_idx, q2k_num, variable_block_sizes):
-    """ref: fastvideo_kernel/block_sparse_attn.py (``block_sparse_attn_from_indices``) -> (o, lse)."""
+    """ref: fastvideo_kernel/block_sparse_attn.py (``block_sparse_attn_from_indices``) -> (o, lse).  Registered as
+    ``torch.ops.fastvideo_kernel.block_sparse_attn_gfx950`` beside the reference's ``_triton`` / ``_sm90`` ops (block_sparse_attn.py:103-145,
+    224-267); forward only (the reference registers backward ops for training, out of scope here: SURVEY §8)."""
     _check_bf16(q, k, v)
-    return ops.attn_block_sparse(q, k, v, q2k_idx.int(), q2k_num.int(), variable_block_sizes.int(), layout="bhsd",
-                                 return_lse=True)
+    _check_cuda(q, k, v)
+    return torch.ops.fastvideo_kernel.block_sparse_attn_gfx950(q, k, v, q2k_idx, q2k_num, variable_block_sizes)
 
 
 def block_sparse_attn(q, k, v, block_map, variable_block_sizes):
@@ -109,7 +119,10 @@ def video_sparse_attn(q, k, v, variable_block_sizes, q_variable_block_sizes, top
     vbs = variable_block_sizes.to(device=q.device, dtype=torch.int32)
     qvbs = q_variable_block_sizes.to(device=q.device, dtype=torch.int32)
 
-    return _vsa_forward(q, k, v, vbs, qvbs, topk, compress_attn_weight, "bhsd", return_intermediates, block_elements)
+    _check_cuda(q, k, v)
+    if return_intermediates:  # test / debug form: the composition's intermediates as a dict, not an op
+        return _vsa_forward(q, k, v, vbs, qvbs, topk, compress_attn_weight, "bhsd", True, block_elements)
+    return torch.ops.fastvideo_kernel.video_sparse_attn_gfx950(q, k, v, vbs, qvbs, int(topk), block_elements, compress_attn_weight, "bhsd")
 
 
 def _expand_block_lists(idx, num, vbs, block_elements):
@@ -184,28 +197,61 @@ def video_sparse_attn_bshd(q, k, v, variable_block_sizes, q_variable_block_sizes
         raise ValueError(f"variable_block_sizes must have length kv_num_blocks={k.shape[1] // block_size}, got {vbs.numel()}")
     if qvbs.numel() != q.shape[1] // block_size:
         raise ValueError(f"q_variable_block_sizes must have length q_num_blocks={q.shape[1] // block_size}, got {qvbs.numel()}")
-    return _vsa_forward(q, k, v, vbs, qvbs, topk, compress_attn_weight, "bshd", False, block_size)
+    _check_cuda(q, k, v)
+    return torch.ops.fastvideo_kernel.video_sparse_attn_gfx950(q, k, v, vbs, qvbs, int(topk), int(block_size), compress_attn_weight, "bshd")
 
 
 _STA_CANVAS = {"30x48x80": (30, 48, 80), "36x48x48": (36, 48, 48), "18x48x80": (18, 48, 80)}
 
 
-def sliding_tile_attention(q, k, v, window_size, text_length=0, has_text=False, seq_shape="18x48x80",
-                           tile_size=(6, 8, 8)):
-    """ref: fastvideo_kernel/ops.py:21-62.  q,k,v [B,H,S,D] bf16, tokens in tile-major order; ``window_size`` is a
-    per-head list of (t,h,w) windows in tiles.  ``seq_shape`` is "TxHxW" (the reference's three canvases or any
-    other canvas divisible by ``tile_size`` — the reference kernels hard-code theirs).
-    Text tokens (HunyuanVideo/StepVideo variants) are not part of the Wan path and are refused."""
-    if has_text or text_length:
-        raise NotImplementedError("sliding_tile_attention: text tokens are not supported on the Wan T2V path")
+def sliding_tile_attention(q, k, v, window_size, text_length, has_text=True, seq_shape="30x48x80", tile_size=(6, 8, 8)):
+    """ref: fastvideo_kernel/ops.py:21-62 — same positional arguments and defaults (``text_length`` required, ``has_text=True``,
+    ``seq_shape="30x48x80"``).  q,k,v [B,H,S,D] bf16, image tokens first in tile-major order; ``window_size`` is a per-head list of
+    (t,h,w) windows in tiles.  ``seq_shape`` is "TxHxW" (the reference's three canvases or any other canvas divisible by
+    ``tile_size`` — the reference kernels hard-code theirs).
+
+    ``has_text`` (HunyuanVideo / StepVideo): rows past the canvas are text tokens, the first ``text_length`` of them valid.  Mask rule of
+    fastvideo-kernel/tests/support_flex_sta.py:52-55: an image query attends its window plus the valid text keys, a text query attends
+    every image key plus the valid text keys.  As in the reference (ops.py:36-43) the sequence is padded up to whole 384-row tiles with
+    copies of its last rows and the result sliced back.  ``has_text=False``: the sequence is exactly the canvas; ``text_length`` is ignored
+    (the reference hands it to a kernel that does not read it then).
+
+    Registered as ``torch.ops.fastvideo_kernel.sliding_tile_attention_gfx950`` (opaque to torch.compile, fake kernel = empty_like(q))."""
     _check_bf16(q, k, v)
     canvas = _STA_CANVAS.get(seq_shape) or tuple(int(x) for x in seq_shape.split("x"))
-    if any(c % t for c, t in zip(canvas, tile_size)):
-        raise ValueError(f"canvas {canvas} is not divisible by tile {tile_size}")
-    tiles = tuple(c // t for c, t in zip(canvas, tile_size))
+    if len(canvas) != 3 or any(c % t for c, t in zip(canvas, tile_size)):
+        raise ValueError(f"canvas {canvas} is not divisible by tile {tuple(tile_size)}")
     if len(window_size) != q.shape[1]:
         raise ValueError(f"window_size must list one (t,h,w) per head ({q.shape[1]}), got {len(window_size)}")
-    return sliding_tile_attention_canvas(q, k, v, tiles, math.prod(tile_size), window_size, layout="bhsd")
+    img = canvas[0] * canvas[1] * canvas[2]
+    if has_text:
+        if q.shape[2] < img or not 0 <= int(text_length) <= q.shape[2] - img:
+            raise ValueError(f"sliding_tile_attention: {q.shape[2]} rows do not hold the {img}-token canvas {seq_shape} plus {text_length} text tokens")
+    elif q.shape[2] != img:
+        raise ValueError(f"sliding_tile_attention: {q.shape[2]} rows != the {img} tokens of canvas {seq_shape} (has_text=False)")
+    flat = [int(x) for w in window_size for x in w]
+    _check_cuda(q, k, v)
+    return torch.ops.fastvideo_kernel.sliding_tile_attention_gfx950(q, k, v, flat, int(text_length) if has_text else -1, list(canvas),
+                                                                    [int(t) for t in tile_size])
+
+
+def _sta_impl(q, k, v, windows_flat, text_length, canvas, tile_size):
+    """Body of the registered op.  text_length < 0: no text rows."""
+    tok = math.prod(tile_size)
+    tiles = tuple(c // t for c, t in zip(canvas, tile_size))
+    windows = tuple(tuple(windows_flat[3 * i:3 * i + 3]) for i in range(len(windows_flat) // 3))
+    if text_length < 0:
+        return sliding_tile_attention_canvas(q, k, v, tiles, tok, windows, layout="bhsd")
+    if tok < 256 or tok % 128:
+        raise NotImplementedError(f"sliding_tile_attention with text rows needs tiles of 256 / 384 / 512 ... tokens (tile {tuple(tile_size)} holds {tok})")
+    S = q.shape[2]
+    pad = (-S) % tok
+    if pad:  # ops.py:36-43: whole tiles, the filler is masked (keys) or sliced off (queries)
+        q, k, v = (torch.cat([t, t[:, :, -pad:]], dim=2) for t in (q, k, v))
+    img = math.prod(canvas)
+    idx, num, sizes = _canvas_tile_lists(tiles, tok, windows, q.shape[0], q.device, text_rows=S + pad - img, text_length=int(text_length))
+    o = ops.attn_tile_lists(q.contiguous(), k.contiguous(), v.contiguous(), idx, num, sizes, tok, None, layout="bhsd")
+    return o[:, :, :S] if pad else o
 
 
 def sliding_tile_attention_canvas(q, k, v, tiles, tile_tokens, window_size, layout="bhsd"):
@@ -224,10 +270,13 @@ def sliding_tile_attention_canvas(q, k, v, tiles, tile_tokens, window_size, layo
 _CANVAS_LISTS = {}
 
 
-def _canvas_tile_lists(tiles, tok, windows, batch, device):
+def _canvas_tile_lists(tiles, tok, windows, batch, device, text_rows=0, text_length=0):
     """Per-(head, tile) KV lists of 64-token blocks for a whole-tile canvas (every block full), cached per geometry on the device.
-    Window rule: fastvideo-kernel/tests/support_flex_sta.py:44-51 (clamped centre, integer k//2; identical to fvk_attn_sta_bf16's)."""
-    key = (tiles, tok, windows, batch, str(device))
+    Window rule: fastvideo-kernel/tests/support_flex_sta.py:44-51 (clamped centre, integer k//2; identical to fvk_attn_sta_bf16's).
+    ``text_rows`` (a multiple of ``tok``) rows follow the canvas, the first ``text_length`` valid (support_flex_sta.py:52-55): their
+    64-row blocks join every image tile's list with their valid-key counts, and the text rows form extra query tiles whose list is
+    every image block plus the valid text blocks."""
+    key = (tiles, tok, windows, batch, str(device), text_rows, text_length)
     hit = _CANVAS_LISTS.get(key)
     if hit is not None:
         return hit
@@ -245,15 +294,25 @@ def _canvas_tile_lists(tiles, tok, windows, batch, device):
                   for z in win(c, tiles[2], w[2]) for s_ in range(sub)]
                  for a in range(tiles[0]) for b in range(tiles[1]) for c in range(tiles[2])]
         per_head[w] = lists
+    sizes = np.full((n_tiles * sub + text_rows // 64,), 64, dtype=np.int32)
+    if text_rows:
+        if text_rows % tok:
+            raise ValueError(f"text rows ({text_rows}) must fill whole {tok}-row tiles")
+        sizes[n_tiles * sub:] = np.clip(text_length - 64 * np.arange(text_rows // 64), 0, 64)
+        text_blocks = [n_tiles * sub + j for j in range(text_rows // 64) if sizes[n_tiles * sub + j] > 0]
+        text_query = list(range(n_tiles * sub)) + text_blocks
+        for w in per_head:
+            per_head[w] = [l + text_blocks for l in per_head[w]] + [text_query] * (text_rows // tok)
+    n_lists = n_tiles + text_rows // tok
     mx = max(len(l) for ls in per_head.values() for l in ls)
-    idx = np.zeros((len(windows), n_tiles, mx), dtype=np.int32)
-    num = np.zeros((len(windows), n_tiles), dtype=np.int32)
+    idx = np.zeros((len(windows), n_lists, mx), dtype=np.int32)
+    num = np.zeros((len(windows), n_lists), dtype=np.int32)
     for h_, w in enumerate(windows):
         for t, l in enumerate(per_head[w]):
             idx[h_, t, :len(l)], num[h_, t] = l, len(l)
     out = (torch.from_numpy(idx).to(device)[None].expand(batch, -1, -1, -1).contiguous(),
            torch.from_numpy(num).to(device)[None].expand(batch, -1, -1).contiguous(),
-           torch.full((n_tiles * sub,), 64, dtype=torch.int32, device=device))
+           torch.from_numpy(sizes).to(device))
     if len(_CANVAS_LISTS) >= 16:
         _CANVAS_LISTS.clear()
     _CANVAS_LISTS[key] = out
@@ -351,6 +410,46 @@ def sliding_tile_block_lists(grid, tile_size=(6, 8, 8), window=(3, 3, 3), group_
                 q2k_num=torch.from_numpy(num), q_block=qb, S_pad=len(vbs) * tok, num_tiles=nt,
                 density=float(sum(int(bsz[i * (qb // 64):(i + 1) * (qb // 64)].sum()) * sum(int(bsz[b]) for b in l)
                                   for i, l in enumerate(lists))) / float(n_tok)**2)  # attended (query, key) pairs / S^2
+
+
+# ------------------------------------------------------------------ torch.library registration
+# The reference wraps every kernel entry in torch.library.custom_op + register_fake (fastvideo_kernel/block_sparse_attn.py:103-145,224-267) so
+# that torch.compile (component_loader.py:1127 ``enable_torch_compile``) sees ONE opaque node per kernel instead of graph-breaking on the
+# foreign call.  Same here: the ctypes calls into libfvk_amd.so live inside three ops in the reference's own ``fastvideo_kernel`` namespace,
+# named like its per-backend ops (``_triton`` / ``_sm90`` -> ``_gfx950``); the fake kernels give shapes / dtypes only.  device_types="cuda"
+# (ROCm tensors are "cuda" tensors): a CPU tensor is refused by the dispatcher, there is no CPU fallback.  Forward only.
+@torch.library.custom_op("fastvideo_kernel::block_sparse_attn_gfx950", mutates_args=(), device_types="cuda")
+def _block_sparse_attn_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q2k_idx: torch.Tensor, q2k_num: torch.Tensor,
+                          variable_block_sizes: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor]:
+    return ops.attn_block_sparse(q, k, v, q2k_idx.int(), q2k_num.int(), variable_block_sizes.int(), layout="bhsd", return_lse=True)
+
+
+@torch.library.register_fake("fastvideo_kernel::block_sparse_attn_gfx950")
+def _block_sparse_attn_fake(q, k, v, q2k_idx, q2k_num, variable_block_sizes):
+    return torch.empty_like(q), torch.empty((q.shape[0], q.shape[1], q.shape[2]), device=q.device, dtype=torch.float32)
+
+
+@torch.library.custom_op("fastvideo_kernel::video_sparse_attn_gfx950", mutates_args=(), device_types="cuda")
+def _video_sparse_attn_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, variable_block_sizes: torch.Tensor,
+                          q_variable_block_sizes: torch.Tensor, topk: int, block_elements: int, compress_attn_weight: torch.Tensor | None,
+                          layout: str) -> torch.Tensor:
+    return _vsa_forward(q, k, v, variable_block_sizes, q_variable_block_sizes, topk, compress_attn_weight, layout, False, block_elements)
+
+
+@torch.library.register_fake("fastvideo_kernel::video_sparse_attn_gfx950")
+def _video_sparse_attn_fake(q, k, v, variable_block_sizes, q_variable_block_sizes, topk, block_elements, compress_attn_weight, layout):
+    return torch.empty_like(q)
+
+
+@torch.library.custom_op("fastvideo_kernel::sliding_tile_attention_gfx950", mutates_args=(), device_types="cuda")
+def _sliding_tile_attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, windows: list[int], text_length: int, canvas: list[int],
+                               tile_size: list[int]) -> torch.Tensor:
+    return _sta_impl(q, k, v, windows, text_length, canvas, tile_size)
+
+
+@torch.library.register_fake("fastvideo_kernel::sliding_tile_attention_gfx950")
+def _sliding_tile_attention_fake(q, k, v, windows, text_length, canvas, tile_size):
+    return torch.empty_like(q)
 
 
 __all__ = [

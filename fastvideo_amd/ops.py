@@ -158,7 +158,11 @@ def rmsnorm_rope(tensors, weights=None, cos=None, sin=None, head_dim=128, seq_le
     if row_maps is not None:
         if len(row_maps) != n or any(o.stride(0) != ostride or o.stride(1) != 1 for o in outs):
             raise RuntimeError("rmsnorm_rope: row_maps needs one entry per tensor and outputs with one common row stride")
-        maps = [None if r is None else _chk(r, torch.int32, "row_map").contiguous() for r in row_maps]
+        # contiguous maps only: a ``.contiguous()`` copy would be a fresh tensor object on every call, and _check_row_map (keyed on the
+        # object) would pay its device sync per call instead of once per geometry
+        if any(r is not None and not r.is_contiguous() for r in row_maps):
+            raise RuntimeError("rmsnorm_rope: row maps must be contiguous int32 tensors")
+        maps = [None if r is None else _chk(r, torch.int32, "row_map") for r in row_maps]
         if any(r is not None and r.numel() != M for r in maps):
             raise RuntimeError("rmsnorm_rope: every row map must have one entry per input row")
         for r, o in zip(maps, outs):
@@ -237,6 +241,33 @@ def v_transpose(v, src_rows=None):
         if src_rows.numel() != S_pad:
             raise RuntimeError(f"v_transpose: src_rows must cover whole 128-key tiles (got {src_rows.numel()} entries)")
         _lib.call("fvk_v_transpose_gather_bf16", _p(v), _p(vt), _p(src_rows), B, S, H, D, v.stride(1), v.stride(0), v.stride(2), S_pad, _stream())
+    return vt
+
+
+def gemm_vt_eligible(x, w) -> bool:
+    """Whether fvk_gemm_vt_bf16 serves V^T = w · x^T for token rows x [B, S, K] (or [S, K]) and V weight rows w [d, K]."""
+    K = x.shape[-1]
+    S = x.shape[-2]
+    return (x.dtype == BF16 and w.dtype == BF16 and K % 128 == 0 and w.shape[0] % 128 == 0 and w.shape[0] > 128 and S % 8 == 0
+            and x.is_contiguous() and w.is_contiguous())
+
+
+def gemm_vt(x, w, bias=None):
+    """V projection written straight into the attention kernels' V^T layout (fvk_gemm_vt_bf16): x bf16 [B, S, K] dense token rows, w bf16
+    [d, K] = the V rows of the QKV weight, bias bf16 [d].  -> Vt [B, d / 128, 128, S_pad] — what ``v_transpose(linear(x, w, bias))`` returns,
+    bit for bit, without writing V, reading it back and a layout pass."""
+    _chk(x, BF16, "x"), _chk(w, BF16, "w")
+    if x.dim() == 2:
+        x = x[None]
+    B, S, K = x.shape
+    d = w.shape[0]
+    if not gemm_vt_eligible(x, w) or w.shape[1] != K:
+        raise RuntimeError(f"gemm_vt: shape not served (x {tuple(x.shape)}, w {tuple(w.shape)}): use gemm + v_transpose")
+    if bias is not None:
+        _chk(bias, BF16, "bias")
+    S_pad = (S + 127) // 128 * 128
+    vt = torch.empty((B, d // 128, 128, S_pad), dtype=BF16, device=x.device)
+    _lib.call("fvk_gemm_vt_bf16", _p(w), _p(x), _p(bias), _p(vt), B, S, d, K, x.stride(1), x.stride(0), S_pad, _stream())
     return vt
 
 

@@ -136,6 +136,10 @@ class DenoisingLoopHip:
         # cfg_batch: the classifier-free-guidance pair as one batch-2 forward (see ``step``); off = the reference's two forwards per step
         # (denoising.py:497-560).  Needs equal-length prompt / negative embeddings (the pipelines pad both to 512 text tokens).
         self.cfg_batch = bool(cfg_batch)
+        if self.cfg_batch and any(getattr(m, "quant", None) == "fp8" for m in (transformer, transformer_2) if m is not None):
+            raise ValueError("DenoisingLoopHip(cfg_batch=True): a per-tensor fp8 model quantises its activations with ONE absmax over the whole "
+                             "[B*S, d] matrix, so the batched pair would share a scale and differ from the reference's two forwards; use "
+                             "quantization='fp8_channel' (per-token scales) or cfg_batch=False")
         self.model_2 = transformer_2
         self.g2 = float(guidance_scale if guidance_scale_2 is None else guidance_scale_2)
         self.boundary_timestep = None if boundary_ratio is None else boundary_ratio * num_train_timesteps
@@ -154,8 +158,10 @@ class DenoisingLoopHip:
     def step(self, i: int, x, x16, prompt_embeds, negative_prompt_embeds=None):
         """Denoising step i of the schedule: DiT forward(s) on the bf16 latent ``x16`` + the fused CFG / UniPC tail on the fp32 latent ``x``.
         Returns the next (x, x16).  With ``cfg_batch`` the conditional / unconditional pair runs as ONE batch-2 forward (latent repeated,
-        embeddings stacked): every kernel of the model is row- and batch-independent, so each half equals its stand-alone forward bit for bit
-        (tests/test_gpu_sched.py), while the pair shares every launch — half the launches, twice the grid per launch."""
+        embeddings stacked): every kernel of a bf16 / fp8_channel model is row- and batch-independent (per-token scales; the split-KV count of
+        an under-filled attention grid is taken from one sample's grid), so each half equals its stand-alone forward bit for bit
+        (tests/test_gpu_sched.py), while the pair shares every launch — half the launches, twice the grid per launch.  A per-TENSOR fp8 model
+        is refused at construction: its activation scale is one absmax over the whole [B*S, d] matrix, which the pair would share."""
         model, g = self.expert_for(float(self.stepper.timesteps[i]))
         use_cfg = negative_prompt_embeds is not None and self.g > 1.0  # batch-level switch (pipeline_batch_info.py:270-272)
         t = self.stepper.timesteps[i].to(device=x.device, dtype=torch.float32).reshape(1)

@@ -79,6 +79,7 @@ class WanTransformer3DModelHip:
         self._tune = None
         self._forwards = 0
         self.vsa_trace = None    # set to a list to collect every layer's VSA block mask (tests)
+        self.vt_gemm = True      # dense, single GPU, bf16: V projection written as V^T by its own GEMM (ops.gemm_vt); False = fused QKV + layout pass (A/B, tests)
 
     # ------------------------------------------------------------------ weights
     def _load(self, sd):
@@ -225,16 +226,20 @@ class WanTransformer3DModelHip:
         self.attn_tune_report = {"attn_w16_ms": round(med[ops.ATTN_KERNEL_W16], 4), "attn_w64_ms": round(med[ops.ATTN_KERNEL_W64], 4),
                                  "launches_timed": len(ev) - 2, "kept": "attn_w16" if self.attn_kernel == ops.ATTN_KERNEL_W16 else "attn_w64"}
 
-    def _dense_attn(self, q4, k4, v4):
+    def _dense_attn(self, q4, k4, v4, vt=None):
         """Dense self-attention of ALL batch elements in ONE launch: q4 [B,Sq,h,D], k4 / v4 [B,Skv,h,D] (strided views ok) -> o [B,Sq,h,D].
+        ``vt``: a ready V^T [B,h,D,Skv_pad] (the V projection written in that layout by ops.gemm_vt; then v4 is ignored).
         The reference runs the classifier-free-guidance pair as two forwards (denoising.py:497-560); batched here (DenoisingLoopHip(cfg_batch=
         True)) the pair shares every launch — per sample the arithmetic is the same (rows and batch elements are independent in every kernel)."""
-        vt = ops.v_transpose(v4)
+        if vt is None:
+            vt = ops.v_transpose(v4)
         kern, tune = self.attn_kernel, self._tune
         # key runs are decided for the rank's WHOLE head group (the pipelined exchange launches it as two head chunks on two streams: they
         # fill the chip together, and must run the arithmetic of the un-chunked launch)
         heads = max(q4.shape[2], self.sp.lay.heads_per_group if self.sp.lay.P > 1 else q4.shape[2])
-        splits = ops.attn_key_splits(-(-q4.shape[1] // 256) * heads * q4.shape[0], -(-k4.shape[1] // 128)) if q4.shape[1] >= 256 else 1
+        # ... and from ONE sample's grid: the split count sets the merge rounding, so a batch-2 (cfg_batch) launch must take the count its
+        # samples take alone, or its halves would not equal their stand-alone forwards bit for bit at under-filled geometries (ADVICE r4)
+        splits = ops.attn_key_splits(-(-q4.shape[1] // 256) * heads, -(-k4.shape[1] // 128)) if q4.shape[1] >= 256 else 1
         long_keys = q4.shape[1] >= 256 and k4.shape[1] >= 2048
         if splits > 1 or not long_keys:
             # short key axes take the 8-wave kernel and split-KV grids always run attn_w16 (fvk_attn_dense_split_bf16): nothing to choose
@@ -551,20 +556,29 @@ class WanTransformer3DModelHip:
             # (byte-identical to the stand-alone quantiser; no bf16 copy, no absmax + quantise passes)
             fq = "only" if self.quant == "fp8_channel" else None
             nh = ops.ln_modulate(x, mul=mul_i, add=shift_i, eps=self.eps, rows_per_batch=rpb, fp8_rowwise=fq if b["n_qkv"] != 4 else None)
-            if self.quant and b["n_qkv"] == 4:
+            # single GPU, dense attention, bf16 linears (the contract step): the V projection is a GEMM of its own that writes V^T in the
+            # attention kernels' layout (ops.gemm_vt: the token rows as the GEMM's w operand, key permutation in its staging addresses) —
+            # bit-identical to the fused QKV GEMM + the V^T layout pass, without writing V, reading it back and a launch of that pass
+            vt_i = None
+            if (self.vt_gemm and P == 1 and self.attention == "dense" and not self.quant and b["n_qkv"] == 3
+                    and ops.gemm_vt_eligible(nh.view(B, Sl, d), b["qkv_w"][2 * d:])):
+                qkv = ops.gemm(nh, b["qkv_w"][:2 * d], b["qkv_b"][:2 * d])       # [B*S, 2d]: q | k
+                vt_i = ops.gemm_vt(nh.view(B, Sl, d), b["qkv_w"][2 * d:], b["qkv_b"][2 * d:])
+            elif self.quant and b["n_qkv"] == 4:
                 qkv = torch.empty((B * Sl, 4 * d), dtype=BF16, device=dev)
                 self._lin(nh, b, "qkv", b["qkv_b"], out=qkv[:, :3 * d])
                 ops.gemm(nh, b["gate_w"], b["gate_b"], out=qkv[:, 3 * d:])
             else:
                 qkv = self._lin(nh, b, "qkv", b["qkv_b"])  # [B*Sl, 3d (+d gate)]; fp8: nh quantised once for q, k and v (wants_prequantized_input)
             nq = b["n_qkv"]
-            batched = B > 1 and P == 1 and self.attention == "dense"
+            batched = (B > 1 or vt_i is not None) and P == 1 and self.attention == "dense"
             attn = torch.empty((B * Sl, d), dtype=BF16, device=dev) if (B > 1 and not batched) else None
             if batched:
                 # all batch elements (the classifier-free-guidance pair) in one QK-norm / RoPE pass, one V^T pass and ONE attention launch:
                 # positions are row % S in the norm pass, the attention kernels take the batch as a grid dimension
                 qn, kn = ops.rmsnorm_rope([qkv[:, :d], qkv[:, d:2 * d]], [b["nq_w"], b["nk_w"]], cos, sin, head_dim=D, seq_len=S, eps=self.eps)
-                attn = self._dense_attn(qn.view(B, S, H, D), kn.view(B, S, H, D), qkv[:, 2 * d:3 * d].view(B, S, H, D)).view(B * S, d)
+                attn = self._dense_attn(qn.view(B, S, H, D), kn.view(B, S, H, D), None if vt_i is not None else qkv[:, 2 * d:3 * d].view(B, S, H, D),
+                                        vt=vt_i).view(B * S, d)
             for bi in range(0 if batched else B):
                 rows = qkv[bi * Sl:(bi + 1) * Sl]
                 gate = rows[:, 3 * d:4 * d].view(Sl, H, D) if nq == 4 else None

@@ -151,6 +151,15 @@ int fvk_v_transpose_gather_bf16(const void* v, void* vt, const int32_t* src_rows
 int fvk_gemm_bf16(const void* x, const void* w, const void* bias, void* out, int M, int N, int K, long lda,
                   long ldc, int epilogue, const void* residual, const float* gate, int rows_per_batch,
                   void* stream);
+/* V projection written STRAIGHT into the attention kernels' V^T layout (round 5; replaces `to_v` = F.linear, linear.py:146-156, followed by the
+ * layout pass fvk_v_transpose_bf16):
+ *   vt[b, n, p] = bf16( sum_k wv[n,k] * x[b, key(p), k] + bias[n] )   for key(p) < S,   0 for the padding positions up to S_pad
+ * wv bf16 [d, K] (the V rows of the fused QKV weight), x bf16 [B, S, K] (dense rows, batch stride x_bstride elements), bias bf16 [d] or NULL,
+ * vt bf16 [B, d / 128, 128, S_pad]; key(p) = p with bits 2 and 3 of its index exchanged (fvk_v_transpose_bf16's order).  Same products, same
+ * k order and the same rounding points as fvk_gemm_bf16 followed by fvk_v_transpose_bf16 — the MFMA operands trade places (bit-identical:
+ * tests/test_gpu_kernels.py).  Needs K % 128 == 0, d % 128 == 0 and > 128, S % 8 == 0, S_pad % 64 == 0 in [S, round_up(S, 256)]. */
+int fvk_gemm_vt_bf16(const void* wv, const void* x, const void* bias, void* vt, int B, int S, int d, int K, long ldx,
+                     long x_bstride, int S_pad, void* stream);
 /* `batch` independent GEMMs (no bias): operand b at x + b*x_bstride etc.  Used for the VSA coarse scores
  * q_c · k_c^T / sqrt(D) per (batch, head) (ref: fastvideo_kernel/ops.py:113).  epilogue NONE or DIV. */
 int fvk_gemm_bf16_batched(const void* x, const void* w, void* out, int batch, int M, int N, int K, long lda, long ldc,

@@ -174,11 +174,39 @@ def block_sparse_attn(q, k, v, block_map: np.ndarray, vbs: np.ndarray, block: in
     return torch.matmul(torch.softmax(s, dim=-1), v.float())
 
 
-def video_sparse_attn(q, k, v, vbs, q_vbs, topk: int, block_elements: int = 64, gate=None, mask_override=None):
+def block_sparse_attn_gathered(q, k, v, block_map: np.ndarray, vbs: np.ndarray, block: int = 64) -> torch.Tensor:
+    """The SAME arithmetic as ``block_sparse_attn`` (exact fp32 softmax over the valid columns of the selected KV blocks, scale
+    1/sqrt(D)), evaluated one query block at a time over ITS selected blocks only, so that the real geometry (S_pad = 39 936, 12 heads,
+    top-125 of 624 blocks) needs megabytes instead of the 76 GB of a dense [B,H,S,S] score tensor.  Equal to the dense-mask form up to
+    fp32 summation order (tests/test_oracle_chunked.py).  q,k,v [B,H,S_pad,D] -> fp32."""
+    B, H, S, D = q.shape
+    nq = S // block
+    out = torch.zeros((B, H, S, D), dtype=torch.float32)
+    vb = torch.from_numpy(vbs.astype(np.int64))
+    scale = D**-0.5
+    kf, vf = k.float(), v.float()
+    ar = torch.arange(block)
+    for b in range(B):
+        for h in range(H):
+            kb = kf[b, h].view(-1, block, D)
+            vbk = vf[b, h].view(-1, block, D)
+            for i in range(nq):
+                sel = torch.from_numpy(np.nonzero(block_map[b, h, i])[0])
+                if sel.numel() == 0:
+                    continue
+                ok = (ar[None, :] < vb[sel][:, None]).reshape(-1)                    # valid columns of the selected blocks
+                ks, vs = kb[sel].reshape(-1, D)[ok], vbk[sel].reshape(-1, D)[ok]
+                sc = (q[b, h, i * block:(i + 1) * block].float() @ ks.T) * scale
+                out[b, h, i * block:(i + 1) * block] = torch.softmax(sc, dim=-1) @ vs
+    return out
+
+
+def video_sparse_attn(q, k, v, vbs, q_vbs, topk: int, block_elements: int = 64, gate=None, mask_override=None, gathered: bool = False):
     """``video_sparse_attn`` — fastvideo-kernel/python/fastvideo_kernel/ops.py:65-133.
     q,k,v(,gate) [B,H,S_pad,D] bf16.  Returns (out bf16, dict of intermediates).
     ``mask_override`` (bool [B,H,Nq,Nkv]) replaces the top-k selection: tests feed the mask the device computed from ITS coarse
-    scores (a bf16 ulp in one score can flip a near-tie), so that the composite is compared block for block."""
+    scores (a bf16 ulp in one score can flip a near-tie), so that the composite is compared block for block.  ``gathered``: evaluate
+    the sparse branch block by block (block_sparse_attn_gathered) — the form that fits the real geometry in memory."""
     B, H, S, D = q.shape
     q_c = block_mean(q, q_vbs, block_elements)
     k_c = block_mean(k, vbs, block_elements)
@@ -188,7 +216,7 @@ def video_sparse_attn(q, k, v, vbs, q_vbs, topk: int, block_elements: int = 64, 
     out_c = torch.matmul(attn, v_c)
     out_c = out_c.view(B, H, S // block_elements, 1, D).repeat(1, 1, 1, block_elements, 1).view(B, H, S, D)
     mask = topk_mask_bisect(scores.float().numpy(), topk) if mask_override is None else mask_override
-    out_s = block_sparse_attn(q, k, v, mask, vbs, block_elements).to(q.dtype)
+    out_s = (block_sparse_attn_gathered if gathered else block_sparse_attn)(q, k, v, mask, vbs, block_elements).to(q.dtype)
     out = out_c * gate + out_s if gate is not None else out_c + out_s
     return out, dict(q_c=q_c, k_c=k_c, v_c=v_c, scores=scores, mask=mask, out_c=out_c, out_s=out_s)
 
@@ -260,3 +288,31 @@ def sta_mask_ragged(grid_thw, kernel, tile_thw) -> torch.Tensor:
         lo, hi = win[idx, 0], win[idx, 1]
         m &= (idx[None, :] >= lo[:, None]) & (idx[None, :] < hi[:, None])
     return m
+
+
+def sta_attention_ragged(q, k, v, scale: float, grid_thw, kernel, tile_thw) -> torch.Tensor:
+    """Exact fp32 attention under ``sta_mask_ragged(grid_thw, kernel, tile_thw)`` without building the [S,S] mask or score tensor: every
+    query TILE (all of its tokens share one window) attends the tokens whose tile lies in its clamped-centre window.  Tokens in raster
+    order (t,h,w).  Equal to wan_oracle.attention_fp32_ref(q, k, v, scale, sta_mask_ragged(...)) up to fp32 summation order
+    (tests/test_oracle_chunked.py); fits BASELINE config 3's real geometry (grid (21,30,52), tile (6,8,8): 112 tiles of <= 384 tokens,
+    windows of <= 27 tiles).  q,k,v [B,H,S,D] -> fp32 [B,H,S,D]."""
+    T, H_, W_ = grid_thw
+    nt = tuple(-(-g // t) for g, t in zip(grid_thw, tile_thw))
+    t_idx = torch.arange(T).view(T, 1, 1).expand(T, H_, W_).reshape(-1) // tile_thw[0]
+    h_idx = torch.arange(H_).view(1, H_, 1).expand(T, H_, W_).reshape(-1) // tile_thw[1]
+    w_idx = torch.arange(W_).view(1, 1, W_).expand(T, H_, W_).reshape(-1) // tile_thw[2]
+    qf, kf, vf = q.float(), k.float(), v.float()
+    out = torch.zeros_like(qf)
+    for a in range(nt[0]):
+        t0, t1 = sta_window(a, nt[0], kernel[0])
+        for b in range(nt[1]):
+            h0, h1 = sta_window(b, nt[1], kernel[1])
+            for c in range(nt[2]):
+                w0, w1 = sta_window(c, nt[2], kernel[2])
+                rows = torch.nonzero((t_idx == a) & (h_idx == b) & (w_idx == c)).flatten()
+                if rows.numel() == 0:
+                    continue
+                keys = torch.nonzero((t_idx >= t0) & (t_idx < t1) & (h_idx >= h0) & (h_idx < h1) & (w_idx >= w0) & (w_idx < w1)).flatten()
+                sc = torch.matmul(qf[:, :, rows], kf[:, :, keys].transpose(-1, -2)) * scale
+                out[:, :, rows] = torch.matmul(torch.softmax(sc, dim=-1), vf[:, :, keys])
+    return out

@@ -105,6 +105,21 @@ def test_dense_impl_key_padding_masks():
         for form, m in (("bool [B,Skv]", mask), ("int64", mask.long()), ("[B,1,1,Skv]", mask[:, None, None, :].to(DEV)),
                         ("additive 0/-inf", torch.zeros((B, Skv)).masked_fill(~mask, float("-inf")))):
             _attn_check(impl.forward(q, k, v, md(m)), r, f"key-padding mask {name}, {form}")
+        # the "large negative" additive masks HF pipelines write instead of -inf (finfo.min of the mask dtype): masked all the same
+        for dt in (torch.float32, torch.bfloat16):
+            big = torch.zeros((B, Skv), dtype=dt).masked_fill(~mask, torch.finfo(dt).min)
+            assert torch.equal(impl.forward(q, k, v, md(big)), impl.forward(q, k, v, md(mask))), (name, dt)
+    with pytest.raises(NotImplementedError, match="additive"):
+        impl.forward(q, k, v, md(torch.full((B, Skv), -1.5)))                 # a bias is not a padding mask
+    # SELF-attention (Sq == Skv): the reference's flash_attn_no_pad unpads the queries with the same mask and pads the output back with
+    # ZERO rows (flash_attn.py:322-330) — valid rows as SDPA, padded rows exactly zero
+    qs = rnd((B, Skv, H, D), 9).to(DEV)
+    o_self = impl.forward(qs, k, v, md(tail))
+    r_self = F.scaled_dot_product_attention(qs.float().cpu().transpose(1, 2), k.float().cpu().transpose(1, 2), v.float().cpu().transpose(1, 2),
+                                            attn_mask=tail[:, None, None, :], scale=D**-0.5).transpose(1, 2)
+    _attn_check(o_self[1:, :413], r_self[1:, :413], "self-attention key padding, valid rows")
+    _attn_check(o_self[:1], r_self[:1], "self-attention key padding, unmasked sample")
+    assert (o_self[1, 413:] == 0).all(), "padded query rows must be zero (flash_attn_no_pad / pad_input)"
     # a shorter mask covers the LAST keys; the keys in front of it are attended (front-pad, sdpa.py:88-92)
     short = torch.ones((B, 500), dtype=torch.bool)
     short[0, 450:] = False
@@ -238,11 +253,68 @@ def test_kernel_api_sliding_tile_attention_on_the_reference_canvas():
         worst_max, tot, cnt = max(worst_max, err.max().item()), tot + err.sum().item(), cnt + err.numel()
     print(f"STA 18x48x80 vs masked fp32: max|err|={worst_max:.4g} mean|err|={tot / cnt:.4g}")
     assert worst_max < 4e-2 and tot / cnt < 2e-4, (worst_max, tot / cnt)
-    # text tokens are a HunyuanVideo / StepVideo feature: refused, not ignored
-    with pytest.raises(NotImplementedError):
+    # has_text=True says rows past the canvas are text: 10 valid text tokens in a sequence that is exactly the canvas is an argument error
+    with pytest.raises(ValueError, match="text tokens"):
         KA.sliding_tile_attention(q, k, v, wins, 10, True, "18x48x80")
     with pytest.raises(ValueError):
         KA.sliding_tile_attention(q, k, v, wins[:3], 0, False, "18x48x80")
+    # has_text=True with no text rows at all is the image-only mask (support_flex_sta.py:52-55 with text_length 0)
+    assert torch.equal(KA.sliding_tile_attention(q[:, :3], k[:, :3], v[:, :3], wins[:3], 0, True, "18x48x80"), o[:, :3])
+
+
+@pytest.mark.parametrize("text_rows,text_length", [(256, 77), (384, 0), (100, 100)])
+def test_kernel_api_sliding_tile_attention_with_text_tokens(text_rows, text_length):
+    """The text-token form of ``sliding_tile_attention`` (fastvideo_kernel/ops.py:36-60; HunyuanVideo / StepVideo callers): image
+    queries attend their window + the valid text keys, text queries attend every image key + the valid text keys
+    (support_flex_sta.py:52-55) — vs exact fp32 attention under the oracle's ``sta_mask`` (the flex-attention mask restated), on a
+    4-tile canvas with a per-head window, text rows that do / do not fill whole 64-row blocks and 384-row tiles."""
+    from fastvideo_amd import kernel_api as KA
+    from oracle import vsa_oracle as V
+    from oracle import wan_oracle as W
+    canvas, tile = (6, 16, 16), (6, 8, 8)
+    img = 6 * 16 * 16
+    S, H, D = img + text_rows, 3, 128
+    wins = [(1, 1, 1), (1, 3, 1), (1, 1, 3)]
+    q, k, v = (_sta_distribution((1, H, S, D), s) for s in (3, 4, 5))
+    o = KA.sliding_tile_attention(q, k, v, wins, text_length, True, "6x16x16")
+    assert o.shape == q.shape and o.dtype == torch.bfloat16
+    qc, kc, vc = q.cpu(), k.cpu(), v.cpu()
+    for h, w in enumerate(wins):
+        m = V.sta_mask(canvas, w, tile, text_length=text_length, total_len=S)
+        ref = W.attention_fp32_ref(qc[:, h:h + 1], kc[:, h:h + 1], vc[:, h:h + 1], D**-0.5, m)
+        rows = slice(0, img + text_length)        # padded text QUERY rows attend real keys too (txt2all); compare every row
+        err = (o[:, h:h + 1].float().cpu() - ref).abs()
+        print(f"STA + text ({text_rows} rows, {text_length} valid), window {w}: max|err|={err.max().item():.4g} mean|err|={err.mean().item():.4g}")
+        assert err[:, :, rows].max().item() < 4e-2 and err.mean().item() < 2e-4, (w, err.max().item(), err.mean().item())
+        assert err.max().item() < 4e-2
+
+
+def test_kernel_api_ops_under_torch_compile_on_the_device():
+    """The three torch.library ops (fastvideo_kernel::*_gfx950) on the MI355X inside torch.compile(fullgraph=True): one graph, no break at
+    the ctypes calls, results bit-identical to the eager calls (the reference registers its kernels the same way so that
+    ``enable_torch_compile`` models trace: block_sparse_attn.py:103-145, component_loader.py:1127).  backend="aot_eager": traces through
+    AOTAutograd with the fake kernels, runs the real ops, and needs no code generator (the product has no Triton)."""
+    from fastvideo_amd import kernel_api as KA
+    raw = (8, 16, 16)   # token grid (8,8,8): 2 x 2 x 2 tiles of (4,4,4) = 8 blocks of 64, 512 tokens
+    md = KA.build_vsa_metadata((8, 8, 8), device=DEV)
+    vbs = md["variable_block_sizes"].int()
+    q, k, v, gate = (rnd((1, 2, 512, 128), s).to(DEV) for s in (1, 2, 3, 4))
+    wins = [(1, 1, 1), (1, 1, 1)]
+
+    def caller(q, k, v, gate, vbs):
+        a = KA.video_sparse_attn(q, k, v, vbs, vbs, 3, (4, 4, 4), compress_attn_weight=gate)
+        b = KA.sliding_tile_attention(torch.cat([a, a, a], 2)[:, :, :768], torch.cat([k, k], 2)[:, :, :768], torch.cat([v, v], 2)[:, :, :768], wins, 0, False, "6x8x16")
+        idx = torch.arange(8, device=q.device, dtype=torch.int32).expand(1, 2, 8, 8).contiguous()
+        num = torch.full((1, 2, 8), 5, device=q.device, dtype=torch.int32)
+        o, lse = KA.block_sparse_attn_from_indices(a, k, v, idx, num, vbs)
+        return a, b, o, lse
+
+    eager = caller(q, k, v, gate, vbs)
+    torch._dynamo.reset()
+    compiled = torch.compile(caller, backend="aot_eager", fullgraph=True)(q, k, v, gate, vbs)
+    for name, x, y in zip(("video_sparse_attn", "sliding_tile_attention", "block_sparse o", "block_sparse lse"), eager, compiled):
+        assert torch.equal(x, y), name
+    assert torch.isfinite(eager[1].float()).all()
 
 
 # ------------------------------------------------------------------ layer ops (fastvideo_amd/layers.py)

@@ -156,6 +156,38 @@ def _lin_ref(x, w, b):
     return (x.float() @ w.float().t() + (0 if b is None else b.float())).bfloat16()
 
 
+@pytest.mark.parametrize("B,S,d,K", [(1, 264, 256, 256), (2, 1000, 1536, 1536), (1, 32760, 1536, 1536), (1, 4095, 384, 128)])
+def test_gemm_vt_equals_linear_then_v_transpose(ops, B, S, d, K):
+    """fvk_gemm_vt_bf16 (round 5): the V projection written straight into the attention kernels' V^T layout == `to_v` as a plain GEMM
+    (linear.py:146-156) followed by the layout pass fvk_v_transpose_bf16, BIT FOR BIT: the same fragments meet in the same MFMAs in the same k
+    order, only as B / A instead of A / B, and the epilogue rounds y = bf16(acc + bias) at the same point.  Cases: one tile; a batch of two with
+    a ragged last tile and a half-filled last 16-key group (1000 = 62 x 16 + 8: positions 4-7 and 12-15 of that group are padding); the
+    contract shape; S % 8 != 0 is refused.  Also against the fp32 oracle, and the padding columns must be exact zeros (0 x finite in P·V)."""
+    if S % 8:
+        x = rnd((B, S, K), 1).to(DEV)
+        assert not ops.gemm_vt_eligible(x, rnd((d, K), 2).to(DEV))
+        with pytest.raises(RuntimeError, match="not served"):
+            ops.gemm_vt(x, rnd((d, K), 2).to(DEV))
+        return
+    x, w, b = rnd((B, S, K), 1), rnd((d, K), 2, K**-0.5), rnd((d,), 3, 0.5)
+    H = d // 128
+    v = ops.gemm(x.to(DEV).view(B * S, K), w.to(DEV), b.to(DEV)).view(B, S, H, 128)
+    want = ops.v_transpose(v)
+    got = ops.gemm_vt(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert got.shape == want.shape == (B, H, 128, (S + 127) // 128 * 128)
+    assert torch.equal(got, want), f"{int((got != want).sum())} of {got.numel()} elements differ, max {(got.float() - want.float()).abs().max().item():.4g}"
+    # no-bias form
+    assert torch.equal(ops.gemm_vt(x.to(DEV), w.to(DEV)), ops.v_transpose(ops.gemm(x.to(DEV).view(B * S, K), w.to(DEV)).view(B, S, H, 128)))
+    # fp32 oracle on the un-permuted columns of a few heads + exact zeros in the padding
+    ref = W.linear(x, w, b).float().view(B, S, H, 128).permute(0, 2, 3, 1)            # [B,H,128,S]
+    pos = torch.arange(got.shape[-1])
+    key = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1)
+    valid = key < S
+    gc = got.float().cpu()
+    close(gc[..., valid], ref[..., key[valid]], what="gemm_vt vs fp32 linear")
+    assert (gc[..., ~valid] == 0).all()
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 128), (1, 1536, 256), (257, 64, 1536), (130, 8960, 192)])
 def test_gemm_bias(ops, M, N, K):
     x, w, b = rnd((M, K), 1), rnd((N, K), 2, K**-0.5), rnd((N, ), 3)

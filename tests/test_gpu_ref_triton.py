@@ -186,3 +186,25 @@ def test_sliding_tile_attention_vs_reference_triton_on_18x48x80():
     print(f"STA 18x48x80 vs reference Triton STA: avg_diff={avg:.4g} max_diff={mx:.4g} (reference thresholds: 3e-6 / 4e-2)")
     assert mx < 4e-2, mx    # the reference's own thresholds (test_sta.py:88-91), against the reference's own kernel
     assert avg < 3e-6, avg  # measured 1.9e-8: the two kernels walk the keys in the same order, their bf16 P roundings coincide
+
+
+def test_sliding_tile_attention_with_text_vs_reference_triton_on_30x48x80():
+    """The text-token form (the reference's DEFAULT arguments: has_text=True, seq_shape="30x48x80" — HunyuanVideo's 115 200 image tokens +
+    256 text rows, 100 of them valid): ``kernel_api.sliding_tile_attention`` vs the reference's own Triton STA kernel
+    (st_attn_triton.py:241-376: windowed image pass + the text pass), whole tensors, the reference's max threshold; the mean is bounded by
+    the bf16 rounding of P / O (the two text passes need not walk the keys in the same order as our single list walk)."""
+    mod = _load("st_attn_triton")
+    _one_config(mod.triton_sta_kernel, BLOCK_Q=64, BLOCK_KV=64, num_stages=1, num_warps=4)
+    from fastvideo_amd import kernel_api as KA
+    B, H, S, D = 1, 2, 115200 + 256, 128
+    wins = [(3, 3, 3), (5, 3, 1)]
+    q, k, v = (_sta_distribution((B, H, S, D), s) for s in (6, 7, 8))
+    ref = _run(mod.sliding_tile_attention_triton, q, k, v, wins, 100, True, "30x48x80")
+    o = KA.sliding_tile_attention(q, k, v, wins, 100)          # the reference's defaults
+    assert o.shape == ref.shape == q.shape
+    valid = 115200 + 100                                         # rows past the valid text tokens are padding (their keys are masked)
+    err = (o.float() - ref.float()).abs()[:, :, :valid]
+    avg, mx = err.mean().item(), err.max().item()
+    e_txt = err[:, :, 115200:].mean().item()
+    print(f"STA 30x48x80 + text vs reference Triton STA: avg_diff={avg:.4g} max_diff={mx:.4g}; text query rows alone avg {e_txt:.4g}")
+    assert mx < 4e-2 and avg < 1e-4 and e_txt < 1e-3, (avg, mx, e_txt)

@@ -136,6 +136,31 @@ def test_batch2_forward_equals_two_forwards(golden_dir, attention):
     assert not torch.equal(a, b)
 
 
+def test_batch2_forward_with_fp8_linears(golden_dir):
+    """per-token fp8 (fp8_channel) keeps the batch-2 == two-forwards identity (every activation row carries its own scale); per-tensor
+    fp8 does NOT (one absmax over the whole [B*S, d] matrix: the pair shares a scale) — DenoisingLoopHip refuses cfg_batch for it instead of
+    silently changing the numbers."""
+    _need_gpu()
+    from fastvideo_amd.scheduler import DenoisingLoopHip
+    from fastvideo_amd.wan_dit import WanTransformer3DModelHip
+    fx = torch.load(os.path.join(golden_dir, "wan_tiny.pt"), weights_only=False)
+    H = fx["config"]["num_heads"]
+    gen = torch.Generator().manual_seed(3)
+    lat = torch.randn((1, 16, 5, 20, 36), generator=gen).bfloat16().cuda()
+    c = fx["cases"][0]
+    neg = (torch.randn(c["ctx"].shape, generator=gen) * 3).bfloat16().cuda()      # a louder negative prompt: the two samples' absmax differ
+    t = torch.tensor([617.0]).cuda()
+    model = WanTransformer3DModelHip(fx["state_dict"], num_heads=H, quantization="fp8_channel")
+    a, b = model(lat, c["ctx"].cuda(), t), model(lat, neg, t)
+    pair = model(lat.expand(2, -1, -1, -1, -1).contiguous(), torch.cat([c["ctx"].cuda(), neg], 0), t.repeat(2))
+    assert torch.equal(pair[0:1], a) and torch.equal(pair[1:2], b) and not torch.equal(a, b)
+    DenoisingLoopHip(model, 4, cfg_batch=True)
+    model_t = WanTransformer3DModelHip(fx["state_dict"], num_heads=H, quantization="fp8")
+    with pytest.raises(ValueError, match="per-tensor fp8"):
+        DenoisingLoopHip(model_t, 4, cfg_batch=True)
+    DenoisingLoopHip(model_t, 4, cfg_batch=False)
+
+
 def test_two_expert_loop_switches_at_the_boundary(golden_dir):
     """Wan2.2-A14B style loop: steps with t >= boundary_ratio * 1000 use the high-noise expert and guidance_scale, the others the
     low-noise expert and guidance_scale_2 (denoising.py:251-256, 377-403).  4 steps, shift 3 => t = 999, 899, 749, 499; boundary 0.875
