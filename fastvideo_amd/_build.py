@@ -16,6 +16,9 @@ SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.
 PROBE_DIR = os.path.join(HERE, "..", "scripts", "probes")
 PROBE_SOURCES = ["attn_pp.hip", "attn_vsa.hip"]
 PROBE_LIB = os.path.join(PROBE_DIR, "libfvk_probe.so")
+# round 5, scripts/coresidency_matrix.py only: the measurement build WITHOUT the two fences of round 4's co-residency bug (the register-file
+# claim of the one-wave-per-SIMD kernels, the packed-fp32 ban in the small kernels' files) — the pre-fix state, rebuilt on purpose to study it
+BUG_LIB = os.path.join(PROBE_DIR, "libfvk_bug.so")
 # The files of the SMALL kernels (norm / RoPE / pack, gathers, quantisers, scheduler step, post-processing: few registers, so their waves can
 # share a SIMD with another kernel's) are compiled WITHOUT packed-fp32 VALU instructions: round 4 found v_pk_mul_f32 / v_pk_add_f32 results of
 # such a wave wrong while a foreign MFMA stream ran on its SIMD (profiles/r04z_pk_f32_beside_mfma.log).  The known aggressors now
@@ -83,13 +86,18 @@ def build_probe(force: bool = False, verbose: bool = True) -> str:
     return build(force, verbose, probe=True)
 
 
-def _build_locked(verbose: bool, probe: bool = False) -> str:
-    objdir = os.path.join(PROBE_DIR, "build") if probe else os.path.join(CSRC, "build")
+def build_bug(verbose: bool = True) -> str:
+    """scripts/probes/libfvk_bug.so (see BUG_LIB); always rebuilt, never built by __graft_entry__.build()."""
+    return _build_locked(verbose, probe=True, bug=True)
+
+
+def _build_locked(verbose: bool, probe: bool = False, bug: bool = False) -> str:
+    objdir = os.path.join(PROBE_DIR, "build_bug" if bug else "build") if probe else os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     cc = hipcc()
     objs = []
     procs = []
-    lib = PROBE_LIB if probe else LIB
+    lib = BUG_LIB if bug else PROBE_LIB if probe else LIB
     srcs = [(src, os.path.join(CSRC, src)) for src in SOURCES] + ([(src, os.path.join(PROBE_DIR, src)) for src in PROBE_SOURCES] if probe else [])
     for src, path in srcs:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -99,10 +107,12 @@ def _build_locked(verbose: bool, probe: bool = False) -> str:
             # its 64-chunk iteration must be FULLY unrolled (every register-array index a constant): above clang's default budget for
             # `#pragma unroll`, silently left as a loop otherwise — with the wave's whole register struct in scratch
             extra += ["-mllvm", "-pragma-unroll-threshold=100000"]
-        if src in NO_PACKED_FP32:
+        if src in NO_PACKED_FP32 and not bug:
             extra += ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
         if probe:
             extra += ["-DFVK_PROBE_BUILD=1", "-I", CSRC]
+        if bug:
+            extra += ["-DFVK_NO_REGISTER_CLAIM=1"]
         cmd = [cc, *FLAGS, *extra, "-c", path, "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for src, p in procs:
@@ -123,8 +133,9 @@ def _build_locked(verbose: bool, probe: bool = False) -> str:
     except OSError as e:
         os.remove(lib)
         raise RuntimeError(f"built library does not load: {e}") from e
-    with open(lib + ".flags", "w") as f:
-        f.write(_flag_stamp(probe) + "\n")
+    if not bug:
+        with open(lib + ".flags", "w") as f:
+            f.write(_flag_stamp(probe) + "\n")
     return lib
 
 

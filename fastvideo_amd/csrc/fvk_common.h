@@ -76,7 +76,11 @@ inline int fvk_config_lds(FvkLdsConfigured& c, const void* func, int bytes, cons
 // registers).  Same stream = no overlap = never seen in a single-stream process; two streams, or two processes on one GPU, hit it.  The
 // clobbers make the compiler report 256 arch VGPRs + 256 AGPRs, so the dispatcher places no second wave on the SIMD; it costs nothing (the
 // kernels run one wave per SIMD by design).
+#if defined(FVK_NO_REGISTER_CLAIM)  // scripts/probes/libfvk_bug.so only (round 5: the pre-fix state rebuilt on purpose, to study the bug)
+#define FVK_CLAIM_WHOLE_REGISTER_FILE()
+#else
 #define FVK_CLAIM_WHOLE_REGISTER_FILE() asm volatile("" ::: "v255", "a255")
+#endif
 
 // device helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ bf16x8 ld_bf16x8(const void* p) {

@@ -443,7 +443,8 @@ int launch_var(const GemmArgs& a, int epilogue, int batch, hipStream_t s) {
 int gemm_w1_vt_launch(GemmArgs a, int batch, hipStream_t s) {
     a.ntm = (a.M + TM - 1) / TM;
     a.ntn = (a.N + TN - 1) / TN;
-    return launch<FVK_EPI_VT, 15>(a, batch, s);
+    // V^T [d, S_pad] is a wide output (N = S): streaming stores, as for every N >= 4096 (gemm_w1_launch) — VAR 143
+    return launch<FVK_EPI_VT, 143>(a, batch, s);
 }
 
 bool gemm_w1_fp8_eligible(const GemmArgs& a) {

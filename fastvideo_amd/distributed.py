@@ -92,11 +92,16 @@ class SequenceParallel:
         # What it can save inside ONE batch-1 forward is bounded: every op of a DiT layer depends on the previous one, so the critical path
         # is still exchange #1 (all of it) -> attention -> exchange #2 of the LAST chunk; only the first chunk's share of exchange #2 (~1/6 of
         # a layer's exchange time) is hidden, and two attention launches in stream order split the grid (192 workgroups at SP = 8 become
-        # 128 + 64; FVK_SP_OVERLAP=2 runs the second chunk on a second HIP stream instead).  Hence OPT-IN (FVK_SP_OVERLAP=1 / 2) until an 8-GPU node has measured it; the default is the plain single-collective
-        # exchange.  Heads are independent in attention, so the result is the plain exchange's bit for bit — checked on the first call
-        # (all-reduced verdict); any rank seeing a difference switches every rank back to the plain exchange.
-        self.overlap = P > 1 and os.environ.get("FVK_SP_OVERLAP") in ("1", "2")
-        self.overlap_streams = 2 if os.environ.get("FVK_SP_OVERLAP") == "2" else 1   # "2": chunk B's attention on a second HIP stream
+        # 128 + 64; FVK_SP_OVERLAP=2 runs the second chunk on a second HIP stream instead).  Heads are independent in attention, so the result
+        # is the plain exchange's bit for bit — checked on the first call (all-reduced verdict); any rank seeing a difference switches every
+        # rank back to the plain exchange.
+        # DEFAULT (round 5): ON in stream order for P >= 4, OFF for P = 2.  The compute-side cost is measured and is what decides
+        # (profiles/r04z_sp_chunk_launch_ab.log): two chunk launches cost nothing at P = 4 / 8 (the key axis is cut into runs there anyway)
+        # and 18 % of the attention time at P = 2 unless the second chunk runs on its own stream — so P = 2 keeps the single collective.
+        # What it HIDES needs xGMI and has never been measured.  FVK_SP_OVERLAP = 0 / 1 / 2 forces plain / one stream / two streams.
+        mode = {"0": 0, "1": 1, "2": 2}.get(os.environ.get("FVK_SP_OVERLAP", "auto"), 1 if P >= 4 else 0)
+        self.overlap = P > 1 and mode > 0
+        self.overlap_streams = 2 if mode == 2 else 1   # 2: chunk B's attention on a second HIP stream
         self._side_stream = None
         self._overlap_checked = False
         # bench.py's exchange accounting: set ``stats`` to a dict to collect, per exchange kind, the bytes this rank sends to OTHER

@@ -79,6 +79,7 @@ class WanTransformer3DModelHip:
         self._tune = None
         self._forwards = 0
         self.vsa_trace = None    # set to a list to collect every layer's VSA block mask (tests)
+        self.fuse_cross_residual = True  # the cross-attention residual add in the out-projection's epilogue (False: in the norm pass; A/B, tests)
         self.vt_gemm = True      # dense, single GPU, bf16: V projection written as V^T by its own GEMM (ops.gemm_vt); False = fused QKV + layout pass (A/B, tests)
 
     # ------------------------------------------------------------------ weights
@@ -626,9 +627,16 @@ class WanTransformer3DModelHip:
             ck = ops.rmsnorm_rope([kv[:, :d]], [b["cnk_w"]], head_dim=D, seq_len=Lc, eps=self.eps)[0]
             co = ops.attn_dense(cq.view(B, Sl, H, D), ck.view(B, Lc, H, D), kv[:, d:].view(B, Lc, H, D), scale=D**-0.5,
                                 layout="bshd")
-            c_out = self._lin(co.view(B * Sl, d), b, "co", b["co_b"])
-            nh, x = ops.ln_modulate(c_out, residual=x, mul=mul_c_i, add=c_shift_i, eps=self.eps, round_residual=True,
-                                    round_norm=True, want_residual=True, rows_per_batch=rpb, fp8_rowwise=fq)
+            # cross_attn_residual_norm is called with gate = 1 (wanvideo.py:425): `residual + x` is then a bf16 + bf16 sum, ROUNDED to bf16
+            # before the norm (layernorm.py:193-199) — so the add rides in the out-projection's epilogue (bf16(x + y), the same one rounding)
+            # and the norm pass reads one tensor instead of two and writes one instead of two (round 5; bit-identical)
+            if self.fuse_cross_residual:
+                x = self._lin(co.view(B * Sl, d), b, "co", b["co_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=None, rows_per_batch=rpb)
+                nh = ops.ln_modulate(x, mul=mul_c_i, add=c_shift_i, eps=self.eps, round_norm=True, rows_per_batch=rpb, fp8_rowwise=fq)
+            else:
+                c_out = self._lin(co.view(B * Sl, d), b, "co", b["co_b"])
+                nh, x = ops.ln_modulate(c_out, residual=x, mul=mul_c_i, add=c_shift_i, eps=self.eps, round_residual=True,
+                                        round_norm=True, want_residual=True, rows_per_batch=rpb, fp8_rowwise=fq)
             f = self._lin(nh, b, "f1", b["f1_b"], epilogue=ops.EPI_GELU_TANH)
             x = self._lin(f, b, "f2", b["f2_b"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=c_gate_i, rows_per_batch=rpb)
             if trace is not None:

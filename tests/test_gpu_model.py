@@ -39,6 +39,12 @@ def test_wan_tiny_forward_matches_reference(tiny):
             _cmp(trace[f"blocks.{i}.out"], blk, f"case {ci} block {i}")
         _cmp(y, case["out"], f"case {ci} output")
         assert y.shape == case["out"].shape and y.dtype == torch.bfloat16
+        # round 5: the cross-attention residual add in the out-projection's epilogue (shipped) == in the norm pass, bit for bit, also on the
+        # small-shape GEMM kernels this geometry takes; likewise the V^T GEMM where the shape admits it
+        for attr in ("fuse_cross_residual", "vt_gemm"):
+            setattr(model, attr, False)
+            assert torch.equal(model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda()), y), attr
+            setattr(model, attr, True)
 
 
 def test_wan_tiny_vsa_matches_oracle(tiny):
@@ -122,6 +128,9 @@ def test_wan_tiny_fp8_matches_oracle(tiny, quant):
     model = WanTransformer3DModelHip(tiny["state_dict"], num_heads=H, quantization=quant)
     y = model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda())
     _cmp(y, ref, f"{quant} output", mean_tol=2e-2)
+    model.fuse_cross_residual = False   # the fp8 GEMM's residual epilogue == the norm-pass form
+    assert torch.equal(model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda()), y)
+    model.fuse_cross_residual = True
     # the quantised forward must differ from the bf16 one (i.e. the fp8 path really ran) but stay close to it
     d_q = (ref.float() - base.float()).abs().mean().item()
     assert 0 < d_q < 0.1 * base.float().abs().mean().item() + 5e-2

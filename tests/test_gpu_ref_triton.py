@@ -191,8 +191,7 @@ def test_sliding_tile_attention_vs_reference_triton_on_18x48x80():
 def test_sliding_tile_attention_with_text_vs_reference_triton_on_30x48x80():
     """The text-token form (the reference's DEFAULT arguments: has_text=True, seq_shape="30x48x80" — HunyuanVideo's 115 200 image tokens +
     256 text rows, 100 of them valid): ``kernel_api.sliding_tile_attention`` vs the reference's own Triton STA kernel
-    (st_attn_triton.py:241-376: windowed image pass + the text pass), whole tensors, the reference's max threshold; the mean is bounded by
-    the bf16 rounding of P / O (the two text passes need not walk the keys in the same order as our single list walk)."""
+    (st_attn_triton.py:241-376: windowed image pass + the text pass), whole tensors, the reference's own thresholds (avg < 3e-6, max < 4e-2: test_sta.py:88-91)."""
     mod = _load("st_attn_triton")
     _one_config(mod.triton_sta_kernel, BLOCK_Q=64, BLOCK_KV=64, num_stages=1, num_warps=4)
     from fastvideo_amd import kernel_api as KA
@@ -207,4 +206,5 @@ def test_sliding_tile_attention_with_text_vs_reference_triton_on_30x48x80():
     avg, mx = err.mean().item(), err.max().item()
     e_txt = err[:, :, 115200:].mean().item()
     print(f"STA 30x48x80 + text vs reference Triton STA: avg_diff={avg:.4g} max_diff={mx:.4g}; text query rows alone avg {e_txt:.4g}")
-    assert mx < 4e-2 and avg < 1e-4 and e_txt < 1e-3, (avg, mx, e_txt)
+    # measured: avg 2.0e-6, max 1.6e-2, text rows 6.1e-7 — inside the reference's OWN thresholds for two bf16-P kernels (test_sta.py:88-91)
+    assert mx < 4e-2 and avg < 3e-6 and e_txt < 3e-6, (avg, mx, e_txt)

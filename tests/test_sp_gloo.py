@@ -27,7 +27,12 @@ def _attn_fn(q, k, v, kv_len):
 
 
 def _worker(rank, world, port, H, S, D, q, k, v, out_q, overlap=False):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FVK_SP_OVERLAP="1" if overlap else "0")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if overlap is None:   # the library default: pipelined in stream order from 4 ranks on, the single collective at 2 (distributed.py)
+        os.environ.pop("FVK_SP_OVERLAP", None)
+        overlap = world >= 4
+    else:
+        os.environ["FVK_SP_OVERLAP"] = "1" if overlap else "0"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from fastvideo_amd.distributed import SequenceParallel
@@ -50,6 +55,12 @@ def _worker(rank, world, port, H, S, D, q, k, v, out_q, overlap=False):
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,H,S", [(2, 12, 33), (4, 12, 64)])
+def test_sp_default_exchange_mode(world, H, S):
+    """No FVK_SP_OVERLAP in the environment: 2 ranks keep the single collective, 4 ranks run the pipelined exchange — same result."""
+    test_sp_attention_equals_single_process(world, H, S, None)
 
 
 @pytest.mark.parametrize("overlap", [False, True])
@@ -89,7 +100,8 @@ def test_sp_attention_world8(H, S):
     ctx = mp.get_context("spawn")
     out_q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, H, S, D, q, k, v, out_q, False)) for r in range(world)]
+    # H = 12: the library's default exchange at 8 ranks (pipelined: 3 heads per group -> chunks of 2 and 1); H = 40: the plain exchange
+    procs = [ctx.Process(target=_worker, args=(r, world, port, H, S, D, q, k, v, out_q, None if H == 12 else False)) for r in range(world)]
     for p in procs:
         p.start()
     full, roundtrip_ok, (G, U) = out_q.get(timeout=240)
