@@ -449,43 +449,54 @@ def main():
     if world > 1:
         model.sp.stats = {}  # per-exchange bytes + HIP-event pairs on the compute stream (fastvideo_amd/distributed.py)
     t0 = time.perf_counter()
+    wall0 = time.time()
     for _ in range(args.steps):
         y = model(latent, ctx, ts)
     sync()
     elapsed = time.perf_counter() - t0
+    wall1 = time.time()
     events, model.attn_events = model.attn_events, None
+    sp_stats = None
+    if world > 1:
+        sp_stats, model.sp.stats = model.sp.stats or {}, None   # the exchange accounting covers the K timed steps only
     if not torch.isfinite(y.float()).all():
         raise SystemExit("non-finite output")
     # socket power / shader clock: a SEPARATE, untimed repeat of the same K steps straight after the timed region (the 20-Hz host
-    # sampling thread shares the GIL with the launch loop, so it must not run inside the region `value` is computed from)
+    # sampling thread shares the GIL with the launch loop, so it must not run inside the region `value` is computed from).  EVERY rank runs the
+    # repeat (a sequence-parallel forward holds collectives: rank 0 alone would wait for its peers forever); only rank 0 samples.
     power = None
-    if rank == 0 and not args.no_power_trace:
-        try:  # scripts/power_trace.py: a host thread reading socket power + shader clock at 20 Hz (measurement only; never required)
-            import importlib.util
-            spec = importlib.util.spec_from_file_location("power_trace", os.path.join(ROOT, "scripts", "power_trace.py"))
-            pt = importlib.util.module_from_spec(spec)
-            spec.loader.exec_module(pt)
-            sampler = pt.PowerSampler(20.0, local_rank).start()
-            tp0, wall0 = time.perf_counter(), time.time()
-            for _ in range(args.steps):
-                model(latent, ctx, ts)
-            torch.cuda.synchronize()
-            wall1, tp1 = time.time(), time.perf_counter()
-            if not sampler.available:
-                sampler.stop()
-                power = {"error": "no power / clock source readable", "sampler_errors": sampler.errors[:4]}
-            else:
-                samples = sampler.stop()
-                power = pt.summarize(samples, wall0, wall1, sampler.src.name)
-                power["what"] = ("socket power and shader clock of this GPU sampled by a host thread (scripts/power_trace.py) over an UNTIMED repeat "
-                                 "of the K steps straight after the timed region; a MEASURED clock, unlike roofline.clock_from_profiled_cycles_ghz")
-                power["ms_per_step_while_sampling"] = round((tp1 - tp0) * 1e3 / args.steps, 3)
-                if sampler.errors:
-                    power["sampler_errors"] = sampler.errors[:4]
-        except Exception as ex:  # noqa: BLE001
-            power = {"error": repr(ex)[:200]}
-    if world > 1:
-        dist.barrier()
+    if not args.no_power_trace:
+        sampler, pt = None, None
+        if rank == 0:
+            try:  # scripts/power_trace.py: a host thread reading socket power + shader clock at 20 Hz (measurement only; never required)
+                import importlib.util
+                spec = importlib.util.spec_from_file_location("power_trace", os.path.join(ROOT, "scripts", "power_trace.py"))
+                pt = importlib.util.module_from_spec(spec)
+                spec.loader.exec_module(pt)
+                sampler = pt.PowerSampler(20.0, local_rank).start()
+            except Exception as ex:  # noqa: BLE001
+                sampler, power = None, {"error": repr(ex)[:200]}
+        sync()
+        tp0, pw0 = time.perf_counter(), time.time()
+        for _ in range(args.steps):
+            model(latent, ctx, ts)
+        sync()
+        pw1, tp1 = time.time(), time.perf_counter()
+        if sampler is not None:
+            try:
+                if not sampler.available:
+                    sampler.stop()
+                    power = {"error": "no power / clock source readable", "sampler_errors": sampler.errors[:4]}
+                else:
+                    samples = sampler.stop()
+                    power = pt.summarize(samples, pw0, pw1, sampler.src.name)
+                    power["what"] = ("socket power and shader clock of this GPU sampled by a host thread (scripts/power_trace.py) over an UNTIMED repeat "
+                                     "of the K steps straight after the timed region; a MEASURED clock, unlike roofline.clock_from_profiled_cycles_ghz")
+                    power["ms_per_step_while_sampling"] = round((tp1 - tp0) * 1e3 / args.steps, 3)
+                    if sampler.errors:
+                        power["sampler_errors"] = sampler.errors[:4]
+            except Exception as ex:  # noqa: BLE001
+                power = {"error": repr(ex)[:200]}
     if world > 1:
         t = torch.tensor([elapsed], device="cpu" if shared else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -567,7 +578,7 @@ def main():
     if world > 1:
         # sequence-parallel exchange accounting of THIS rank (rank 0): bytes sent to other ranks and the time the compute stream spent
         # in each collective (HIP events bracketing it on that stream), i.e. the achieved per-GPU egress rate over xGMI
-        st, model.sp.stats = model.sp.stats or {}, None
+        st = sp_stats or {}
         ex = {}
         for kind, rec in st.items():
             ms = [a.elapsed_time(b) for a, b in rec["events"]]

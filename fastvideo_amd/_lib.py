@@ -12,9 +12,10 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # FVK_PROBE_LIB=1 (measurement scripts and the variant tests only): bind the measurement build of the same sources, which also holds
 # the non-shipping kernel variants behind fvk_set_tunable (scripts/probes/libfvk_probe.so, built by _build.build_probe()).
-PROBE = os.environ.get("FVK_PROBE_LIB") in ("1", "bug")
-# "bug" (scripts/coresidency_matrix.py only): the measurement build WITHOUT round 4's two fences against the co-residency bug (_build.BUG_LIB)
-LIB_PATH = (os.path.join(os.path.dirname(HERE), "scripts", "probes", "libfvk_bug.so" if os.environ.get("FVK_PROBE_LIB") == "bug" else "libfvk_probe.so")
+PROBE = os.environ.get("FVK_PROBE_LIB") in ("1", "bug", "bug2")
+# "bug" (scripts/coresidency_*.py only): the measurement build WITHOUT round 4's two fences against the co-residency bug (_build.BUG_LIB);
+# "bug2": the same with gemm_w1's MFMAs as compiler builtins instead of inline asm (scripts/build_bug2.sh)
+LIB_PATH = (os.path.join(os.path.dirname(HERE), "scripts", "probes", {"bug": "libfvk_bug.so", "bug2": "libfvk_bug2.so"}.get(os.environ.get("FVK_PROBE_LIB"), "libfvk_probe.so"))
             if PROBE else os.path.join(HERE, "libfvk_amd.so"))
 ABI_VERSION = 6
 

@@ -48,10 +48,16 @@ static_assert(LDS_BYTES >= 2 * BUF, "epilogue staging must cover both buffers");
 
 using fvk::GemmArgs;
 
+#if defined(FVK_W1_BUILTIN_MFMA)  // co-residency study only (scripts/probes/libfvk_bug2.so): the SAME kernel with compiler builtins
+#define W1_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
+#define W1_MFMA16(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, ACC, 0, 0, 0)
+#define W1_MFMA16Z(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0)
+#else
 #define W1_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 #define W1_MFMA16(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A), "v"(B))
 // first touch of an accumulator in a tile (DIRECT: no zeroing pass — 256 v_accvgpr_write per tile otherwise)
 #define W1_MFMA16Z(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(A), "v"(B))
+#endif
 typedef int w1_v8i __attribute__((ext_vector_type(8)));
 typedef int w1_v4i __attribute__((ext_vector_type(4)));
 // fp8: the two 16-B halves of each operand's 32-B fragment; unit block scales (E8M0 0x7F = 1.0)
