@@ -12,10 +12,12 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # FVK_PROBE_LIB=1 (measurement scripts and the variant tests only): bind the measurement build of the same sources, which also holds
 # the non-shipping kernel variants behind fvk_set_tunable (scripts/probes/libfvk_probe.so, built by _build.build_probe()).
-PROBE = os.environ.get("FVK_PROBE_LIB") in ("1", "bug", "bug2")
-# "bug" (scripts/coresidency_*.py only): the measurement build WITHOUT round 4's two fences against the co-residency bug (_build.BUG_LIB);
-# "bug2": the same with gemm_w1's MFMAs as compiler builtins instead of inline asm (scripts/build_bug2.sh)
-LIB_PATH = (os.path.join(os.path.dirname(HERE), "scripts", "probes", {"bug": "libfvk_bug.so", "bug2": "libfvk_bug2.so"}.get(os.environ.get("FVK_PROBE_LIB"), "libfvk_probe.so"))
+_PROBE_SEL = os.environ.get("FVK_PROBE_LIB", "")
+PROBE = _PROBE_SEL == "1" or _PROBE_SEL.startswith("bug")
+# "bug", "bug2", "bug_s<N>" (scripts/coresidency_*.py only): measurement builds WITHOUT round 4's two fences against the co-residency bug
+# (_build.BUG_LIB) — plain, with gemm_w1's MFMAs as compiler builtins (scripts/build_bug2.sh), with parts of gemm_w1's loop removed
+# (scripts/build_bug_strips.sh)
+LIB_PATH = (os.path.join(os.path.dirname(HERE), "scripts", "probes", f"libfvk_{_PROBE_SEL}.so" if _PROBE_SEL.startswith("bug") else "libfvk_probe.so")
             if PROBE else os.path.join(HERE, "libfvk_amd.so"))
 ABI_VERSION = 6
 

@@ -48,7 +48,16 @@ static_assert(LDS_BYTES >= 2 * BUF, "epilogue staging must cover both buffers");
 
 using fvk::GemmArgs;
 
-#if defined(FVK_W1_BUILTIN_MFMA)  // co-residency study only (scripts/probes/libfvk_bug2.so): the SAME kernel with compiler builtins
+// W1_STRIP (co-residency study only, scripts/build_bug_strips.sh; results are WRONG, the kernel only serves as an AGGRESSOR): bit 0 no
+// LDS-DMA staging in the loop, bit 1 no fragment reads in the loop, bit 2 no workgroup barriers in the loop, bit 3 no MFMAs
+#ifndef W1_STRIP
+#define W1_STRIP 0
+#endif
+#if (W1_STRIP & 8)
+#define W1_MFMA(ACC, A, B) asm volatile("" : "+a"(ACC) : "v"(A), "v"(B))
+#define W1_MFMA16(ACC, A, B) asm volatile("" : "+a"(ACC) : "v"(A), "v"(B))
+#define W1_MFMA16Z(ACC, A, B) asm volatile("" : "=a"(ACC) : "v"(A), "v"(B))
+#elif defined(FVK_W1_BUILTIN_MFMA)  // co-residency study only (scripts/probes/libfvk_bug2.so): the SAME kernel with compiler builtins
 #define W1_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, ACC, 0, 0, 0)
 #define W1_MFMA16(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, ACC, 0, 0, 0)
 #define W1_MFMA16Z(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0)
@@ -234,12 +243,12 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
     if (!(VAR & 2)) {                                                   \
         asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");    \
         __builtin_amdgcn_sched_barrier(0);                              \
-        __builtin_amdgcn_s_barrier();                                   \
+        if (!(W1_STRIP & 4)) __builtin_amdgcn_s_barrier();              \
         __builtin_amdgcn_sched_barrier(0);                              \
     } else if ((P) & 1) {                                               \
         asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");    \
         __builtin_amdgcn_sched_barrier(0);                              \
-        __builtin_amdgcn_s_barrier();                                   \
+        if (!(W1_STRIP & 4)) __builtin_amdgcn_s_barrier();              \
         __builtin_amdgcn_sched_barrier(0);                              \
     }
     // One 64 x 64 quadrant x K = 64: 16 MFMAs 32x32x16 (ks outer, then 2 x 2 blocks) or 32 MFMAs 16x16x32 (ks outer, then 4 x 4 blocks, the
@@ -265,11 +274,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w1_kernel(GemmArgs a) {
         if (!MI16 || FP8 || (i_ & 1)) {                                                                 \
             const int sl_ = (MI16 && !FP8) ? i_ >> 1 : i_;                                              \
             if (VAR & 1) {                                                                              \
-                if (sl_ < 8) { W1_READ1(RDST, RBUF, RIS_X, ROW0, sl_ & 7) }                             \
-                else if ((sl_ & 1) == 0) W1_STAGE(sk_, st_, ((sl_ - 8) >> 1) & 3)                       \
+                if (sl_ < 8) { if (!(W1_STRIP & 2)) { W1_READ1(RDST, RBUF, RIS_X, ROW0, sl_ & 7) } }    \
+                else if ((sl_ & 1) == 0) { if (!(W1_STRIP & 1)) W1_STAGE(sk_, st_, ((sl_ - 8) >> 1) & 3) } \
             } else {                                                                                    \
-                if ((sl_ & 3) == 0) W1_STAGE(sk_, st_, sl_ >> 2)                                        \
-                if (sl_ & 1) { W1_READ1(RDST, RBUF, RIS_X, ROW0, sl_ >> 1) }                            \
+                if ((sl_ & 3) == 0) { if (!(W1_STRIP & 1)) W1_STAGE(sk_, st_, sl_ >> 2) }               \
+                if (sl_ & 1) { if (!(W1_STRIP & 2)) { W1_READ1(RDST, RBUF, RIS_X, ROW0, sl_ >> 1) } }   \
             }                                                                                           \
         }                                                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                              \
