@@ -1,6 +1,7 @@
 """Generate tests/golden/vae_full_480p.pt: the REAL reference VAE decode of the FULL contract latent (VERDICT r4 weak #2 / next #1b).
 
-Run in the build container only:  ``python oracle/make_golden_vae_full.py``  (tens of minutes of CPU; /root/reference imported).
+Run in the build container only:  ``python oracle/make_golden_vae_full.py [--case 480p|720p]``  (480p: 9 + 28 minutes of CPU on 8 cores for the
+fp32 and the bf16-autocast decode; 720p = BASELINE config 5's decode, 129 frames of 720x1280: about four times that; /root/reference imported).
 
 Test infrastructure (a checker's fixture), never part of the product path.
 
@@ -25,9 +26,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle.make_golden_vae import build_ref_vae  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "vae_full_480p.pt")
-LATENT = (1, 16, 21, 60, 104)
-Z_SEED = 21
+CASES = {"480p": dict(out="vae_full_480p.pt", latent=(1, 16, 21, 60, 104), z_seed=21),      # the contract latent: 81 frames of 480x832
+         "720p": dict(out="vae_full_720p.pt", latent=(1, 16, 33, 90, 160), z_seed=22)}      # BASELINE config 5: 129 frames of 720x1280
 WEIGHT_SEED = 5
 
 
@@ -48,6 +48,9 @@ def sample_mask_sparse(H: int, W: int, seed: int) -> torch.Tensor:
 
 
 def main():
+    case = sys.argv[sys.argv.index("--case") + 1] if "--case" in sys.argv else "480p"
+    OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", CASES[case]["out"])
+    LATENT, Z_SEED = CASES[case]["latent"], CASES[case]["z_seed"]
     torch.set_num_threads(os.cpu_count() or 1)
     vae = build_ref_vae(base_dim=96, seed=WEIGHT_SEED)
     z = torch.randn(LATENT, generator=torch.Generator().manual_seed(Z_SEED))
