@@ -54,26 +54,38 @@ def main():
     torch.set_num_threads(os.cpu_count() or 1)
     vae = build_ref_vae(base_dim=96, seed=WEIGHT_SEED)
     z = torch.randn(LATENT, generator=torch.Generator().manual_seed(Z_SEED))
+    part = OUT + ".fp32.part"      # the fp32 decode kept on disk (full output, fp16-free: ~1.4 GB at 720p) so that an interrupted run resumes at the bf16 decode
     t0 = time.time()
-    with torch.no_grad():
-        y = vae.decode(z)
-    t1 = time.time()
-    print(f"fp32 decode {t1 - t0:.0f} s -> {tuple(y.shape)}", flush=True)
+    if os.path.exists(part):
+        y, dt = torch.load(part, weights_only=False)
+        t1 = t0 + dt
+        print(f"fp32 decode: resumed from {part} ({dt:.0f} s when it ran)", flush=True)
+    else:
+        with torch.no_grad():
+            y = vae.decode(z)
+        t1 = time.time()
+        print(f"fp32 decode {t1 - t0:.0f} s -> {tuple(y.shape)}", flush=True)
+        torch.save((y, t1 - t0), part)
     H, W = y.shape[-2:]
     m = sample_mask_sparse(H, W, Z_SEED)
     ys = y[0][:, :, m].clone()
     whole = dict(y_absmean=y.abs().mean().item(), y_std=y.std().item(), clamped_frac=(y.abs() == 1).float().mean().item())
+    fp32_s = t1 - t0
+    t_b0 = time.time()
     with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
         yb = vae.decode(z)
     t2 = time.time()
+    bf16_s = t2 - t_b0
     e = (yb.float() - y).abs()
     whole.update(e_mean=e.mean().item(), e_max=e.max().item())
     fx = dict(param_spec=vae.param_spec, weight_seed=WEIGHT_SEED, base_dim=96, latent=LATENT, z_seed=Z_SEED, out_shape=tuple(y.shape),
-              y=ys, e_bf16=e[0][:, :, m].half(), whole=whole, seconds=dict(fp32=t1 - t0, bf16_autocast=t2 - t1),
+              y=ys, e_bf16=e[0][:, :, m].half(), whole=whole, seconds=dict(fp32=fp32_s, bf16_autocast=bf16_s),
               threads=torch.get_num_threads())
     torch.save(fx, OUT)
-    print(f"bf16-autocast decode {t2 - t1:.0f} s; sampled {int(m.sum())} px per frame; whole-output stats {whole}")
+    print(f"bf16-autocast decode {bf16_s:.0f} s; sampled {int(m.sum())} px per frame; whole-output stats {whole}")
     print("wrote", OUT, os.path.getsize(OUT) // 1024, "KiB")
+    if os.path.exists(part):
+        os.remove(part)
 
 
 if __name__ == "__main__":
