@@ -246,8 +246,14 @@ def measure_cfg_step(model, cfg, latent, ctx, steps=4, warmup=1):
     out = {"what": "one classifier-free-guidance denoising step = conditional + unconditional DiT forward + fused CFG combine + FlowUniPC step "
                    "(denoising.py:372-596), 50-step schedule, guidance 3.0, flow shift 3.0; same model, latent and text length as the contract line",
            "steps": steps, "warmup": warmup}
+    legs = []
     for name, batch in (("two_forwards", False), ("batch2_forward", True)):
-        loop = DenoisingLoopHip(model, 50, flow_shift=3.0, guidance_scale=3.0, cfg_batch=batch)
+        try:
+            loop = DenoisingLoopHip(model, 50, flow_shift=3.0, guidance_scale=3.0, cfg_batch=batch)
+        except ValueError as e:   # per-tensor fp8 refuses the batched pair (one absmax over both samples): keep the other leg
+            out[name] = {"skipped": str(e)}
+            continue
+        legs.append(name)
         loop.stepper.reset()
         x, x16 = x0.clone(), x0.to(torch.bfloat16)
         for i in range(warmup):
@@ -268,10 +274,54 @@ def measure_cfg_step(model, cfg, latent, ctx, steps=4, warmup=1):
                      "attn_mean_launch_ms": round(sum(a_ms) / len(a_ms), 4), "attn_tflops": round(fl / (sum(a_ms) * 1e-3) / 1e12, 1)}
     S = (latent.shape[2]) * (latent.shape[3] // 2) * (latent.shape[4] // 2)
     fl_step = 2 * __import__("fastvideo_amd.wan_config", fromlist=["x"]).algorithmic_flops(cfg, S, ctx.shape[1])["total"]
-    for name in ("two_forwards", "batch2_forward"):
+    for name in legs:
         out[name]["step_tflops"] = round(fl_step / (out[name]["ms_per_step"] * 1e-3) / 1e12, 1)
         out[name]["step_frac_of_bf16_peak"] = round(out[name]["step_tflops"] / PEAK_BF16_TFLOPS, 4)
-    out["batch2_speedup"] = round(out["two_forwards"]["ms_per_step"] / out["batch2_forward"]["ms_per_step"], 4)
+    if len(legs) == 2:
+        out["batch2_speedup"] = round(out["two_forwards"]["ms_per_step"] / out["batch2_forward"]["ms_per_step"], 4)
+    return out
+
+
+def measure_matrix_ceiling(local_rank, seconds=1.2):
+    """the matrix pipe's SUSTAINED bf16 rate on THIS box at THIS power cap, measured in this process right after the
+    contract measurements — a registers-only stream of v_mfma_f32_16x16x32_bf16 (the instruction of the attention, GEMM and conv kernels) on
+    normal-like operands (fvk_mfma_sustained_probe_bf16; no LDS, no memory traffic, one wave per SIMD), with the socket power and shader clock
+    it ran at.  It is what ANY kernel multiplying real activations could at most reach here (2049-2078 TF at 1400 W, 82 % of
+    the 2.5-PF peak `roofline.frac` stays priced against); the zero-operand run beside it shows the cycle-bound rate of the same loop."""
+    import importlib.util
+    from fastvideo_amd import ops
+    out = {"what": "registers-only v_mfma_f32_16x16x32_bf16 stream, 256 workgroups x 4 waves x 64 accumulator tiles, back to back for ~1.2 s per "
+                   "operand kind, in this process after the timed region (fvk_mfma_sustained_probe_bf16)"}
+    pt = None
+    try:
+        spec = importlib.util.spec_from_file_location("power_trace", os.path.join(ROOT, "scripts", "power_trace.py"))
+        pt = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(pt)
+    except Exception as ex:  # noqa: BLE001
+        out["power_error"] = repr(ex)[:200]
+    for name, data in (("normal_like_operands", 1), ("zero_operands", 0)):
+        sampler = None
+        if pt is not None:
+            try:
+                sampler = pt.PowerSampler(20.0, local_rank).start()
+            except Exception as ex:  # noqa: BLE001
+                out["power_error"] = repr(ex)[:200]
+        torch.cuda.synchronize()
+        w0 = time.time()
+        tf, n, ms = ops.mfma_sustained_probe(seconds if data else seconds / 2, data)
+        w1 = time.time()
+        rec = {"tflops": round(tf, 1), "frac_of_bf16_peak": round(tf / PEAK_BF16_TFLOPS, 4), "launches": n, "ms_per_launch": round(ms, 3)}
+        if sampler is not None:
+            try:
+                if sampler.available:
+                    # skip the first 0.3 s: three warm-up launches and the clock settling under the cap
+                    pw = pt.summarize(sampler.stop(), w0 + 0.3, w1, sampler.src.name)
+                    rec["power_w"], rec["sclk_mhz"] = pw.get("power_w"), pw.get("sclk_mhz")
+                else:
+                    sampler.stop()
+            except Exception as ex:  # noqa: BLE001
+                rec["power_error"] = repr(ex)[:200]
+        out[name] = rec
     return out
 
 
@@ -376,6 +426,7 @@ def main():
                     "over an untimed repeat of the K steps after the timed region (the `power` object)")
     ap.add_argument("--no-cfg-step", action="store_true", help="skip the `cfg_step` sub-object (the full classifier-free-guidance denoising step: "
                     "2 forwards + fused CFG / UniPC tail, measured after the timed region)")
+    ap.add_argument("--no-matrix-ceiling", action="store_true", help="skip roofline.matrix_ceiling (the registers-only MFMA stream timed after the timed region)")
     ap.add_argument("--no-vae", action="store_true", help="skip the `vae` sub-object (VAE decode of the same latent, measured after the timed region)")
     ap.add_argument("--cpu-baseline-kind", default="auto", choices=["auto", "reference", "port"],
                     help="auto: the reference itself when a reference tree is present (live or staged), else the oracle port")
@@ -600,6 +651,15 @@ def main():
             out["cfg_step"] = measure_cfg_step(model, cfg, latent, ctx)
         except Exception as ex:  # noqa: BLE001 - never hide the contract number
             out["cfg_step"] = {"error": repr(ex)[:300]}
+    if rank == 0 and not args.no_matrix_ceiling:
+        try:
+            mc = measure_matrix_ceiling(local_rank)
+            roof["sustained_matrix_rate_at_cap_tf"] = mc["normal_like_operands"]["tflops"]
+            roof["frac_of_sustained_matrix_rate"] = round(achieved / mc["normal_like_operands"]["tflops"], 4)
+            roof["matrix_ceiling"] = mc
+            out["step_frac_of_sustained_matrix_rate"] = round(out["step_tflops"] / (mc["normal_like_operands"]["tflops"] * world), 4)
+        except Exception as ex:  # noqa: BLE001 - never hide the contract number
+            roof["matrix_ceiling"] = {"error": repr(ex)[:300]}
     if world == 1 and args.config in ("cfg2", "cfg5") and not args.layers and not args.no_vae:
         # the other hot kernel family of the path, measured AFTER the timed region on the same latent geometry, so that the
         # driver's record carries it too: `vae` = the --stage vae line without its CPU baseline (3 decodes after 1 warm-up)

@@ -19,7 +19,7 @@ PROBE = _PROBE_SEL == "1" or _PROBE_SEL.startswith("bug")
 # (scripts/build_bug_strips.sh)
 LIB_PATH = (os.path.join(os.path.dirname(HERE), "scripts", "probes", f"libfvk_{_PROBE_SEL}.so" if _PROBE_SEL.startswith("bug") else "libfvk_probe.so")
             if PROBE else os.path.join(HERE, "libfvk_amd.so"))
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -52,6 +52,7 @@ SIGNATURES = {
     "fvk_gemm_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i32, vp, vp, i32, vp],
     "fvk_gemm_bf16_batched": [vp, vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, i64, i32, f32, vp],
     "fvk_gemm_vt_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, i64, i64, i32, vp],
+    "fvk_mfma_sustained_probe_bf16": [vp, i32, i32, i32, vp],
     "fvk_attn_dense_bf16": [C.POINTER(AttnArgs), vp],
     "fvk_attn_dense_kernel_bf16": [C.POINTER(AttnArgs), i32, vp],
     "fvk_attn_dense_split_bf16": [C.POINTER(AttnArgs), i32, vp, vp, vp],

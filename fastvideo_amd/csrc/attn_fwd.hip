@@ -53,6 +53,7 @@ struct ModeArgs {
     // q_rows_valid[i] (optional) = real query rows of list i's q_stride rows.  q_stride = 0: one list per BMQ rows (the plain form).
     const int32_t* q_rows_valid;
     int q_stride, q_offset, n_lists;
+    int xcd_deal;  // block-sparse lists: XCD c (hardware workgroup id % 8) takes the CONTIGUOUS logical ids [c * n / 8, ...) — see the kernel
     // STA
     int ct, ch, cw, tile_tokens;
     int win[3 * 64];
@@ -116,10 +117,20 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
     const int lw = compute ? wave % NW : 0;                          // index among the pair's compute waves
     const int nqb = (MODE == MODE_BLOCKS && ma.q_stride) ? ma.n_lists : (a.Sq + BMQ - 1) / BMQ;  // query blocks (= KV lists) per head
     const int nwg = (nqb + PAIRS - 1) / PAIRS;                       // workgroups per head
-    const int qb = (blockIdx.x % nwg) * PAIRS + pr;
+    // XCD-aware deal (round 6, block-sparse lists): hardware workgroup id x runs on XCD x % 8, each with its own 4-MiB L2.  Dealt round-robin,
+    // the neighbouring query blocks of the tile-major order — whose lists share 61-66 % of their KV blocks (profiles/r04g_vsa_union_overlap.log)
+    // — land on eight different L2s; dealt contiguously, one XCD walks a run of neighbouring query blocks of ONE head at a time, in step
+    // (equal list lengths), and its L2 serves the re-reads.
+    int bid_ = blockIdx.x;
+    if (MODE == MODE_BLOCKS && ma.xcd_deal) {
+        const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
+        bid_ = xcd * xq + (xcd < xr ? xcd : xr) + (int)(blockIdx.x >> 3);
+    }
+    const int bid = bid_;
+    const int qb = (bid % nwg) * PAIRS + pr;
     const bool pair_ok = PAIRS == 1 || qb < nqb;
-    const int h = (blockIdx.x / nwg) % a.H;
-    const int b = blockIdx.x / (nwg * a.H);
+    const int h = (bid / nwg) % a.H;
+    const int b = bid / (nwg * a.H);
     unsigned char* const smem_p = smem + pr * (2 * STAGE_BYTES);     // this pair's double-buffered stage
     constexpr int LIST_CAP = MODE == MODE_BLOCKS ? 2048 : 0;         // KV-list entries kept in LDS per query block (8 KiB)
     int32_t* const lds_lists = reinterpret_cast<int32_t*>(smem + PAIRS * 2 * STAGE_BYTES);
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
     if (MODE == MODE_DENSE) {
         n_tiles = (a.Skv + 63) >> 6;
     } else if (MODE == MODE_BLOCKS) {
-        const long meta = UNION ? ((long)b * a.H + h) * nwg + (blockIdx.x % nwg) : ((long)b * a.H + h) * nqb + (pair_ok ? qb : 0);
+        const long meta = UNION ? ((long)b * a.H + h) * nwg + (bid % nwg) : ((long)b * a.H + h) * nqb + (pair_ok ? qb : 0);
         n_tiles = (UNION || pair_ok) ? ma.q2k_num[meta] : 0;
         if (!UNION && ma.q_rows_valid && pair_ok && ma.q_offset >= ma.q_rows_valid[qb]) n_tiles = 0;  // only padding rows
         blk_list = ma.q2k_idx + meta * ma.max_kv;
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(PAIRS * (NW + NL) * 64, (PAIRS * (NW + NL) == 2 ? 1
         // a second, dependent round trip.  One cooperative fill here, then a ~100-cycle uniform ds_read per tile.
         {
         for (int p = 0; p < PAIRS; ++p) {
-            const int qb_p = (blockIdx.x % nwg) * PAIRS + p;
+            const int qb_p = (bid % nwg) * PAIRS + p;
             if (qb_p < nqb) {
                 const long meta_p = ((long)b * a.H + h) * nqb + qb_p;
                 int n_p = ma.q2k_num[meta_p];
@@ -646,6 +657,9 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     ma.q2k_num = q2k_num;
     ma.kv_block_sizes = kv_block_sizes;
     ma.max_kv = max_kv;
+#if FVK_VARIANTS
+    ma.xcd_deal = fvk::tunable(fvk::TUNE_VSA_IMPL) == 2;   // A/B of the XCD-contiguous workgroup deal ("vsa_impl" 2)
+#endif
     // one workgroup per list: 2 waves (64 rows, the VSA block) or 4 waves (128 rows sharing every K/V tile: sliding-tile windows,
     // where all query blocks of a tile attend the same KV blocks)
     if (q_block == 128) {

@@ -459,6 +459,9 @@ int gemm_w1_vt_launch(GemmArgs a, int batch, hipStream_t s) {
     a.ntm = (a.M + TM - 1) / TM;
     a.ntn = (a.N + TN - 1) / TN;
     // V^T [d, S_pad] is a wide output (N = S): streaming stores, as for every N >= 4096 (gemm_w1_launch) — VAR 143
+#if FVK_VARIANTS
+    if (fvk::tunable(fvk::TUNE_GEMM_IMPL) == 2) return launch<FVK_EPI_VT, 15>(a, batch, s);  // A/B in the step: plain stores
+#endif
     return launch<FVK_EPI_VT, 143>(a, batch, s);
 }
 

@@ -95,11 +95,17 @@ class SequenceParallel:
         # 128 + 64; FVK_SP_OVERLAP=2 runs the second chunk on a second HIP stream instead).  Heads are independent in attention, so the result
         # is the plain exchange's bit for bit — checked on the first call (all-reduced verdict); any rank seeing a difference switches every
         # rank back to the plain exchange.
-        # DEFAULT (round 5): ON in stream order for P >= 4, OFF for P = 2.  The compute-side cost is measured and is what decides
-        # (profiles/r04z_sp_chunk_launch_ab.log): two chunk launches cost nothing at P = 4 / 8 (the key axis is cut into runs there anyway)
-        # and 18 % of the attention time at P = 2 unless the second chunk runs on its own stream — so P = 2 keeps the single collective.
-        # What it HIDES needs xGMI and has never been measured.  FVK_SP_OVERLAP = 0 / 1 / 2 forces plain / one stream / two streams.
-        mode = {"0": 0, "1": 1, "2": 2}.get(os.environ.get("FVK_SP_OVERLAP", "auto"), 1 if P >= 4 else 0)
+        # DEFAULT (round 6): the PLAIN exchange at every P.  Round 5 switched P >= 4 to the pipelined form on the strength of a compute-side
+        # A/B only (profiles/r04z_sp_chunk_launch_ab.log: two chunk launches are free at P = 4 / 8, cost 18 % of the attention at P = 2);
+        # what it HIDES needs xGMI links and has never been measured, so it stays opt-in until one 4 / 8-GPU RCCL run has
+        # validated it for time and for hangs.  FVK_SP_OVERLAP = 0 / 1 / 2 forces plain / one stream / two streams; the mode in use is
+        # logged once per process and printed in bench.py's line.
+        mode = {"0": 0, "1": 1, "2": 2}.get(os.environ.get("FVK_SP_OVERLAP", "auto"), 0)
+        if P > 1 and rank == 0:
+            import logging
+            logging.getLogger("fastvideo_amd").info("sequence-parallel exchange mode: %s (FVK_SP_OVERLAP=%s)",
+                                                     ("plain", "pipelined, one stream", "pipelined, two streams")[mode],
+                                                     os.environ.get("FVK_SP_OVERLAP", "unset"))
         self.overlap = P > 1 and mode > 0
         self.overlap_streams = 2 if mode == 2 else 1   # 2: chunk B's attention on a second HIP stream
         self._side_stream = None

@@ -244,12 +244,26 @@ def v_transpose(v, src_rows=None):
     return vt
 
 
-def gemm_vt_eligible(x, w) -> bool:
-    """Whether fvk_gemm_vt_bf16 serves V^T = w · x^T for token rows x [B, S, K] (or [S, K]) and V weight rows w [d, K]."""
+def gemm_vt_eligible(x, w, bias=None) -> bool:
+    """Whether fvk_gemm_vt_bf16 serves V^T = w · x^T for token rows x [B, S, K] (or [S, K]) and V weight rows w [d, K].  Mirrors EVERY gate of
+    the C side (gemm_bf16.hip: fvk_gemm_vt_bf16 -> gemm_pp_eligible / gemm_ph_eligible / gemm_w1_eligible), so that a caller which falls back
+    to gemm + v_transpose on this predicate never meets FVK_ERR_ARG in the middle of a forward: 16-byte aligned operands (storage offsets of
+    views count), B <= 65535, batch strides in whole 16-byte units, 32-bit byte offsets inside one 256-row panel."""
     K = x.shape[-1]
     S = x.shape[-2]
-    return (x.dtype == BF16 and w.dtype == BF16 and K % 128 == 0 and w.shape[0] % 128 == 0 and w.shape[0] > 128 and S % 8 == 0
-            and x.is_contiguous() and w.is_contiguous())
+    B = x.shape[0] if x.dim() == 3 else 1
+    d = w.shape[0]
+    if not (x.dtype == BF16 and w.dtype == BF16 and x.dim() in (2, 3) and w.dim() == 2 and w.shape[1] == K):
+        return False
+    if not (K % 128 == 0 and K >= 128 and d % 128 == 0 and d > 128 and S > 0 and S % 8 == 0 and 1 <= B <= 65535):
+        return False
+    if not (x.is_contiguous() and w.is_contiguous()):
+        return False
+    if x.data_ptr() % 16 or w.data_ptr() % 16 or (bias is not None and bias.data_ptr() % 8):
+        return False
+    if (S * K) % 8:   # x batch stride in elements
+        return False
+    return 255 * K * 2 + K * 2 <= 0x7fffffff
 
 
 def gemm_vt(x, w, bias=None):
@@ -261,7 +275,7 @@ def gemm_vt(x, w, bias=None):
         x = x[None]
     B, S, K = x.shape
     d = w.shape[0]
-    if not gemm_vt_eligible(x, w) or w.shape[1] != K:
+    if not gemm_vt_eligible(x, w, bias):
         raise RuntimeError(f"gemm_vt: shape not served (x {tuple(x.shape)}, w {tuple(w.shape)}): use gemm + v_transpose")
     if bias is not None:
         _chk(bias, BF16, "bias")
@@ -849,3 +863,30 @@ def silu(x):
     out = torch.empty_like(x)
     _lib.call("fvk_silu_bf16", _p(x), _p(out), x.numel(), _stream())
     return out
+
+
+def mfma_sustained_probe(seconds: float = 1.0, data: int = 1, workgroups: int = 256, iters: int = 20000):
+    """Measurement (bench.py): the registers-only 16x16x32 bf16 MFMA stream of fvk_mfma_sustained_probe_bf16, launched back to back for about
+    ``seconds`` on the current stream.  Returns (TFLOP/s, launches, ms per launch)."""
+    import time
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out = torch.empty(workgroups * 256, dtype=torch.float32, device=dev)
+    fl = workgroups * 4.0 * iters * 64 * 16384
+    for _ in range(3):  # warm-up: clock ramp and module load
+        _lib.call("fvk_mfma_sustained_probe_bf16", _p(out), workgroups, iters, data, _stream())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n, t0 = 0, time.perf_counter()
+    e0.record()
+    while True:
+        for _ in range(8):
+            _lib.call("fvk_mfma_sustained_probe_bf16", _p(out), workgroups, iters, data, _stream())
+        n += 8
+        torch.cuda.synchronize()
+        if time.perf_counter() - t0 >= seconds:
+            break
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    return fl / (ms * 1e-3) / 1e12, n, ms
+

@@ -562,7 +562,7 @@ class WanTransformer3DModelHip:
             # bit-identical to the fused QKV GEMM + the V^T layout pass, without writing V, reading it back and a launch of that pass
             vt_i = None
             if (self.vt_gemm and P == 1 and self.attention == "dense" and not self.quant and b["n_qkv"] == 3
-                    and ops.gemm_vt_eligible(nh.view(B, Sl, d), b["qkv_w"][2 * d:])):
+                    and ops.gemm_vt_eligible(nh.view(B, Sl, d), b["qkv_w"][2 * d:], b["qkv_b"][2 * d:])):
                 qkv = ops.gemm(nh, b["qkv_w"][:2 * d], b["qkv_b"][:2 * d])       # [B*S, 2d]: q | k
                 vt_i = ops.gemm_vt(nh.view(B, Sl, d), b["qkv_w"][2 * d:], b["qkv_b"][2 * d:])
             elif self.quant and b["n_qkv"] == 4:
@@ -615,6 +615,8 @@ class WanTransformer3DModelHip:
                     attn = o
                 else:
                     attn[bi * Sl:(bi + 1) * Sl] = o
+            if trace is not None:   # the self-attention output in token order, before the out-projection (tests/test_gpu_bigseq.py)
+                trace[f"blocks.{i}.attn"] = attn.view(B, Sl, d).clone()
             a_out = self._lin(attn, b, "o", b["o_b"])
             nh, x = ops.ln_modulate(a_out, residual=x, gate=gate_i, ln_w=b["ln2_w"], ln_b=b["ln2_b"], eps=self.eps,
                                     want_residual=True, rows_per_batch=rpb, fp8_rowwise=fq)

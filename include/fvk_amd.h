@@ -27,7 +27,7 @@ extern "C" {
 #define FVK_ERR_LAUNCH (-2)  /* hipLaunch / hip runtime error                  */
 
 const char* fvk_last_error(void);
-int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3, 6 = round 4) */
+int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3, 6 = round 4, 7 = round 5's fvk_gemm_vt_bf16 + round 6's fvk_mfma_sustained_probe_bf16) */
 int fvk_device_arch(char* buf, int len);   /* gcnArchName of the current device ("gfx950...") */
 int fvk_is_probe_build(void);              /* 0: the product library; 1: the measurement build (scripts/probes/libfvk_probe.so) */
 /* Integer knobs for within-process A/B measurements (scripts/microbench.py); 0 = shipped configuration.
@@ -385,6 +385,13 @@ int fvk_unpatchify_bf16(const void* x, void* latent, int B, int C, int T, int Hh
 int fvk_timestep_embedding_bf16(const float* t, void* out, int B, int dim, float max_period, void* stream);
 /* y = bf16(silu(float(x))) elementwise, n % 8 == 0. */
 int fvk_silu_bf16(const void* x, void* y, long n, void* stream);
+
+/* ------------------------------------------------------------------ measurement: the matrix pipe's sustained bf16 rate on THIS device
+ * (no reference counterpart; SURVEY §8d asks for "the measured peaks on the box" next to every result).  `workgroups` x 4 waves (one per
+ * SIMD) each issue iters x 64 register-only v_mfma_f32_16x16x32_bf16 on normal-like operands (data = 1) or zeros (data = 0): 16 384 FLOP per
+ * instruction, no LDS, no memory traffic in the loop.  out: >= workgroups * 256 floats of scratch.  bench.py times it after the timed
+ * region and prints roofline.sustained_matrix_rate_at_cap_tf with the socket power and shader clock it ran at. */
+int fvk_mfma_sustained_probe_bf16(float* out, int workgroups, int iters, int data, void* stream);
 
 #ifdef __cplusplus
 }

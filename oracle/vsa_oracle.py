@@ -174,11 +174,12 @@ def block_sparse_attn(q, k, v, block_map: np.ndarray, vbs: np.ndarray, block: in
     return torch.matmul(torch.softmax(s, dim=-1), v.float())
 
 
-def block_sparse_attn_gathered(q, k, v, block_map: np.ndarray, vbs: np.ndarray, block: int = 64) -> torch.Tensor:
+def block_sparse_attn_gathered(q, k, v, block_map: np.ndarray, vbs: np.ndarray, block: int = 64, q_blocks=None) -> torch.Tensor:
     """The SAME arithmetic as ``block_sparse_attn`` (exact fp32 softmax over the valid columns of the selected KV blocks, scale
     1/sqrt(D)), evaluated one query block at a time over ITS selected blocks only, so that the real geometry (S_pad = 39 936, 12 heads,
     top-125 of 624 blocks) needs megabytes instead of the 76 GB of a dense [B,H,S,S] score tensor.  Equal to the dense-mask form up to
-    fp32 summation order (tests/test_oracle_chunked.py).  q,k,v [B,H,S_pad,D] -> fp32."""
+    fp32 summation order (tests/test_oracle_chunked.py).  q,k,v [B,H,S_pad,D] -> fp32.  ``q_blocks``: evaluate only these query blocks
+    (the other rows of the result stay zero) — the sampled form for BASELINE config 5's 2 160 blocks (tests/test_gpu_bigseq.py)."""
     B, H, S, D = q.shape
     nq = S // block
     out = torch.zeros((B, H, S, D), dtype=torch.float32)
@@ -190,7 +191,7 @@ def block_sparse_attn_gathered(q, k, v, block_map: np.ndarray, vbs: np.ndarray, 
         for h in range(H):
             kb = kf[b, h].view(-1, block, D)
             vbk = vf[b, h].view(-1, block, D)
-            for i in range(nq):
+            for i in (range(nq) if q_blocks is None else q_blocks):
                 sel = torch.from_numpy(np.nonzero(block_map[b, h, i])[0])
                 if sel.numel() == 0:
                     continue
@@ -201,12 +202,14 @@ def block_sparse_attn_gathered(q, k, v, block_map: np.ndarray, vbs: np.ndarray, 
     return out
 
 
-def video_sparse_attn(q, k, v, vbs, q_vbs, topk: int, block_elements: int = 64, gate=None, mask_override=None, gathered: bool = False):
+def video_sparse_attn(q, k, v, vbs, q_vbs, topk: int, block_elements: int = 64, gate=None, mask_override=None, gathered: bool = False,
+                      q_blocks=None):
     """``video_sparse_attn`` — fastvideo-kernel/python/fastvideo_kernel/ops.py:65-133.
     q,k,v(,gate) [B,H,S_pad,D] bf16.  Returns (out bf16, dict of intermediates).
     ``mask_override`` (bool [B,H,Nq,Nkv]) replaces the top-k selection: tests feed the mask the device computed from ITS coarse
     scores (a bf16 ulp in one score can flip a near-tie), so that the composite is compared block for block.  ``gathered``: evaluate
-    the sparse branch block by block (block_sparse_attn_gathered) — the form that fits the real geometry in memory."""
+    the sparse branch block by block (block_sparse_attn_gathered) — the form that fits the real geometry in memory; ``q_blocks`` (gathered
+    form only): the sparse branch on these query blocks only (the rows of every other block hold the coarse branch alone)."""
     B, H, S, D = q.shape
     q_c = block_mean(q, q_vbs, block_elements)
     k_c = block_mean(k, vbs, block_elements)
@@ -216,7 +219,11 @@ def video_sparse_attn(q, k, v, vbs, q_vbs, topk: int, block_elements: int = 64, 
     out_c = torch.matmul(attn, v_c)
     out_c = out_c.view(B, H, S // block_elements, 1, D).repeat(1, 1, 1, block_elements, 1).view(B, H, S, D)
     mask = topk_mask_bisect(scores.float().numpy(), topk) if mask_override is None else mask_override
-    out_s = (block_sparse_attn_gathered if gathered else block_sparse_attn)(q, k, v, mask, vbs, block_elements).to(q.dtype)
+    if q_blocks is not None:
+        assert gathered, "q_blocks: gathered form only"
+        out_s = block_sparse_attn_gathered(q, k, v, mask, vbs, block_elements, q_blocks=q_blocks).to(q.dtype)
+    else:
+        out_s = (block_sparse_attn_gathered if gathered else block_sparse_attn)(q, k, v, mask, vbs, block_elements).to(q.dtype)
     out = out_c * gate + out_s if gate is not None else out_c + out_s
     return out, dict(q_c=q_c, k_c=k_c, v_c=v_c, scores=scores, mask=mask, out_c=out_c, out_s=out_s)
 
