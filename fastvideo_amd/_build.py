@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfvk_amd.so")
-SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.hip", "gemm_w1.hip", "gemm_w1n.hip", "fp8.hip", "attn_fwd.hip", "attn_pp2.hip", "attn_w16.hip", "attn_w64.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_conv3w.hip", "vae_post.hip", "sched_step.hip", "mfma_probe.hip"]
+SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.hip", "gemm_w1.hip", "gemm_w1n.hip", "fp8.hip", "attn_fwd.hip", "attn_bs16.hip", "attn_pp2.hip", "attn_w16.hip", "attn_w64.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_conv3w.hip", "vae_post.hip", "sched_step.hip", "mfma_probe.hip"]
 # measurement build (scripts/probes/libfvk_probe.so): the same sources with -DFVK_PROBE_BUILD (variant dispatch + fvk_set_tunable knobs
 # compiled in) plus the experiment kernels that never shipped.  Nothing in the product path loads it (fastvideo_amd/_lib.py: FVK_PROBE_LIB=1).
 PROBE_DIR = os.path.join(HERE, "..", "scripts", "probes")
@@ -103,7 +103,7 @@ def _build_locked(verbose: bool, probe: bool = False, bug: bool = False) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         extra = ["-ffp-contract=off"] if src in ("sched_step.hip", "vae_post.hip") else []  # bit-exact fp32 arithmetic (no fused multiply-add)
-        if src in ("attn_w16.hip", "attn_w64.hip", "gemm_w1.hip", "gemm_w1n.hip", "vae_conv3w.hip"):
+        if src in ("attn_w16.hip", "attn_w64.hip", "attn_bs16.hip", "gemm_w1.hip", "gemm_w1n.hip", "vae_conv3w.hip"):
             # its 64-chunk iteration must be FULLY unrolled (every register-array index a constant): above clang's default budget for
             # `#pragma unroll`, silently left as a loop otherwise — with the wave's whole register struct in scratch
             extra += ["-mllvm", "-pragma-unroll-threshold=100000"]

@@ -33,6 +33,8 @@ int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, h
 #endif
 int fvk_attn_vsa_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
                         hipStream_t s);  // attn_vsa.hip: 64-row lists, key-split, register-staged prefetch
+int fvk_attn_bs16_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
+                         int variant, hipStream_t s);  // attn_bs16.hip (round 6): 64-row lists, one wave per list, attn_w16's in-wave pipeline
 
 namespace {
 
@@ -669,10 +671,13 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
 #endif
         return launch<4, MODE_BLOCKS>(a, ma, (hipStream_t)stream);
     }
-    // 64-row lists (the VSA block): two lists per 8-wave workgroup, each with 2 compute + 2 loader waves ("attn_impl" 50 = the former
-    // one-list 4-wave workgroups, two per CU, for A/B)
+    // 64-row lists (the VSA block).  Shipped since round 6: attn_bs16.hip — one wave per list on attn_w16's in-wave software pipeline, private
+    // 5-slot LDS rings, no barriers, XCD-contiguous ids.  Measurement build: "attn_impl" 55 = the round-1..5 kernel of this file (two lists per
+    // 8-wave workgroup, each with 2 compute + 2 loader waves; with "vsa_impl" 2 on XCD-contiguous ids), 56 = attn_bs16 on hardware workgroup
+    // ids, 50 = the former one-list 4-wave workgroups, two per CU
 #if FVK_VARIANTS
     const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
+    if (impl == 0 || impl == 56) return fvk_attn_bs16_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, impl == 56, (hipStream_t)stream);
     if (impl == 50) return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);
     // Shipped: two lists per workgroup, 2 compute + 2 loader waves each, one-stage-ahead LDS-DMA.  Two alternatives were built to attack what
     // looked like its limits and are kept for A/B because BOTH land on the same ~23 B / clock / CU of K / V^T ingest (2.55-2.60 ms at cfg2):
@@ -682,8 +687,10 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     // i.e. neither the prefetch depth nor the single compute wave per SIMD is the bound; the per-CU ingest rate is.
     if (impl == 53) return launch<2, MODE_BLOCKS, 128, 2, 2, true>(a, ma, (hipStream_t)stream);
     if (impl == 54 && max_kv <= 2048) return fvk_attn_vsa_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, (hipStream_t)stream);
+    return launch<2, MODE_BLOCKS, 128, 2, 2>(a, ma, (hipStream_t)stream);  // 55 (and every other value)
+#else
+    return fvk_attn_bs16_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, 0, (hipStream_t)stream);
 #endif
-    return launch<2, MODE_BLOCKS, 128, 2, 2>(a, ma, (hipStream_t)stream);
 }
 
 extern "C" int fvk_attn_block_sparse_union_bf16(const fvk_attn_args* a, const int32_t* u_idx, const int32_t* u_num, int max_u, void* stream) {

@@ -224,8 +224,10 @@ int fvk_attn_dense_split_bf16(const fvk_attn_args* a, int n_split, float* o_part
  * blocks q2k_idx[b,h,i,0..q2k_num[b,h,i]) (64 keys each, of which the first kv_block_sizes[j] are valid).
  * ref: fastvideo-kernel/csrc/attention/block_sparse_h100.cu:66-272, triton_kernels/block_sparse_attn_triton.py:32-160.
  * q2k_idx int32 [B,H,Nq,max_kv], q2k_num int32 [B,H,Nq] with Nq = Sq / q_block, kv_block_sizes int32 [Nkv]. Skv multiple of 64.
- * A list may be empty (q2k_num = 0: the block's output rows are written as zeros) and a listed block may have size 0.  Block ids
- * must be < 2^24; the first 2048 entries of a list are kept in LDS (longer lists fall back to global reads past that point).
+ * A list may be empty (q2k_num = 0: the block's output rows are written as zeros) and a listed block may have size 0 (as the FIRST block of a
+ * 64-row list it sends the rows through the exact pass: it would have set the softmax reference).  q_block 64 (round 6, attn_bs16.hip): one wave per list, lists read with scalar loads (any
+ * length up to max_kv; ids outside [0, Skv / 64) are clamped).  q_block 128: block ids must be < 2^24; the first 2048 entries of a list are
+ * kept in LDS (longer lists fall back to global reads past that point).
  * Every entry point taking fvk_attn_args refuses (FVK_ERR_ARG) a (batch, head) K slice whose extent reaches 4 GiB: the K / V^T
  * streams are addressed through 32-bit buffer descriptors. */
 int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,

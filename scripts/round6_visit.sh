@@ -33,5 +33,10 @@ PY
   F=$(find $OUT/vt_ab -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && python scripts/condense_prof.py $F $OUT/vt_ab_kernel_stats.csv
   find $OUT -name "*.csv" -size +2M -delete
   ;;
+2)
+  # the new block-sparse kernel (attn_bs16.hip): every test that reaches it, then the kernel-level A/B against the round-1 kernel
+  timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_ref_triton.py tests/test_gpu_boundary.py -x -q -k "sparse or vsa or block or triton" > $OUT/sparse_tests.log 2>&1; echo "sparse tests rc=$?"; tail -15 $OUT/sparse_tests.log
+  timeout 300 python scripts/vsa_bs16_ab.py > $OUT/vsa_bs16_ab.log 2>&1; echo "bs16_ab rc=$?"; tail -40 $OUT/vsa_bs16_ab.log
+  ;;
 esac
 echo "visit $V done"
