@@ -64,6 +64,7 @@ struct IterArgs {
     int valid_prev;                       // valid keys of block t-1 (masks P(t-1))
 };
 
+template <int AUX>
 struct BS16 {
     bf16x8 qf[4][4];     // Q fragments [q block][k-step of 32 d]   (accumulator file)
     f32x4 o[4][9];       // O^T accumulators [q block][16-row d block]; block 8 = the row sums (A operand all ones)
@@ -82,12 +83,12 @@ struct BS16 {
     // piece p (0..7) of K group G (keys 32 G + 4 p .. + 4) of the block whose rows start kb bytes into the head's K slice -> slot
     __device__ __forceinline__ void issue_k(int G, int p, int slot, unsigned kb) const {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + slot + p * 1024), 16, kv[(p & 1) + 2 * (p >> 2)],
-                                                 __builtin_amdgcn_readfirstlane(kb + (unsigned)(8 * G + p) * k_pstride), 0, 0);
+                                                 __builtin_amdgcn_readfirstlane(kb + (unsigned)(8 * G + p) * k_pstride), 0, AUX);
     }
     // piece p (0..7) of V^T half hf (d rows 64 hf + 8 p .. + 8) of the block whose columns start vb bytes into a V^T row -> slot
     __device__ __forceinline__ void issue_v(int hf, int p, int slot, unsigned vb) const {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + slot + p * 1024), 16, vv[p & 1],
-                                                 __builtin_amdgcn_readfirstlane(vb + (unsigned)(8 * hf + p) * v_pstride), 0, 0);
+                                                 __builtin_amdgcn_readfirstlane(vb + (unsigned)(8 * hf + p) * v_pstride), 0, AUX);
     }
     // V^T fragment: 32-key group G, d block db (0..7) — half db >> 2;  K fragment: score tile T = 2 * group + a/b, k-step ks
     __device__ __forceinline__ bf16x8 frag_v(int G, int db, int sVa, int sVb) const {
@@ -342,7 +343,7 @@ __device__ __forceinline__ int slot_of(int h, int k) {
     return (t >= NSLOT ? t - NSLOT : t) * SLOT;
 }
 
-template <bool PLAIN_IDS = false>
+template <bool PLAIN_IDS = false, int AUX = 0>
 __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, const int32_t* __restrict__ q2k_idx, const int32_t* __restrict__ q2k_num,
                                                            const int32_t* __restrict__ kv_block_sizes, int max_kv) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
     const bf16_t* vtp = (const bf16_t*)a.vt + ((long)b * a.H + h) * 128L * a.Skv_pad;
     bf16_t* op = (bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs;
 
-    BS16 w;
+    BS16<AUX> w;
     w.smem = smem_all + wave * WAVE_LDS;
     w.c2 = a.scale * 1.4426950408889634f;
     w.lp = 16 * (g >> 1) + 4 * (g & 1);
@@ -446,15 +447,15 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
         }
         wait_vm<0>();
         __builtin_amdgcn_sched_barrier(0);
-        w.qk_plain<0>(0, SLOT);
-        if (valA < 64) w.mask_keys<0>(valA, g);
+        w.template qk_plain<0>(0, SLOT);
+        if (valA < 64) w.template mask_keys<0>(valA, g);
         // the fixed reference: exact row max of the first block (it has at least one valid key)
-        w.m_run[0] = w.row_max<0, 0>();
-        w.m_run[1] = w.row_max<0, 1>();
-        w.m_run[2] = w.row_max<0, 2>();
-        w.m_run[3] = w.row_max<0, 3>();
-        w.exp_pack_all<0>();
-        w.qk_plain<1>(2 * SLOT, 3 * SLOT);
+        w.m_run[0] = w.template row_max<0, 0>();
+        w.m_run[1] = w.template row_max<0, 1>();
+        w.m_run[2] = w.template row_max<0, 2>();
+        w.m_run[3] = w.template row_max<0, 3>();
+        w.template exp_pack_all<0>();
+        w.template qk_plain<1>(2 * SLOT, 3 * SLOT);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // every fragment read of slots 0-3 has returned: the slots may be overwritten
         __builtin_amdgcn_sched_barrier(0);
         // the ring as iteration 1 (head 0) expects it, in the steady state's ISSUE ORDER (the counted waits count on it):
@@ -485,11 +486,11 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
             IterArgs c;
             c.sVa = slot_of(hd, 0); c.sVb = slot_of(hd, 1); c.sKa = slot_of(hd, 2); c.sKb = slot_of(hd, 3); c.sSp = slot_of(hd, 4);
             c.vb_t = (unsigned)idA * 128u; c.kb_t2 = (unsigned)idC * kblk; c.vb_t1 = (unsigned)idB * 128u; c.valid_prev = valA;
-            w.iter<0>(c);
+            w.template iter<0>(c);
             hd = hd == 0 ? 4 : hd - 1;  // + 4 mod 5
             c.sVa = slot_of(hd, 0); c.sVb = slot_of(hd, 1); c.sKa = slot_of(hd, 2); c.sKb = slot_of(hd, 3); c.sSp = slot_of(hd, 4);
             c.vb_t = (unsigned)idB * 128u; c.kb_t2 = (unsigned)idD * kblk; c.vb_t1 = (unsigned)idC * 128u; c.valid_prev = valB;
-            w.iter<1>(c);
+            w.template iter<1>(c);
             hd = hd == 0 ? 4 : hd - 1;
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(idE), "+s"(idF), "+s"(valC), "+s"(valD)::"memory");
             idE = idE < 0 ? 0 : (idE < nkv ? idE : nkv - 1);
@@ -507,14 +508,14 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
 #pragma unroll
         for (int p = 0; p < 8; ++p) w.issue_v(1, p, slot_of(hd, 2), (unsigned)idA * 128u);
         __builtin_amdgcn_sched_barrier(0);
-        if (valA < 64) w.mask_p<0>(valA);
-        w.pv_plain<0>(slot_of(hd, 0), slot_of(hd, 1));
-        w.fence_s<1>();
-        w.exp_pack_all<1>();
-        if (valB < 64) w.mask_p<1>(valB);
+        if (valA < 64) w.template mask_p<0>(valA);
+        w.template pv_plain<0>(slot_of(hd, 0), slot_of(hd, 1));
+        w.template fence_s<1>();
+        w.template exp_pack_all<1>();
+        if (valB < 64) w.template mask_p<1>(valB);
         wait_vm<0>();
         __builtin_amdgcn_sched_barrier(0);
-        w.pv_plain<1>(slot_of(hd, 4), slot_of(hd, 2));
+        w.template pv_plain<1>(slot_of(hd, 4), slot_of(hd, 2));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     w.fence_o();  // the last MFMAs' results before the epilogue's v_accvgpr_read
@@ -554,13 +555,18 @@ int fvk_attn_bs16_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const i
     const long nblk = nwg * a->H * a->B;
     FVK_CHECK(nblk < 0x7fffffffL, FVK_ERR_ARG, "fvk_attn_block_sparse_bf16: grid too large");
 #if FVK_VARIANTS
-    if (variant == 1) {
-        static FvkLdsConfigured configured1;
-        if (int rc = fvk_config_lds(configured1, (const void*)attn_bs16_kernel<true>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16)")) return rc;
-        hipLaunchKernelGGL((attn_bs16_kernel<true>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num, kv_block_sizes, max_kv);
-        FVK_LAUNCH_CHECK();
-        return FVK_OK;
+#define FVK_BS16_VARIANT(N, ...)                                                                                                          \
+    if (variant == N) {                                                                                                                   \
+        static FvkLdsConfigured configured_v;                                                                                             \
+        if (int rc = fvk_config_lds(configured_v, (const void*)attn_bs16_kernel<__VA_ARGS__>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16)")) return rc; \
+        hipLaunchKernelGGL((attn_bs16_kernel<__VA_ARGS__>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num, kv_block_sizes, max_kv); \
+        FVK_LAUNCH_CHECK();                                                                                                               \
+        return FVK_OK;                                                                                                                    \
     }
+    FVK_BS16_VARIANT(1, true, 0)    // hardware workgroup order
+    FVK_BS16_VARIANT(2, false, 2)   // LDS-DMA pieces with the nt policy (aux = 2)
+    FVK_BS16_VARIANT(3, false, 1)   // ... with sc0 (aux = 1)
+#undef FVK_BS16_VARIANT
 #endif
     (void)variant;
     static FvkLdsConfigured configured;

@@ -677,7 +677,8 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     // ids, 50 = the former one-list 4-wave workgroups, two per CU
 #if FVK_VARIANTS
     const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
-    if (impl == 0 || impl == 56) return fvk_attn_bs16_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, impl == 56, (hipStream_t)stream);
+    if (impl == 0 || (impl >= 56 && impl <= 58))   // 57 / 58: the LDS-DMA pieces with the nt / sc0 cache policy
+        return fvk_attn_bs16_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, impl ? impl - 55 : 0, (hipStream_t)stream);
     if (impl == 50) return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);
     // Shipped: two lists per workgroup, 2 compute + 2 loader waves each, one-stage-ahead LDS-DMA.  Two alternatives were built to attack what
     // looked like its limits and are kept for A/B because BOTH land on the same ~23 B / clock / CU of K / V^T ingest (2.55-2.60 ms at cfg2):

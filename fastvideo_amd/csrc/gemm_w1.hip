@@ -514,7 +514,13 @@ int gemm_w1_launch(GemmArgs a, int epilogue, int batch, hipStream_t s) {
     if (epilogue == FVK_EPI_RESIDUAL_GATE && a.gate && a.rows_per_batch < 128) return launch_var<7>(a, epilogue, batch, s);
     // streaming output stores where the output is wide (N >= 4096: QKV, FFN-in, every 14B projection): +4 % on QKV, +6-10 % at the 14B shapes
     // (the freshly written tile does not push the operand panels out of L2 / MALL); -1 % where the output is the narrow residual stream
-    return a.N >= 4096 ? launch_var<143>(a, epilogue, batch, s) : launch_var<15>(a, epilogue, batch, s);
+    int nt_min = 4096;
+#if FVK_VARIANTS
+    if (impl == 3) nt_min = 3072;  // A/B: + the q | k projection (N = 3072 since the V^T GEMM left the fused QKV launch)
+    if (impl == 4) nt_min = 0;     // A/B: every output streamed
+    if (impl == 6) nt_min = 1 << 30;  // A/B: no streaming stores at all
+#endif
+    return a.N >= nt_min ? launch_var<143>(a, epilogue, batch, s) : launch_var<15>(a, epilogue, batch, s);
 }
 
 }  // namespace fvk

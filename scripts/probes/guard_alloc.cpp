@@ -1,0 +1,96 @@
+// Guard-page device allocator for out-of-bounds hunts: plugs into PyTorch through torch.cuda.memory.CUDAPluggableAllocator
+// (scripts/guard_run.py).  Every allocation gets its OWN virtual-address reservation: whole granules of physical memory mapped at the front, one
+// granule of UNMAPPED address space behind them, and the tensor is placed so that it ENDS where the mapping ends (FVK_GUARD_MODE=front: so that it
+// STARTS where the mapping starts, with the previous reservation's unmapped granule in front of it).  A read or write past the end (or in front of
+// the start) of ANY tensor — by 16 bytes or by gigabytes — is then a GPU page fault ("Memory access fault by GPU ... address 0x...") instead of a
+// silent read of a mapped neighbour, which is what the caching allocator turns every small overrun into.  Freed tensors are unmapped at once
+// (after a stream synchronisation), so a use after free faults as well.
+//   hipcc -O2 -shared -fPIC scripts/probes/guard_alloc.cpp -o scripts/probes/libguard_alloc.so
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+
+namespace {
+struct Rec {
+    void* base;
+    size_t reserved, mapped;
+    hipMemGenericAllocationHandle_t h;
+};
+std::unordered_map<void*, Rec> g_live;
+std::mutex g_mu;
+size_t g_gran = 0, g_align = 16;
+bool g_front = false;
+long g_allocs = 0, g_bytes = 0;
+
+#define GCHECK(x)                                                                                       \
+    do {                                                                                                \
+        hipError_t e_ = (x);                                                                            \
+        if (e_ != hipSuccess) {                                                                         \
+            fprintf(stderr, "[guard_alloc] %s failed: %s\n", #x, hipGetErrorString(e_));                \
+            abort();                                                                                    \
+        }                                                                                               \
+    } while (0)
+}  // namespace
+
+extern "C" void* guard_malloc(ssize_t size, int device, hipStream_t) {
+    if (size <= 0) size = 1;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_gran) {
+        GCHECK(hipMemGetAllocationGranularity(&g_gran, &prop, hipMemAllocationGranularityMinimum));
+        if (const char* a = getenv("FVK_GUARD_ALIGN")) g_align = (size_t)atol(a);
+        if (const char* m = getenv("FVK_GUARD_MODE")) g_front = m[0] == 'f';
+        fprintf(stderr, "[guard_alloc] granule %zu B, tensor alignment %zu B, tensors placed at the %s of their mapping\n", g_gran, g_align,
+                g_front ? "START" : "END");
+    }
+    const size_t need = ((size_t)size + g_align - 1) / g_align * g_align;
+    const size_t mapped = (need + g_gran - 1) / g_gran * g_gran;
+    const size_t reserved = mapped + g_gran;  // one unmapped granule behind the mapping
+    void* base = nullptr;
+    GCHECK(hipMemAddressReserve(&base, reserved, 0, nullptr, 0));
+    Rec r{base, reserved, mapped, {}};
+    GCHECK(hipMemCreate(&r.h, mapped, &prop, 0));
+    GCHECK(hipMemMap(base, mapped, 0, r.h, 0));
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    GCHECK(hipMemSetAccess(base, mapped, &acc, 1));
+    void* p = g_front ? base : (void*)((char*)base + (mapped - need));
+    g_live[p] = r;
+    ++g_allocs;
+    g_bytes += size;
+    return p;
+}
+
+extern "C" void guard_free(void* p, ssize_t, int, hipStream_t stream) {
+    if (!p) return;
+    Rec r;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_live.find(p);
+        if (it == g_live.end()) {
+            fprintf(stderr, "[guard_alloc] free of unknown pointer %p\n", p);
+            return;
+        }
+        r = it->second;
+        g_live.erase(it);
+    }
+    (void)stream;
+    GCHECK(hipDeviceSynchronize());  // nothing in flight may still touch it
+    GCHECK(hipMemUnmap(r.base, r.mapped));
+    GCHECK(hipMemRelease(r.h));
+    GCHECK(hipMemAddressFree(r.base, r.reserved));
+}
+
+extern "C" void guard_stats(long* allocs, long* bytes, long* live) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    *allocs = g_allocs;
+    *bytes = g_bytes;
+    *live = (long)g_live.size();
+}

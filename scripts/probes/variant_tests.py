@@ -64,11 +64,12 @@ def _attn_check(out, ref, what):
         f"{what}: max {err.max().item():.4g} mean {err.mean().item():.4g} (bound {mean_bound:.4g})"
 
 
-@pytest.mark.parametrize("impl", [53, 54])
+@pytest.mark.parametrize("impl", [53, 54, 55, 56])
 def test_attn_block_sparse_measurement_variants(ops, impl):
-    """The two A/B variants of the 64-row list kernel kept in the library ("attn_impl" 53: register-staged loader waves, bit-identical to
-    the shipped kernel; 54: attn_vsa.hip, all waves compute, key-split with a final merge: equal to rounding) on ragged block sizes, odd
-    list counts (an unpaired last list), an empty list and lists from 1 to 9 tiles, against the oracle and the shipped kernel."""
+    """The A/B variants of the 64-row list entry kept in the measurement build ("attn_impl" 55: the round-1..5 kernel of attn_fwd.hip — two lists
+    per 8-wave workgroup; 53: the same with register-staged loader waves, bit-identical to 55; 54: attn_vsa.hip, all waves compute, key-split
+    with a final merge: equal to 55 to rounding; 56: the shipped attn_bs16 on hardware workgroup ids, bit-identical to the shipped deal) on ragged
+    block sizes, odd list counts (an unpaired last list), an empty list and lists from 1 to 9 tiles, against the oracle."""
     B, H, nq, nk = 1, 3, 7, 9
     q, k, v = rnd((B, H, nq * 64, 128), 1), rnd((B, H, nk * 64, 128), 2), rnd((B, H, nk * 64, 128), 3)
     rng = np.random.default_rng(impl)
@@ -82,21 +83,30 @@ def test_attn_block_sparse_measurement_variants(ops, impl):
     ref = torch.nan_to_num(V.block_sparse_attn(q, k, v, bm, vbs), nan=0.0)
     idx, num = V.map_to_index(bm)
     args = (q.to(DEV), k.to(DEV), v.to(DEV), torch.from_numpy(idx).to(DEV), torch.from_numpy(num).to(DEV), torch.from_numpy(vbs).to(DEV))
-    base, base_lse = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
-    ops.set_tunable("attn_impl", impl)
+    shipped, shipped_lse = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
+    _attn_check(shipped, ref, "block sparse, shipped (attn_bs16)")
     try:
+        ops.set_tunable("attn_impl", 55)
+        base, base_lse = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
+        ops.set_tunable("attn_impl", impl)
         out, lse = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
     finally:
         ops.set_tunable("attn_impl", 0)
     _attn_check(out, ref, f"block sparse, attn_impl {impl}")
-    assert (out[0, 2, 5 * 64:6 * 64] == 0).all()
-    if impl == 53:
+    assert (out[0, 2, 5 * 64:6 * 64] == 0).all() and (shipped[0, 2, 5 * 64:6 * 64] == 0).all()
+    live_h2 = torch.ones(nq, dtype=torch.bool); live_h2[5] = False
+    if impl in (53, 55):
         assert torch.equal(out, base) and torch.equal(lse, base_lse)
+    elif impl == 56:
+        assert torch.equal(out, shipped) and torch.equal(lse, shipped_lse)
     else:
-        live = torch.ones(nq, dtype=torch.bool); live_h2 = live.clone(); live_h2[5] = False
         assert (out.float() - base.float()).abs().max().item() < 8e-3
         sel = lse[0, 2].view(nq, 64)[live_h2.to(DEV)]
         assert (sel - base_lse[0, 2].view(nq, 64)[live_h2.to(DEV)]).abs().max().item() < 1e-3
+    # the shipped kernel against the round-1 kernel: the same attention to rounding (fixed vs running softmax reference; LSE from the bf16-P row sum)
+    assert (shipped.float() - base.float()).abs().max().item() < 8e-3
+    sel = shipped_lse[0, 2].view(nq, 64)[live_h2.to(DEV)]
+    assert (sel - base_lse[0, 2].view(nq, 64)[live_h2.to(DEV)]).abs().max().item() < 2e-2
 
 
 @pytest.mark.parametrize("n,topk", [(50, 9), (624, 125), (1440, 288), (7, 7), (8192, 100), (65, 64)])

@@ -38,5 +38,49 @@ PY
   timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_ref_triton.py tests/test_gpu_boundary.py -x -q -k "sparse or vsa or block or triton" > $OUT/sparse_tests.log 2>&1; echo "sparse tests rc=$?"; tail -15 $OUT/sparse_tests.log
   timeout 300 python scripts/vsa_bs16_ab.py > $OUT/vsa_bs16_ab.log 2>&1; echo "bs16_ab rc=$?"; tail -40 $OUT/vsa_bs16_ab.log
   ;;
+3)
+  # full GPU suite with the new block-sparse kernel, then its counters, then the VSA bench line
+  timeout 1700 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -6 $OUT/pytest_gpu.log
+  timeout 300 python scripts/vsa_bs16_ab.py > $OUT/vsa_bs16_ab.log 2>&1; echo "bs16_ab rc=$?"
+  i=0
+  for SET in "GRBM_GUI_ACTIVE" \
+             "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
+             "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+             "SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL" \
+             "TA_TA_BUSY_sum TA_BUSY_avr TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum" \
+             "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    i=$((i+1))
+    PMC=1 ATTN_IMPL=0 N_LAUNCH=3 timeout 150 rocprofv3 --kernel-trace --pmc $SET --output-format csv -d "$OUT/p$i" -o pmc -- python scripts/vsa_bs16_ab.py > "$OUT/p$i.log" 2>&1 < /dev/null
+    echo "pass $i ($SET) rc=$? $(tail -1 $OUT/p$i.log | cut -c1-160)"
+  done
+  python - <<'PY'
+import csv, glob, collections, json
+ctr = collections.defaultdict(list); dur = []
+for f in glob.glob("gpurun_out/r6v3/p*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "attn_bs16_kernel" in r["Kernel_Name"]: ctr[r["Counter_Name"]].append(float(r["Counter_Value"]))
+for f in glob.glob("gpurun_out/r6v3/p1/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "attn_bs16_kernel" in r["Kernel_Name"]: dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+m = {k: sum(v[-3:]) / len(v[-3:]) for k, v in ctr.items()}   # the last three launches: the measured lists (the model's own forward launched it twice before)
+d3 = dur[-3:]
+res = dict(kernel="attn_bs16_kernel (block-sparse, one wave per 64-row list), cfg2 VSA lists of the model's second layer: 624 blocks, top-125, 12 heads",
+           ms_under_profiler=round(sum(d3) / max(len(d3), 1), 4), **m)
+if "GRBM_GUI_ACTIVE" in m and d3:
+    cyc = m["GRBM_GUI_ACTIVE"] / 8
+    res["effective_clock_ghz"] = round(cyc / (res["ms_under_profiler"] * 1e-3) / 1e9, 3)
+    for name, c, div in (("mfma_busy_fraction", "SQ_VALU_MFMA_BUSY_CYCLES", 1024), ("lds_active_fraction", "SQ_LDS_IDX_ACTIVE", 256)):
+        if c in m: res[name] = round(m[c] / div / cyc, 3)
+if "SQ_INSTS_LDS" in m and "SQ_INSTS_MFMA" in m:
+    res["lds_instructions_per_mfma"] = round(m["SQ_INSTS_LDS"] / m["SQ_INSTS_MFMA"], 3)
+    res["valu_instructions_per_mfma"] = round(m["SQ_INSTS_VALU"] / m["SQ_INSTS_MFMA"], 3)
+if "SQ_WAIT_ANY" in m and "SQ_WAVE_CYCLES" in m: res["wait_any_over_wave_cycles"] = round(m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"], 3)
+if "TCC_HIT_sum" in m: res["l2_hit_rate"] = round(m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]), 4)
+if "FETCH_SIZE" in m: res["fabric_read_GB_per_launch"] = round(2 * m["FETCH_SIZE"] * 1024 / 1e9, 3)
+json.dump(res, open("gpurun_out/r6v3/pmc_vsa_bs16.json", "w"), indent=1); print(json.dumps(res, indent=1))
+PY
+  find $OUT -name "*.csv" -size +2M -delete
+  timeout 600 python bench.py --attention vsa --steps 10 --warmup 3 --no-cpu-baseline --no-vae > $OUT/bench_vsa.log 2>&1; echo "bench vsa rc=$?"; tail -1 $OUT/bench_vsa.log | cut -c1-1500
+  ;;
 esac
 echo "visit $V done"

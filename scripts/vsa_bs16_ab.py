@@ -30,7 +30,8 @@ del model, sd
 q, k, v = (torch.randn((1, S_pad, 12, 128), generator=g, device=dev).bfloat16() for _ in range(3))
 mask_rand = ops.topk_mask(torch.randn((1, 12, n, n), generator=g, device=dev), topk)
 lists = {"model_layer1": ops.map_to_index(mask_model), "uniform_random": ops.map_to_index(mask_rand)}
-VARIANTS = {"bs16 (shipped)": (0, 0), "bs16, hardware ids": (56, 0), "round-1 kernel": (55, 0), "round-1 kernel, XCD-contiguous ids": (55, 2)}
+VARIANTS = {"bs16 (shipped)": (0, 0), "bs16, hardware ids": (56, 0), "bs16, nt pieces": (57, 0), "bs16, sc0 pieces": (58, 0), "round-1 kernel": (55, 0),
+            "round-1 kernel, XCD-contiguous ids": (55, 2)}
 
 
 def run(idx, num):

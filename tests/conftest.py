@@ -7,6 +7,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _guard  # noqa: E402
+_guard.maybe_install()   # FVK_GUARD_ALLOC=1 only: the guard-page device allocator, before the first device allocation (tests/_guard.py)
 
 
 def pytest_configure(config):

@@ -26,6 +26,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+import _guard  # noqa: E402
+_guard.maybe_install()   # (spawned workers import this module: FVK_GUARD_ALLOC=1 reaches them too)
+
 CFG4_LATENT = (1, 16, 21, 90, 160)   # 21 x 45 x 80 = 75 600 tokens
 CFG5_LATENT = (1, 16, 33, 90, 160)   # 33 x 45 x 80 = 118 800 tokens
 
@@ -41,17 +44,18 @@ def _cmp(y, ref, what, atol=1e-1, rtol=1e-2, mean_tol=1.5e-2):
 
 
 def _cmp_attn_rows(dev, ref, what):
-    """Sampled self-attention rows, device (bf16) vs exact fp32 softmax attention of the ORACLE's q / k / v over all keys.  The two sides' q / k
-    differ by the bf16 rounding of the projections upstream, so the kernel-level bound of tests/test_gpu_kernels.py (mean |err| < 3e-3 x mean
-    |ref| + 2e-5 on identical inputs) is widened to 1e-2 x mean |ref| here; the maximum is bounded relative to the largest output (a bf16 ulp is
-    2^-8 of the value) and by the reference's attention threshold 4e-2 (fastvideo-kernel/tests/test_sta.py:88-91)."""
+    """Sampled self-attention rows, device (bf16) vs exact fp32 softmax attention of the ORACLE's q / k / v over all keys: the kernel-level bound
+    of tests/test_gpu_kernels.py (mean |err| < 3e-3 x mean |ref| + 2e-5) although the two sides' q / k differ by the bf16 rounding of the
+    projections upstream (measured in round 6: 1.4e-3 x mean |ref| at both token counts); the maximum within four bf16 ulps of the largest
+    output (a bf16 ulp is 2^-8 of the value; measured 0.3 ulp) and inside the reference's attention threshold 4e-2
+    (fastvideo-kernel/tests/test_sta.py:88-91)."""
     dev, ref = dev.float().cpu(), ref.float()
     assert torch.isfinite(dev).all(), what
     err = (dev - ref).abs()
     print(f"{what}: {tuple(ref.shape)} max|err|={err.max().item():.4g} mean|err|={err.mean().item():.4g} "
           f"ref_absmean={ref.abs().mean().item():.4g} ref_absmax={ref.abs().max().item():.4g}")
-    assert err.mean().item() < 1e-2 * ref.abs().mean().item() + 2e-5, f"{what}: mean error {err.mean().item():.4g}"
-    assert err.max().item() < min(4e-2, 3e-2 * ref.abs().max().item() + 1e-3), f"{what}: max error {err.max().item():.4g}"
+    assert err.mean().item() < 3e-3 * ref.abs().mean().item() + 2e-5, f"{what}: mean error {err.mean().item():.4g}"
+    assert err.max().item() < min(4e-2, 1.6e-2 * ref.abs().max().item() + 1e-3), f"{what}: max error {err.max().item():.4g}"
 
 
 def _sample_rows(S, row_stride_elems, n_random=256, seed=0):

@@ -313,8 +313,16 @@ def test_vsa_union_lists_and_union_walk_are_exact(ops):
     q, k, v = rnd((B, H, S, D), 1).to(DEV), rnd((B, H, nk * 64, D), 2).to(DEV), rnd((B, H, nk * 64, D), 3).to(DEV)
     two = ops.attn_block_sparse(q, k, v, idx, num, vbs.to(DEV), return_lse=True, pair_union=False)
     uni = ops.attn_block_sparse(q, k, v, idx, num, vbs.to(DEV), return_lse=True, pair_union=True)
-    assert torch.equal(two[0], uni[0]) and torch.equal(two[1], uni[1])
-    assert (uni[0][0, 2, 4 * 64:5 * 64] == 0).all()    # the empty list: zeros, as the two-list kernel
+    # round 6: the plain 64-row form runs attn_bs16 (fixed softmax reference, one wave per list), the union walk still runs the round-1 kernel
+    # (online softmax) — the same attention to rounding: one bf16 ulp of the output (|o| < 0.5 here), LSE to the bf16-P row sum's 2^-9
+    # (bit-identity of the union walk with the round-1 two-list kernel: scripts/probes/variant_tests.py, measurement build)
+    assert torch.isfinite(two[0].float()).all() and torch.isfinite(uni[0].float()).all()
+    d = (two[0].float() - uni[0].float()).abs()
+    assert d.max().item() <= 2e-3 and d.mean().item() <= 1e-4, (d.max().item(), d.mean().item())
+    live = num.view(B, H, nq) > 0
+    rows = live.repeat_interleave(64, dim=2)
+    assert (two[1][rows] - uni[1][rows]).abs().max().item() <= 2e-2
+    assert (uni[0][0, 2, 4 * 64:5 * 64] == 0).all() and (two[0][0, 2, 4 * 64:5 * 64] == 0).all()    # the empty list: zeros in both
 
 
 # ------------------------------------------------------------------ attention

@@ -12,6 +12,9 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 
+import _guard  # noqa: E402
+_guard.maybe_install()   # (spawned workers import this module: FVK_GUARD_ALLOC=1 reaches them too)
+
 
 @pytest.fixture(autouse=True)
 def _let_child_contexts_go():
