@@ -74,6 +74,53 @@ class BlockPlan:
     n_recv: int
 
 
+class GraphSegments:
+    """One forward captured as HIP graphs CUT AT THE COLLECTIVES (round 6): everything a rank launches between two exchanges — ~10 kernels per
+    segment, two segments per layer — becomes one graph launch, the exchanges themselves stay eager calls on the same buffers.  Built by
+    ``WanTransformer3DModelHip.capture``; ``SequenceParallel`` cuts the running capture wherever it would call a collective (``cut``).  All
+    segments share one memory pool and are replayed in capture order, so a tensor produced in one segment is still there for the next.
+    P = 1: no cut, the whole forward is one graph.  Why: a rank of an SP = 8 run has ~34 ms of GPU work per forward against 8 ms of host issue
+    (profiles/r02_host_issue_and_hipgraph.json); with the launches in graphs the host only issues 2 graphs + 2 collectives per layer."""
+
+    def __init__(self):
+        self.items = []     # ("graph", torch.cuda.CUDAGraph) | ("call", thunk re-running one collective on its capture-time buffers)
+        self.pool = torch.cuda.graph_pool_handle()
+        self._g = None
+        self.host_s = {"graph_launch": 0.0, "collective": 0.0}   # host seconds spent in replay(), by kind (bench / scripts read it)
+
+    def begin(self):
+        self._g = torch.cuda.CUDAGraph()
+        self._g.capture_begin(pool=self.pool)
+
+    def cut(self, thunk):
+        """End the running segment, run the collective now (eagerly, on the capture stream), remember it, open the next segment."""
+        self._g.capture_end()
+        self.items.append(("graph", self._g))
+        thunk()
+        self.items.append(("call", thunk))
+        self.begin()
+
+    def end(self):
+        self._g.capture_end()
+        self.items.append(("graph", self._g))
+        self._g = None
+
+    def replay(self):
+        import time
+        for kind, it in self.items:
+            t0 = time.perf_counter()
+            if kind == "graph":
+                it.replay()
+                self.host_s["graph_launch"] += time.perf_counter() - t0
+            else:
+                it()
+                self.host_s["collective"] += time.perf_counter() - t0
+
+    @property
+    def n_graphs(self):
+        return sum(1 for k, _ in self.items if k == "graph")
+
+
 class SequenceParallel:
 
     def __init__(self, num_heads: int, group=None):
@@ -113,6 +160,8 @@ class SequenceParallel:
         # bench.py's exchange accounting: set ``stats`` to a dict to collect, per exchange kind, the bytes this rank sends to OTHER
         # ranks and HIP-event pairs around the collective on the caller's stream (None = nothing recorded, nothing extra on the stream)
         self.stats = None
+        # set by WanTransformer3DModelHip.capture while a forward is being captured: collectives cut the graph (GraphSegments)
+        self.segmenter = None
 
     def _tick(self):
         if self.stats is None or self._stage_host:
@@ -167,6 +216,19 @@ class SequenceParallel:
             return x
         xm = x.movedim(dim, 0).contiguous()
         dev = xm.device
+        if self.segmenter is not None:
+            out = xm.new_empty((P * xm.shape[0], *xm.shape[1:]))
+
+            def run():
+                if self._stage_host:
+                    xh = xm.cpu()
+                    oh = xh.new_empty(out.shape)
+                    dist.all_gather_into_tensor(oh, xh, group=self.group)
+                    out.copy_(oh)
+                else:
+                    dist.all_gather_into_tensor(out, xm, group=self.group)
+            self.segmenter.cut(run)
+            return out[:S].movedim(0, dim).contiguous()
         if self._stage_host:
             xm = xm.cpu()
         out = xm.new_empty((P * xm.shape[0], *xm.shape[1:]))
@@ -176,6 +238,21 @@ class SequenceParallel:
     # -- the exchanges ------------------------------------------------------------------------------------------
     def _a2a(self, send: torch.Tensor, in_splits, out_splits, out_rows: int) -> torch.Tensor:
         dev = send.device
+        if self.segmenter is not None:
+            # graph segments: the collective cuts the capture and is re-run at every replay on these very buffers
+            send_c = send.contiguous()
+            recv = send_c.new_empty((out_rows, *send_c.shape[1:]))
+
+            def run():
+                if self._stage_host:
+                    sh = send_c.cpu()
+                    rh = sh.new_empty(recv.shape)
+                    dist.all_to_all_single(rh, sh, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+                    recv.copy_(rh)
+                else:
+                    dist.all_to_all_single(recv, send_c, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+            self.segmenter.cut(run)
+            return recv
         if self._stage_host:
             send = send.cpu()
         recv = send.new_empty((out_rows, *send.shape[1:]))

@@ -659,3 +659,44 @@ class WanTransformer3DModelHip:
         return ops.unpatchify(y.view(B, S, -1), (B, c_out, T, Hh, W), self.patch)
 
     __call__ = forward
+
+    def capture(self, hidden_states, encoder_hidden_states, timestep, warmup: int = 2):
+        """The forward for inputs of THESE shapes as HIP graphs (round 6; ``distributed.GraphSegments``): one graph at SP = 1, graph segments
+        cut at the exchanges under sequence parallelism.  Returns ``replay(hidden_states, encoder_hidden_states, timestep) -> output``: the
+        inputs are copied into the captured buffers, the graphs replayed, and the SAME output tensor returned every time (clone it to keep
+        it).  Bit-identical to ``forward`` (the same kernels on the same data: tests/test_gpu_graph.py).  Every rank of an SP group must call
+        it (the capture runs the forward: its collectives are real).  Not served: the pipelined exchange (FVK_SP_OVERLAP), per-launch
+        HIP-event hooks (attn_events), the in-place kernel choice (attn_autotune must have finished or be off), ``trace``."""
+        from .distributed import GraphSegments
+        if self.sp.overlap:
+            raise NotImplementedError("capture: the pipelined exchange (FVK_SP_OVERLAP) issues its collectives asynchronously; capture the plain exchange")
+        if self.attn_events is not None or self._tune is not None or (self.attn_autotune and self.attention == "dense" and self.attn_tune_report is None):
+            raise RuntimeError("capture: HIP-event hooks / the in-place attention kernel choice synchronise the stream; finish them first")
+        static = [hidden_states.clone(), encoder_hidden_states.clone(), timestep.clone()]
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        seg = GraphSegments()
+        with torch.cuda.stream(side):
+            for _ in range(warmup):    # module loads, LDS attributes, metadata caches, allocator growth: none of it inside the capture
+                self.forward(*static)
+            torch.cuda.synchronize()
+            self.sp.segmenter = seg
+            try:
+                seg.begin()
+                out = self.forward(*static)
+                seg.end()
+            finally:
+                self.sp.segmenter = None
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+
+        def replay(hidden_states, encoder_hidden_states, timestep):
+            for dst, src in zip(static, (hidden_states, encoder_hidden_states, timestep)):
+                if dst.shape != src.shape:
+                    raise ValueError(f"captured for {tuple(dst.shape)}, got {tuple(src.shape)}")
+                dst.copy_(src)
+            seg.replay()
+            return out
+        replay.segments = seg
+        return replay

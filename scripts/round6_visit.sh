@@ -82,5 +82,27 @@ PY
   find $OUT -name "*.csv" -size +2M -delete
   timeout 600 python bench.py --attention vsa --steps 10 --warmup 3 --no-cpu-baseline --no-vae > $OUT/bench_vsa.log 2>&1; echo "bench vsa rc=$?"; tail -1 $OUT/bench_vsa.log | cut -c1-1500
   ;;
+4)
+  # HIP-graph capture tests, host issue eager vs graphs (SP = 1 and 8 ranks sharing the GPU), store-policy A/B of the contract step
+  timeout 900 python -m pytest tests/test_gpu_graph.py -x -q > $OUT/graph_tests.log 2>&1; echo "graph tests rc=$?"; tail -8 $OUT/graph_tests.log
+  timeout 1700 python -m pytest tests -m gpu -q --deselect tests/test_gpu_graph.py > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -6 $OUT/pytest_gpu.log
+  timeout 1200 python scripts/graph_host_issue.py 8 > $OUT/host_issue.log 2>&1; echo "host issue rc=$?"; tail -40 $OUT/host_issue.log
+  timeout 900 python scripts/step_tunable_ab.py '[["shipped (N >= 4096 streamed)", {}], ["N >= 3072 streamed (+ q|k)", {"gemm_impl": 3}], ["all streamed", {"gemm_impl": 4}], ["none streamed", {"gemm_impl": 6}], ["vt plain", {"gemm_impl": 2}]]' 4 > $OUT/store_ab.log 2>&1; echo "store_ab rc=$?"; grep forward_ms $OUT/store_ab.log | cut -c1-900
+  timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vsa_prof -o vsa -- python bench.py --attention vsa --steps 3 --warmup 1 --no-cpu-baseline --no-vae --no-power-trace --no-matrix-ceiling > $OUT/vsa_prof.log 2>&1
+  F=$(find $OUT/vsa_prof -name '*kernel_stats.csv' | head -1); [ -n "$F" ] && python scripts/condense_prof.py $F $OUT/vsa_kernel_stats.csv && head -30 $OUT/vsa_kernel_stats.csv
+  find $OUT -name "*.csv" -size +2M -delete
+  timeout 900 python bench.py --config cfg5 --attention vsa --quant fp8 --steps 3 --warmup 1 --no-cpu-baseline --no-vae --no-power-trace > $OUT/bench_cfg5_vsa_fp8.log 2>&1; echo "cfg5 vsa fp8 rc=$?"; tail -1 $OUT/bench_cfg5_vsa_fp8.log | cut -c1-700
+  ;;
+5)
+  # guard-page allocator: every test that reaches the sparse kernels / the SP paths, each tensor ending at an unmapped page
+  for T in "tests/test_gpu_kernels.py" "tests/test_gpu_ref_triton.py" "tests/test_gpu_boundary.py" "tests/test_gpu_model.py" "tests/test_gpu_sp.py" \
+           "tests/test_gpu_fullgeom.py::test_one_block_at_cfg2_vsa_matches_oracle tests/test_gpu_fullgeom.py::test_one_block_at_cfg2_sta_matches_oracle" \
+           "tests/test_gpu_fullsize.py" "tests/test_gpu_graph.py"; do
+    N=$(echo $T | tr '/:. ' '____' | cut -c1-60)
+    FVK_GUARD_ALLOC=1 timeout 1500 python -m pytest $T -x -q > $OUT/guard_$N.log 2>&1; echo "guard $T rc=$? $(tail -1 $OUT/guard_$N.log | cut -c1-150)"
+    grep -i "memory access fault\|page not present\|guard_alloc\]" $OUT/guard_$N.log | sort | uniq -c | head -5
+  done
+  FVK_GUARD_ALLOC=1 FVK_GUARD_MODE=front timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_ref_triton.py -x -q > $OUT/guard_front.log 2>&1; echo "guard front rc=$? $(tail -1 $OUT/guard_front.log | cut -c1-150)"
+  ;;
 esac
 echo "visit $V done"
