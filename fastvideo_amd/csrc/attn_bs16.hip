@@ -64,7 +64,9 @@ struct IterArgs {
     int valid_prev;                       // valid keys of block t-1 (masks P(t-1))
 };
 
-template <int AUX>
+// ABL (measurement build; results are WRONG, timing is what is measured): bit 0 = only every second LDS-DMA piece is issued (half the L2 -> LDS
+// traffic), bit 1 = no softmax VALU in the loop, bit 2 = no counted vmcnt waits in the loop
+template <int AUX, int ABL = 0>
 struct BS16 {
     bf16x8 qf[4][4];     // Q fragments [q block][k-step of 32 d]   (accumulator file)
     f32x4 o[4][9];       // O^T accumulators [q block][16-row d block]; block 8 = the row sums (A operand all ones)
@@ -279,7 +281,7 @@ struct BS16 {
         auto load_frag = [&](int L) {
             return L < 16 ? frag_v(L & 1, L >> 1, c.sVa, c.sVb) : frag_k((L - 16) >> 2, (L - 16) & 3, c.sKa, c.sKb);
         };
-        wait_vm<25>();
+        if (!(ABL & 4)) wait_vm<25>();
         __builtin_amdgcn_sched_barrier(0);
         bf16x8 fr[FD];
 #pragma unroll
@@ -304,12 +306,12 @@ struct BS16 {
             }
             __builtin_amdgcn_sched_barrier(0);  // the MFMA FIRST: everything below runs in its shadow
             if (qb == 3 && !is_ones && L + FD < 32) {
-                if (L + FD == 8) wait_vm<20>();
-                if (L + FD == 16) wait_vm<20>();
-                if (L + FD == 24) wait_vm<22>();
+                if (!(ABL & 4) && L + FD == 8) wait_vm<20>();
+                if (!(ABL & 4) && L + FD == 16) wait_vm<20>();
+                if (!(ABL & 4) && L + FD == 24) wait_vm<22>();
                 fr[L % FD] = load_frag(L + FD);
             }
-            if ((m & 3) == 1) {
+            if ((m & 3) == 1 && !((ABL & 1) && ((m >> 2) & 1))) {
                 const int k = m >> 2;
                 if (k < 7) issue_v(0, k + 1, c.sSp, c.vb_t);
                 else if (k < 15) issue_v(1, k - 7, c.sVa, c.vb_t);
@@ -317,7 +319,7 @@ struct BS16 {
                 else if (k >= 25 && k < 33) issue_k(1, k - 25, c.sKa, c.kb_t2);
                 else if (k == 33) issue_v(0, 0, c.sKb, c.vb_t1);
             }
-            if (m < 128) {
+            if (m < 128 && !(ABL & 2)) {
                 const int cc = m >> 1;  // the score this chunk pair works on
                 if ((m & 1) == 0) {
                     const int q_ = cc >> 4, G = (cc >> 3) & 1, x = cc & 7;
@@ -343,7 +345,7 @@ __device__ __forceinline__ int slot_of(int h, int k) {
     return (t >= NSLOT ? t - NSLOT : t) * SLOT;
 }
 
-template <bool PLAIN_IDS = false, int AUX = 0>
+template <bool PLAIN_IDS = false, int AUX = 0, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, const int32_t* __restrict__ q2k_idx, const int32_t* __restrict__ q2k_num,
                                                            const int32_t* __restrict__ kv_block_sizes, int max_kv) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -373,7 +375,7 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
     const bf16_t* vtp = (const bf16_t*)a.vt + ((long)b * a.H + h) * 128L * a.Skv_pad;
     bf16_t* op = (bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs;
 
-    BS16<AUX> w;
+    BS16<AUX, ABL> w;
     w.smem = smem_all + wave * WAVE_LDS;
     w.c2 = a.scale * 1.4426950408889634f;
     w.lp = 16 * (g >> 1) + 4 * (g & 1);
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
         }                                                                                                            \
     }
     FVK_BS_STORE_ROWS(false)
-    if (__any(redo[0] || redo[1] || redo[2] || redo[3])) {  // this wave only: the waves of a workgroup share nothing
+    if (ABL == 0 && __any(redo[0] || redo[1] || redo[2] || redo[3])) {  // this wave only: the waves of a workgroup share nothing
         w.exact_pass(list, kv_block_sizes, n_real, nkv, kblk, g);
         FVK_BS_STORE_ROWS(true)
     }
@@ -566,6 +568,11 @@ int fvk_attn_bs16_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const i
     FVK_BS16_VARIANT(1, true, 0)    // hardware workgroup order
     FVK_BS16_VARIANT(2, false, 2)   // LDS-DMA pieces with the nt policy (aux = 2)
     FVK_BS16_VARIANT(3, false, 1)   // ... with sc0 (aux = 1)
+    FVK_BS16_VARIANT(11, false, 0, 1)  // timing ablations (wrong results): half the LDS-DMA pieces
+    FVK_BS16_VARIANT(12, false, 0, 2)  // no softmax VALU
+    FVK_BS16_VARIANT(14, false, 0, 4)  // no counted waits
+    FVK_BS16_VARIANT(13, false, 0, 3)  // half the pieces, no softmax
+    FVK_BS16_VARIANT(17, false, 0, 7)  // MFMAs + fragment reads + half the pieces
 #undef FVK_BS16_VARIANT
 #endif
     (void)variant;

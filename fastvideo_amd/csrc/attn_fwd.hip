@@ -677,7 +677,7 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     // ids, 50 = the former one-list 4-wave workgroups, two per CU
 #if FVK_VARIANTS
     const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
-    if (impl == 0 || (impl >= 56 && impl <= 58))   // 57 / 58: the LDS-DMA pieces with the nt / sc0 cache policy
+    if (impl == 0 || (impl >= 56 && impl <= 58) || (impl >= 66 && impl <= 72))   // 57 / 58: nt / sc0 cache policy of the pieces; 66.. timing ablations
         return fvk_attn_bs16_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, impl ? impl - 55 : 0, (hipStream_t)stream);
     if (impl == 50) return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);
     // Shipped: two lists per workgroup, 2 compute + 2 loader waves each, one-stage-ahead LDS-DMA.  Two alternatives were built to attack what

@@ -47,6 +47,9 @@ __device__ __forceinline__ float row4_sum(float v) {
     return v + __shfl_xor(v, 32);
 }
 
+// LV (round 6 A/B): the row sums as fp32 VALU adds of the UNROUNDED probabilities (what the reference kernels sum:
+// block_sparse_attn_triton.py:150, st_attn_triton.py:83) instead of a ninth d block of ones on the matrix pipe (1/17 of the MFMA work)
+template <bool LV = false>
 struct W16 {
     // registers of one wave (everything is indexed with compile-time constants after unrolling)
     bf16x8 qf[4][4];     // Q fragments [q block][k-step of 32 d]
@@ -54,6 +57,7 @@ struct W16 {
     f32x4 s[2][4][4];    // S^T [sub-tile parity][q block][tile: 2 * group + (a = 0 / b = 1)]
     bf16x8 pf[2][4][2];  // P^T, packed [sub-tile parity][q block][32-key group]
     float m_run[4];
+    float l_acc[4];      // LV: this lane's share of the row sums (16 of a row's 64 scores per sub-tile)
     bf16x8 ones;         // A operand of the row-sum MFMA
     // fragment offsets INCLUDING the ring slot of the stage the pipelined loop reads next (V^T: stage j, K: stage j + 1); flipped
     // (^ 32 KiB) once per pair instead of adding a run-time slot offset in front of every read
@@ -116,7 +120,7 @@ struct W16 {
 #pragma unroll
         for (int G = 0; G < 2; ++G)
 #pragma unroll
-            for (int db = 0; db < 9; ++db) {
+            for (int db = 0; db < (LV ? 8 : 9); ++db) {
                 const bf16x8 fr = db < 8 ? frag_v(2 * hf + G, db, flip) : ones;
                 FVK_PV4(0, fr, PAR, G, db);
             }
@@ -150,8 +154,11 @@ struct W16 {
 #pragma unroll
         for (int G = 0; G < 2; ++G)
 #pragma unroll
-            for (int x = 0; x < 8; ++x)
-                pf[PAR][QB][G][x] = (bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(s[PAR][QB][2 * G + (x >> 2)][x & 3], c2, -mc));
+            for (int x = 0; x < 8; ++x) {
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[PAR][QB][2 * G + (x >> 2)][x & 3], c2, -mc));
+                if (LV) l_acc[QB] += p;
+                pf[PAR][QB][G][x] = (bf16_t)p;
+            }
     }
     template <int PAR>
     __device__ __forceinline__ void exp_pack_all() {
@@ -173,6 +180,7 @@ struct W16 {
             for (int d = 0; d < 9; ++d)  // block 8 = the running row sum: rescaled with O
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[qb][d][r] *= alpha;
+            if (LV) l_acc[qb] *= alpha;
             m_run[qb] = m_new;
         }
         exp_pack_all<PAR>();
@@ -208,6 +216,7 @@ struct W16 {
 #pragma unroll
         for (int qb = 0; qb < 4; ++qb) {
             m_run[qb] = -1e30f;
+            l_acc[qb] = 0.f;
 #pragma unroll
             for (int d = 0; d < 9; ++d)
 #pragma unroll
@@ -277,7 +286,7 @@ struct W16 {
             const int L = F < 8 ? F : F < 17 ? F - 1 : F - 2;  // LDS fragment of this slot (ones slots: none)
             if (F < 18) {
                 const int G = F >= 9, db = is_ones ? 8 : (F - 9 * G);
-                if (is_ones) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[qb][8]) : "v"(ones), "v"(pf[EVEN][qb][G]));
+                if (is_ones) { if (!LV) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[qb][8]) : "v"(ones), "v"(pf[EVEN][qb][G])); }
                 else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(o[qb][db]) : "v"(fr[L % FD]), "v"(pf[EVEN][qb][G]));
             } else {
                 const int ks = (L - 16) >> 2, T = (L - 16) & 3;
@@ -296,6 +305,7 @@ struct W16 {
                 const int c = m >> 1;  // the score this chunk pair works on
                 if ((m & 1) == 0) {
                     const int q_ = c >> 4, G = (c >> 3) & 1, x = c & 7;
+                    if (LV) l_acc[q_] += p_nx;
                     pf[CUR][q_][G][x] = (bf16_t)p_nx;
                     if (x & 1) asm volatile("" : "+v"(pf[CUR][q_][G]));  // the pair's v_cvt_pk stays in this chunk
                 } else {
@@ -315,7 +325,7 @@ struct W16 {
 // SPLIT (fvk_attn_dense_split_bf16): the key axis is cut into `n_split` runs of whole 128-key stages and every (query block, head, batch,
 // run) is its own workgroup; a run's result is written UN-merged (normalised O as fp32 rows + base-2 LSE) and attn_merge_splits_kernel
 // combines the runs (a run with no keys writes LSE = -inf and is ignored).
-template <int ABL = 0, bool PLAIN_IDS = false, bool SPLIT = false>
+template <int ABL = 0, bool PLAIN_IDS = false, bool SPLIT = false, bool LV = false>
 __global__ __launch_bounds__(256, 1) void attn_w16_kernel(fvk_attn_args a, int n_split, float* o_part, float* lse_part) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void attn_w16_kernel(fvk_attn_args a, int n
         return;
     }
 
-    W16 w;
+    W16<LV> w;
     w.smem = smem;
     w.n = n;
     w.c2 = a.scale * 1.4426950408889634f;
@@ -394,6 +404,7 @@ __global__ __launch_bounds__(256, 1) void attn_w16_kernel(fvk_attn_args a, int n
 #pragma unroll
     for (int qb = 0; qb < 4; ++qb) {
         w.m_run[qb] = -1e30f;
+        w.l_acc[qb] = 0.f;
 #pragma unroll
         for (int d = 0; d < 9; ++d)
 #pragma unroll
@@ -427,41 +438,41 @@ __global__ __launch_bounds__(256, 1) void attn_w16_kernel(fvk_attn_args a, int n
     BAR()
     const int v0 = v_last < 64 ? v_last : 64;  // valid keys of the last stage's two sub-tiles
     const int v1 = v_last > 64 ? v_last - 64 : 0;
-    w.qk_plain<0>(0, true);  // stage 0 = the slot fk does NOT point at
-    if (n == 1) w.mask_keys<0>(v0, g);
+    w.template qk_plain<0>(0, true);  // stage 0 = the slot fk does NOT point at
+    if (n == 1) w.template mask_keys<0>(v0, g);
     // the fixed reference: exact row max of the first sub-tile (it has at least one valid key)
-    w.m_run[0] = w.row_max<0, 0>();
-    w.m_run[1] = w.row_max<0, 1>();
-    w.m_run[2] = w.row_max<0, 2>();
-    w.m_run[3] = w.row_max<0, 3>();
-    w.exp_pack_all<0>();
-    w.qk_plain<1>(1, true);
+    w.m_run[0] = w.template row_max<0, 0>();
+    w.m_run[1] = w.template row_max<0, 1>();
+    w.m_run[2] = w.template row_max<0, 2>();
+    w.m_run[3] = w.template row_max<0, 3>();
+    w.template exp_pack_all<0>();
+    w.template qk_plain<1>(1, true);
     // ---- pairs j = 0 .. n-2: iterations t = 2j+1 and 2j+2 behind ONE barrier; the last pair masks sub-tile 2n-2 ------------------------------
     for (int j = 0; j + 2 < n; ++j) {  // straight-line body: a conditional inside would make the register assignment of the two paths meet with copies
         if (!(ABL & 2)) {
             WAIT_ALL()  // this wave's pieces of set j-1 (issued a whole pair ago) have landed
             BAR()       // every wave is past iteration 2j: the slots of K(j) and V^T(j-1) are free, set j-1 is visible
         }
-        w.iter<0, false, ABL>(j, 64, g);
-        w.iter<1, false, ABL>(j, 64, g);
+        w.template iter<0, false, ABL>(j, 64, g);
+        w.template iter<1, false, ABL>(j, 64, g);
         w.flip_slots();
     }
     if (n >= 2) {
         WAIT_ALL()
         BAR()
-        w.iter<0, false, ABL & 8>(n - 2, 64, g);
-        w.iter<1, true, ABL & 8>(n - 2, v0, g);
+        w.template iter<0, false, ABL & 8>(n - 2, 64, g);
+        w.template iter<1, true, ABL & 8>(n - 2, v0, g);
         w.flip_slots();
     }
     // ---- tail: P·V(2n-2), softmax of sub-tile 2n-1 (second half of the last stage, masked), P·V(2n-1) --------------------------------------
     WAIT_ALL()  // V^T(n-1) (and the harmless re-reads of stage 0) landed
     BAR()
-    w.pv_plain<0>(0, false);  // fv points at the slot of stage n-1
+    w.template pv_plain<0>(0, false);  // fv points at the slot of stage n-1
     if (v1 > 0) {  // workgroup-uniform
-        w.fence_s<1>();
-        w.mask_keys<1>(v1, g);
-        w.exp_pack_all<1>();
-        w.pv_plain<1>(1, false);
+        w.template fence_s<1>();
+        w.template mask_keys<1>(v1, g);
+        w.template exp_pack_all<1>();
+        w.template pv_plain<1>(1, false);
     }
     w.fence_o();  // the last MFMAs' results before the epilogue's v_accvgpr_read
     WAIT_ALL()  // the harmless re-reads of stage 0 have landed (the exact pass below re-uses the ring; afterwards the LDS can be re-assigned)
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(256, 1) void attn_w16_kernel(fvk_attn_args a, int n
     bool redo[4] = {false, false, false, false};
 #define FVK_STORE_ROWS(ONLY_REDO)                                                                                    \
     _Pragma("unroll") for (int qb = 0; qb < 4; ++qb) {                                                               \
-        const float l_tot = w.o[qb][8][0]; /* every row of block 8 holds the whole row sum */                        \
+        const float l_tot = LV ? row4_sum(w.l_acc[qb]) : w.o[qb][8][0]; /* every row of block 8 holds the whole row sum */ \
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;                                                          \
         if (!(ONLY_REDO)) redo[qb] = !(l_tot < L_LIMIT);                                                             \
         if (q_ok[qb] && (!(ONLY_REDO) || redo[qb])) {                                                                \
@@ -507,12 +518,12 @@ __global__ __launch_bounds__(256, 1) void attn_w16_kernel(fvk_attn_args a, int n
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
-template <int ABL = 0, bool PLAIN_IDS = false>
+template <int ABL = 0, bool PLAIN_IDS = false, bool LV = false>
 int launch_w16(const fvk_attn_args* a, hipStream_t s) {
     static FvkLdsConfigured configured;
-    if (int rc = fvk_config_lds(configured, (const void*)attn_w16_kernel<ABL, PLAIN_IDS>, LDS_BYTES, "fvk_attn_dense_bf16 (w16)")) return rc;
+    if (int rc = fvk_config_lds(configured, (const void*)attn_w16_kernel<ABL, PLAIN_IDS, false, LV>, LDS_BYTES, "fvk_attn_dense_bf16 (w16)")) return rc;
     const long nblk = (long)((a->Sq + 255) / 256) * a->H * a->B;
-    hipLaunchKernelGGL((attn_w16_kernel<ABL, PLAIN_IDS>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, 1, (float*)nullptr, (float*)nullptr);
+    hipLaunchKernelGGL((attn_w16_kernel<ABL, PLAIN_IDS, false, LV>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, 1, (float*)nullptr, (float*)nullptr);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }
@@ -559,6 +570,7 @@ int fvk_attn_w16_launch(const fvk_attn_args* a, int variant, hipStream_t s) {
         case 17: return launch_w16<7>(a, s);
         case 18: return launch_w16<8>(a, s);
         case 19: return launch_w16<16>(a, s);  // no exact recompute (timing probe: are rows being redone?)
+        case 20: return launch_w16<0, false, true>(a, s);  // row sums as fp32 VALU adds instead of the ninth d block (round 6 A/B)
         default: break;
     }
 #endif
