@@ -3,13 +3,16 @@
 // granule of UNMAPPED address space behind them, and the tensor is placed so that it ENDS where the mapping ends (FVK_GUARD_MODE=front: so that it
 // STARTS where the mapping starts, with the previous reservation's unmapped granule in front of it).  A read or write past the end (or in front of
 // the start) of ANY tensor — by 16 bytes or by gigabytes — is then a GPU page fault ("Memory access fault by GPU ... address 0x...") instead of a
-// silent read of a mapped neighbour, which is what the caching allocator turns every small overrun into.  Freed tensors are unmapped at once
-// (after a stream synchronisation), so a use after free faults as well.
+// silent read of a mapped neighbour, which is what the caching allocator turns every small overrun into.  A freed tensor's ADDRESS RANGE is never
+// handed out again (the first version unmapped and re-reserved at once: the second test of every file then read stale data through re-used
+// virtual addresses, profiles/r06d_guard_page_runs.md); its physical memory goes to a quarantine that is unmapped oldest-first beyond
+// FVK_GUARD_QUARANTINE_GB (default 48), so a late use after free faults as well.
 //   hipcc -O2 -shared -fPIC scripts/probes/guard_alloc.cpp -o scripts/probes/libguard_alloc.so
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
 #include <mutex>
 #include <unordered_map>
 
@@ -20,6 +23,8 @@ struct Rec {
     hipMemGenericAllocationHandle_t h;
 };
 std::unordered_map<void*, Rec> g_live;
+std::deque<Rec> g_quarantine;
+size_t g_quarantine_bytes = 0, g_quarantine_cap = 48UL << 30;
 std::mutex g_mu;
 size_t g_gran = 0, g_align = 16;
 bool g_front = false;
@@ -46,6 +51,7 @@ extern "C" void* guard_malloc(ssize_t size, int device, hipStream_t) {
         GCHECK(hipMemGetAllocationGranularity(&g_gran, &prop, hipMemAllocationGranularityMinimum));
         if (const char* a = getenv("FVK_GUARD_ALIGN")) g_align = (size_t)atol(a);
         if (const char* m = getenv("FVK_GUARD_MODE")) g_front = m[0] == 'f';
+        if (const char* q = getenv("FVK_GUARD_QUARANTINE_GB")) g_quarantine_cap = (size_t)atol(q) << 30;
         fprintf(stderr, "[guard_alloc] granule %zu B, tensor alignment %zu B, tensors placed at the %s of their mapping\n", g_gran, g_align,
                 g_front ? "START" : "END");
     }
@@ -70,22 +76,27 @@ extern "C" void* guard_malloc(ssize_t size, int device, hipStream_t) {
 
 extern "C" void guard_free(void* p, ssize_t, int, hipStream_t stream) {
     if (!p) return;
-    Rec r;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        auto it = g_live.find(p);
-        if (it == g_live.end()) {
-            fprintf(stderr, "[guard_alloc] free of unknown pointer %p\n", p);
-            return;
-        }
-        r = it->second;
-        g_live.erase(it);
-    }
     (void)stream;
-    GCHECK(hipDeviceSynchronize());  // nothing in flight may still touch it
-    GCHECK(hipMemUnmap(r.base, r.mapped));
-    GCHECK(hipMemRelease(r.h));
-    GCHECK(hipMemAddressFree(r.base, r.reserved));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_live.find(p);
+    if (it == g_live.end()) {
+        fprintf(stderr, "[guard_alloc] free of unknown pointer %p\n", p);
+        return;
+    }
+    g_quarantine.push_back(it->second);
+    g_quarantine_bytes += it->second.mapped;
+    g_live.erase(it);
+    if (g_quarantine_bytes > g_quarantine_cap) {
+        GCHECK(hipDeviceSynchronize());  // nothing in flight may still touch what is unmapped now
+        while (g_quarantine_bytes > g_quarantine_cap / 2 && !g_quarantine.empty()) {
+            const Rec r = g_quarantine.front();
+            g_quarantine.pop_front();
+            g_quarantine_bytes -= r.mapped;
+            GCHECK(hipMemUnmap(r.base, r.mapped));
+            GCHECK(hipMemRelease(r.h));
+            // (the reservation itself is kept for the life of the process: its addresses are never re-used)
+        }
+    }
 }
 
 extern "C" void guard_stats(long* allocs, long* bytes, long* live) {

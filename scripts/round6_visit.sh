@@ -95,14 +95,24 @@ PY
   ;;
 5)
   # guard-page allocator: every test that reaches the sparse kernels / the SP paths, each tensor ending at an unmapped page
+  timeout 300 python scripts/guard_selftest.py > $OUT/guard_selftest.log 2>&1; echo "guard selftest rc=$? $(tail -1 $OUT/guard_selftest.log)"
+  timeout 120 python scripts/guard_selftest.py oob > $OUT/guard_selftest_oob.log 2>&1; echo "guard oob rc=$? (non-zero + a fault message = the detector works) $(grep -i 'fault\|NO FAULT' $OUT/guard_selftest_oob.log | head -2)"
   for T in "tests/test_gpu_kernels.py" "tests/test_gpu_ref_triton.py" "tests/test_gpu_boundary.py" "tests/test_gpu_model.py" "tests/test_gpu_sp.py" \
            "tests/test_gpu_fullgeom.py::test_one_block_at_cfg2_vsa_matches_oracle tests/test_gpu_fullgeom.py::test_one_block_at_cfg2_sta_matches_oracle" \
-           "tests/test_gpu_fullsize.py" "tests/test_gpu_graph.py"; do
+           "tests/test_gpu_fullsize.py"; do
     N=$(echo $T | tr '/:. ' '____' | cut -c1-60)
     FVK_GUARD_ALLOC=1 timeout 1500 python -m pytest $T -x -q > $OUT/guard_$N.log 2>&1; echo "guard $T rc=$? $(tail -1 $OUT/guard_$N.log | cut -c1-150)"
     grep -i "memory access fault\|page not present\|guard_alloc\]" $OUT/guard_$N.log | sort | uniq -c | head -5
   done
   FVK_GUARD_ALLOC=1 FVK_GUARD_MODE=front timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_ref_triton.py -x -q > $OUT/guard_front.log 2>&1; echo "guard front rc=$? $(tail -1 $OUT/guard_front.log | cut -c1-150)"
+  ;;
+7)
+  timeout 400 python scripts/attn_lsum_ab.py > $OUT/attn_lsum_ab.log 2>&1; echo "lsum_ab rc=$?"; tail -30 $OUT/attn_lsum_ab.log
+  timeout 900 python scripts/step_tunable_ab.py '[["attn_w16, row sums on the matrix pipe", {"attn_impl": 300}], ["attn_w16, row sums as VALU adds", {"attn_impl": 320}]]' 5 > $OUT/lsum_step_ab.log 2>&1; echo "lsum step rc=$?"; grep forward_ms $OUT/lsum_step_ab.log | cut -c1-700
+  ;;
+6)
+  timeout 600 python scripts/vsa_bs16_ablate.py > $OUT/bs16_ablate.log 2>&1; echo "ablate rc=$?"; tail -30 $OUT/bs16_ablate.log
+  timeout 1500 python -m pytest tests/test_gpu_bigseq.py -q --durations=0 > $OUT/bigseq_durations.log 2>&1; echo "bigseq rc=$?"; grep -E "passed|failed|s call|s setup" $OUT/bigseq_durations.log | head -20
   ;;
 esac
 echo "visit $V done"
