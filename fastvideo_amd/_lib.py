@@ -126,5 +126,15 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
 
 
+_TRACE = os.environ.get("FVK_TRACE_CALLS") == "1"   # fault hunts (scripts/round6_visit.sh, guard-page runs): name every call, run it to completion
+
+
 def call(name: str, *args) -> None:
+    if _TRACE:
+        import sys
+        import torch
+        print(f"[fvk] {name}", file=sys.stderr, flush=True)
+        check(getattr(load(), name)(*args), name)
+        torch.cuda.synchronize()
+        return
     check(getattr(load(), name)(*args), name)

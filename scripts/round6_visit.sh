@@ -114,5 +114,10 @@ PY
   timeout 600 python scripts/vsa_bs16_ablate.py > $OUT/bs16_ablate.log 2>&1; echo "ablate rc=$?"; tail -30 $OUT/bs16_ablate.log
   timeout 1500 python -m pytest tests/test_gpu_bigseq.py -q --durations=0 > $OUT/bigseq_durations.log 2>&1; echo "bigseq rc=$?"; grep -E "passed|failed|s call|s setup" $OUT/bigseq_durations.log | head -20
   ;;
+8)
+  # which kernel faults under the guard-page allocator: every C-ABI call named and synchronised
+  FVK_GUARD_ALLOC=1 FVK_TRACE_CALLS=1 timeout 600 python -m pytest "tests/test_gpu_model.py::test_wan_tiny_sta_matches_oracle" -x -q -s > $OUT/trace_sta.log 2>&1; echo "trace sta rc=$?"; grep "\[fvk\]\|fault" $OUT/trace_sta.log | tail -6
+  FVK_GUARD_ALLOC=1 FVK_TRACE_CALLS=1 timeout 900 python -m pytest "tests/test_gpu_sp.py::test_sp_pipelined_exchange_equals_sp1" -x -q -s > $OUT/trace_sp.log 2>&1; echo "trace sp rc=$?"; grep "\[fvk\]\|fault" $OUT/trace_sp.log | tail -12
+  ;;
 esac
 echo "visit $V done"
