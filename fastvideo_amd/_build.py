@@ -86,6 +86,21 @@ def build_probe(force: bool = False, verbose: bool = True) -> str:
     return build(force, verbose, probe=True)
 
 
+GUARD_LIB = os.path.join(PROBE_DIR, "libguard_alloc.so")
+
+
+def build_guard(force: bool = False) -> str:
+    """scripts/probes/libguard_alloc.so: the guard-page device allocator of the out-of-bounds hunts (tests/_guard.py, tests/test_gpu_guard.py).
+    Host code only; test infrastructure, never loaded by the product."""
+    src = os.path.join(PROBE_DIR, "guard_alloc.cpp")
+    if not force and os.path.exists(GUARD_LIB) and os.path.getmtime(GUARD_LIB) >= os.path.getmtime(src):
+        return GUARD_LIB
+    r = subprocess.run([hipcc(), "-O2", "-shared", "-fPIC", src, "-o", GUARD_LIB], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on guard_alloc.cpp:\n{r.stdout}")
+    return GUARD_LIB
+
+
 def build_bug(verbose: bool = True) -> str:
     """scripts/probes/libfvk_bug.so (see BUG_LIB); always rebuilt, never built by __graft_entry__.build()."""
     return _build_locked(verbose, probe=True, bug=True)

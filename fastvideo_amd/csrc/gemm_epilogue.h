@@ -67,7 +67,8 @@ __device__ __forceinline__ void gemm_tile_epilogue(const GemmArgs& a, Acc& acc, 
             m = m < a.M ? m : a.M - 1;
             resv[it] = ld_bf16x8(a.residual + (long)m * a.ldc + nc);
         }
-        const int mf = m0 + wm * 128, ml = (mf + 127 < a.M ? mf + 127 : a.M - 1);
+        // (clamped: a wave tile that starts at or past row M stores nothing, but must not read a gate row past the end of the gate tensor)
+        const int mf = (m0 + wm * 128 < a.M ? m0 + wm * 128 : a.M - 1), ml = (m0 + wm * 128 + 127 < a.M ? m0 + wm * 128 + 127 : a.M - 1);
         gate_uniform = a.gate && (mf / a.rows_per_batch == ml / a.rows_per_batch);
         if (gate_uniform) {
             const float* gp = a.gate + (long)(mf / a.rows_per_batch) * a.N + nc;

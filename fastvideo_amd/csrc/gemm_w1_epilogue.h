@@ -33,7 +33,9 @@ __device__ __forceinline__ void w1_direct_epilogue(const fvk::GemmArgs& a, f32x4
     // gate rows (one per rows_per_batch output rows; rows_per_batch >= 128 here — gemm_w1_launch sends finer gates to the LDS-bounce variant):
     // the wave's 128 rows see at most TWO of them, loaded once per column group; row m takes the second one from `bnd` on
     const int mf = m0 + wm * 128;
-    const int gb0 = RG ? mf / a.rows_per_batch : 0;
+    // (a wave tile that starts at or past row M stores nothing, but its gate loads below must stay inside the [M / rows_per_batch, N] gate
+    // tensor: round 6's guard-page runs caught the last layer's FFN-out reading one gate row past the end — profiles/r06d_guard_page_runs.md)
+    const int gb0 = RG ? (mf < a.M ? mf : a.M - 1) / a.rows_per_batch : 0;
     const int bnd = (gb0 + 1) * a.rows_per_batch;
     const bool two_gates = RG && a.gate && bnd < mf + 128 && bnd < a.M;
     // One 32-column group at a time, its eight m blocks inside: the per-column state (bias, fp8 weight scales, gate) and the group's eight

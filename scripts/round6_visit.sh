@@ -119,5 +119,17 @@ PY
   FVK_GUARD_ALLOC=1 FVK_TRACE_CALLS=1 timeout 600 python -m pytest "tests/test_gpu_model.py::test_wan_tiny_sta_matches_oracle" -x -q -s > $OUT/trace_sta.log 2>&1; echo "trace sta rc=$?"; grep "\[fvk\]\|fault" $OUT/trace_sta.log | tail -6
   FVK_GUARD_ALLOC=1 FVK_TRACE_CALLS=1 timeout 900 python -m pytest "tests/test_gpu_sp.py::test_sp_pipelined_exchange_equals_sp1" -x -q -s > $OUT/trace_sp.log 2>&1; echo "trace sp rc=$?"; grep "\[fvk\]\|fault" $OUT/trace_sp.log | tail -12
   ;;
+9)
+  # after the gate-row fix: the guard regression tests, then EVERY gpu test file under the guard-page allocator (one process per file)
+  timeout 1500 python -m pytest tests/test_gpu_guard.py -x -q > $OUT/test_gpu_guard.log 2>&1; echo "test_gpu_guard rc=$? $(tail -1 $OUT/test_gpu_guard.log)"
+  for T in tests/test_gpu_model.py tests/test_gpu_sp.py tests/test_gpu_fullgeom.py tests/test_gpu_fp8.py tests/test_gpu_sched.py tests/test_gpu_causal.py \
+           tests/test_gpu_loader.py tests/test_gpu_reference_model.py tests/test_gpu_vae.py tests/test_gpu_vae_tiled.py tests/test_gpu_vae_real.py \
+           tests/test_gpu_boundary.py tests/test_gpu_ref_triton.py tests/test_gpu_fullsize.py tests/test_gpu_rccl_single_rank.py; do
+    [ -f $T ] || continue
+    N=$(basename $T .py)
+    FVK_GUARD_ALLOC=1 timeout 1500 python -m pytest $T -q > $OUT/guard_$N.log 2>&1; echo "guard $T rc=$? $(tail -1 $OUT/guard_$N.log | cut -c1-150)"
+    grep -i "memory access fault" $OUT/guard_$N.log | sort | uniq -c | head -3
+  done
+  ;;
 esac
 echo "visit $V done"
