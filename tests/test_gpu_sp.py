@@ -16,17 +16,9 @@ import _guard  # noqa: E402
 _guard.maybe_install()   # (spawned workers import this module: FVK_GUARD_ALLOC=1 reaches them too)
 
 
-@pytest.fixture(autouse=True)
-def _let_child_contexts_go():
-    """Every test here ends with child processes that used the GPU having just exited; the next test's parent-side forward starts at once.  Round 5
-    saw ONE unexplained abort of such a forward in three full-suite runs (a GPU fault in the parent right after the previous test's children were
-    reaped; never reproduced in isolation — DESIGN §6).  Half a second for the driver to finish tearing the children's device contexts down costs
-    7 s per suite and removes the one timing coincidence the failing run had."""
-    yield
-    import time
-    if torch.cuda.is_available():
-        torch.cuda.synchronize()
-    time.sleep(0.5)
+# (Round 5 had an `autouse` half-second pause here after one unexplained GPU fault in a parent-process forward.  Round 6 found the cause with the
+# guard-page allocator — an out-of-bounds read of one gate row by the last layer's gated-residual GEMM, profiles/r06d_guard_page_runs.md — and fixed
+# it; the pause is gone.  This file runs clean under FVK_GUARD_ALLOC=1.)
 
 
 def _free_port():

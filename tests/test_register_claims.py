@@ -14,7 +14,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "fastvideo_amd", "libfvk_amd.so")
 LLVM = "/opt/rocm/lib/llvm/bin"
-CLAIMING = ("gemm_w1_kernel", "gemm_w1n_kernel", "vae_conv3w_kernel", "attn_w16_kernel", "attn_w64_kernel")
+CLAIMING = ("gemm_w1_kernel", "gemm_w1n_kernel", "vae_conv3w_kernel", "attn_w16_kernel", "attn_w64_kernel", "attn_bs16_kernel", "mfma_sustained_probe_kernel")
 
 
 def _device_elfs(blob: bytes):
