@@ -131,5 +131,13 @@ PY
     grep -i "memory access fault" $OUT/guard_$N.log | sort | uniq -c | head -3
   done
   ;;
+10)
+  timeout 900 python scripts/sp_rank_emulation.py > $OUT/sp_rank_emulation.json 2> $OUT/sp_rank_emulation.err; echo "sp emulation rc=$?"; python -c "
+import json
+d=json.load(open('$OUT/sp_rank_emulation.json'))
+for k,v in d.items(): print(k, v['layer_us'], v.get('layer_us_in_sequence_eager'), v.get('layer_us_in_sequence_hip_graph'), v.get('compute_only_speedup'), v.get('compute_only_speedup_in_sequence_eager'), v.get('compute_only_speedup_in_sequence_hip_graph'))
+"
+  timeout 1700 python -m pytest tests -m gpu -q --durations=25 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -40 $OUT/pytest_gpu.log
+  ;;
 esac
 echo "visit $V done"

@@ -57,11 +57,45 @@ for P in (1, 2, 4, 8):
     r["gemm ffn-in + gelu"] = t(lambda: ops.gemm(x, W["f1"], b["f1"], epilogue=ops.EPI_GELU_TANH))
     r["gemm ffn-out + gated residual"] = t(lambda: ops.gemm(ff, W["f2"], b["f2"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=mod))
     tot = sum(r.values())
+    # round 6: the same ops IN THE ORDER A LAYER RUNS THEM (every op once per layer, 30 layers back to back), issued eagerly and replayed as ONE
+    # HIP graph — what a rank's compute costs when launch gaps are the eager host's and when they are the graph's
+    def layer():
+        ops.ln_modulate(x, mul=mod, add=mod)
+        ops.gemm(x, W["qkv"], b["qkv"])
+        ops.rmsnorm_rope([qkv[:, :d], qkv[:, d:2 * d]], [nw, nw], cos, sin, head_dim=D, seq_len=S)
+        ops.v_transpose(vall)
+        ops.attn_dense(qb, kall[:, :S], vt=vt, layout="bshd")
+        ops.gemm(x, W["o"], b["o"])
+        ops.ln_modulate(x, mul=mod, add=mod)
+        ops.gemm(x, W["o"], b["o"])
+        ops.attn_dense(cq, ck, cv, layout="bshd")
+        ops.gemm(x, W["o"], b["o"])
+        ops.ln_modulate(x, mul=mod, add=mod)
+        ops.gemm(x, W["f1"], b["f1"], epilogue=ops.EPI_GELU_TANH)
+        ops.gemm(ff, W["f2"], b["f2"], epilogue=ops.EPI_RESIDUAL_GATE, residual=x, gate=mod)
+    def thirty():
+        for _ in range(30):
+            layer()
+    seq_eager = t(thirty, n=3) / 30
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        thirty()
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            thirty()
+    torch.cuda.current_stream().wait_stream(side)
+    seq_graph = t(gr.replay, n=3) / 30
+    del gr
     nqb = ((G * Sl + 255) // 256) * hg
     out[f"P{P}"] = dict(layout=f"G{G}xU{U}", Sl=Sl, attn_workgroups=nqb, attn_key_splits=ops.attn_key_splits(nqb, (S + 127) // 128),
                         self_attention_unsplit_us=round(unsplit, 1), layer_us=round(tot, 1), forward_ms_30_layers=round(tot * 30 / 1e3, 2),
+                        layer_us_in_sequence_eager=round(seq_eager, 1), layer_us_in_sequence_hip_graph=round(seq_graph, 1),
                         per_op_us={k_: round(v_, 1) for k_, v_ in r.items()})
 base = out["P1"]["layer_us"]
 for P in (2, 4, 8):
     out[f"P{P}"]["compute_only_speedup"] = round(base / out[f"P{P}"]["layer_us"], 2)
+    out[f"P{P}"]["compute_only_speedup_in_sequence_eager"] = round(out["P1"]["layer_us_in_sequence_eager"] / out[f"P{P}"]["layer_us_in_sequence_eager"], 2)
+    out[f"P{P}"]["compute_only_speedup_in_sequence_hip_graph"] = round(out["P1"]["layer_us_in_sequence_hip_graph"] / out[f"P{P}"]["layer_us_in_sequence_hip_graph"], 2)
 print(json.dumps(out))
