@@ -83,14 +83,26 @@ struct BS16 {
     int lp;                         // lane part of a score's key index: 16 (g >> 1) + 4 (g & 1)
 
     // piece p (0..7) of K group G (keys 32 G + 4 p .. + 4) of the block whose rows start kb bytes into the head's K slice -> slot
+    // (the instruction's immediate offset moves the LDS destination AND the source address: pieces p & 3 of a half group share one M0 value — one
+    // M0 write per four pieces instead of one per piece — and the scalar offset takes the 1024 * (p & 3) bytes back.  The immediate must be a
+    // constant for the front end: a four-way switch that folds once the loops are unrolled)
+#define FVK_BS_PIECE(RSRC, VOFF, SOFF)                                                                                              \
+    {                                                                                                                               \
+        lds_void* d_ = (lds_void*)(smem + slot + (p & 4) * 1024);                                                                   \
+        const unsigned so_ = __builtin_amdgcn_readfirstlane((SOFF) - (unsigned)(p & 3) * 1024u);                                    \
+        switch (p & 3) {                                                                                                            \
+            case 0: __builtin_amdgcn_raw_ptr_buffer_load_lds(RSRC, d_, 16, VOFF, so_, 0, AUX); break;                               \
+            case 1: __builtin_amdgcn_raw_ptr_buffer_load_lds(RSRC, d_, 16, VOFF, so_, 1024, AUX); break;                            \
+            case 2: __builtin_amdgcn_raw_ptr_buffer_load_lds(RSRC, d_, 16, VOFF, so_, 2048, AUX); break;                            \
+            default: __builtin_amdgcn_raw_ptr_buffer_load_lds(RSRC, d_, 16, VOFF, so_, 3072, AUX); break;                           \
+        }                                                                                                                           \
+    }
     __device__ __forceinline__ void issue_k(int G, int p, int slot, unsigned kb) const {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lds_void*)(smem + slot + p * 1024), 16, kv[(p & 1) + 2 * (p >> 2)],
-                                                 __builtin_amdgcn_readfirstlane(kb + (unsigned)(8 * G + p) * k_pstride), 0, AUX);
+        FVK_BS_PIECE(k_rsrc, kv[(p & 1) + 2 * (p >> 2)], kb + (unsigned)(8 * G + p) * k_pstride)
     }
     // piece p (0..7) of V^T half hf (d rows 64 hf + 8 p .. + 8) of the block whose columns start vb bytes into a V^T row -> slot
     __device__ __forceinline__ void issue_v(int hf, int p, int slot, unsigned vb) const {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lds_void*)(smem + slot + p * 1024), 16, vv[p & 1],
-                                                 __builtin_amdgcn_readfirstlane(vb + (unsigned)(8 * hf + p) * v_pstride), 0, AUX);
+        FVK_BS_PIECE(v_rsrc, vv[p & 1], vb + (unsigned)(8 * hf + p) * v_pstride)
     }
     // V^T fragment: 32-key group G, d block db (0..7) — half db >> 2;  K fragment: score tile T = 2 * group + a/b, k-step ks
     __device__ __forceinline__ bf16x8 frag_v(int G, int db, int sVa, int sVb) const {

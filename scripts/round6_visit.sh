@@ -139,5 +139,13 @@ for k,v in d.items(): print(k, v['layer_us'], v.get('layer_us_in_sequence_eager'
 "
   timeout 1700 python -m pytest tests -m gpu -q --durations=25 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -40 $OUT/pytest_gpu.log
   ;;
+11)
+  timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_ref_triton.py -x -q -k "sparse or vsa or block or triton" > $OUT/sparse_tests.log 2>&1; echo "sparse tests rc=$?"; tail -5 $OUT/sparse_tests.log
+  timeout 300 python scripts/vsa_bs16_ab.py > $OUT/vsa_bs16_ab.log 2>&1; echo "bs16_ab rc=$?"; python -c "
+import json
+s=open('$OUT/vsa_bs16_ab.log').read(); j=json.loads(s[s.index('{'):])
+for k,v in j.items(): print(k, {a:min(b) for a,b in v['ms'].items()}, v['bs16_vs_round1_max_abs'], v['max_abs_err_vs_exact_fp32_on_sampled_blocks'])
+"
+  ;;
 esac
 echo "visit $V done"

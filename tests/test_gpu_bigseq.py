@@ -27,6 +27,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import _guard  # noqa: E402
+import _mp  # noqa: E402
 _guard.maybe_install()   # (spawned workers import this module: FVK_GUARD_ALLOC=1 reaches them too)
 
 CFG4_LATENT = (1, 16, 21, 90, 160)   # 21 x 45 x 80 = 75 600 tokens
@@ -165,7 +166,7 @@ def _sp_worker(rank, world, port, out_q):
         model = WanTransformer3DModelHip(sd, cfg.num_heads, cfg.head_dim, cfg.patch_size, cfg.eps, cfg.freq_dim, device="cuda:0")
         y = model(latent.cuda(), ctx.cuda(), t.cuda()).cpu()
         if rank == 0:
-            out_q.put((y, (model.sp.lay.G, model.sp.lay.U), model.sp.overlap))
+            out_q.put(_mp.ship((y, (model.sp.lay.G, model.sp.lay.U), model.sp.overlap)))
             out_q.close(); out_q.join_thread()
         dist.barrier()
     finally:
@@ -192,7 +193,7 @@ def test_cfg4_block_on_eight_ranks_sharing_the_gpu_equals_sp1():
     procs = [mpc.Process(target=_sp_worker, args=(r, world, port, out_q)) for r in range(world)]
     for p in procs:
         p.start()
-    y, (G, U), overlap = out_q.get(timeout=900)
+    y, (G, U), overlap = _mp.unship(out_q.get(timeout=900))
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0

@@ -12,6 +12,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 import _guard  # noqa: E402
+import _mp  # noqa: E402
 _guard.maybe_install()
 
 
@@ -61,7 +62,7 @@ def _worker(rank, world, port, attention, shape, out_q):
         replay = model.capture(*a)
         ra, rb = replay(*a).clone(), replay(*b).clone()
         if rank == 0:
-            out_q.put((ya.cpu(), yb.cpu(), ra.cpu(), rb.cpu(), replay.segments.n_graphs, sum(1 for k, _ in replay.segments.items if k == "call")))
+            out_q.put(_mp.ship((ya.cpu(), yb.cpu(), ra.cpu(), rb.cpu(), replay.segments.n_graphs, sum(1 for k, _ in replay.segments.items if k == "call"))))
             out_q.close(); out_q.join_thread()
         dist.barrier()
     finally:
@@ -83,7 +84,7 @@ def test_graph_segments_under_sequence_parallelism(world, attention):
     procs = [ctx.Process(target=_worker, args=(r, world, port, attention, shape, out_q)) for r in range(world)]
     for p in procs:
         p.start()
-    ya, yb, ra, rb, n_graphs, n_calls = out_q.get(timeout=300)
+    ya, yb, ra, rb, n_graphs, n_calls = _mp.unship(out_q.get(timeout=300))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

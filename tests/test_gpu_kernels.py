@@ -487,6 +487,40 @@ def test_attn_block_sparse(ops):
     assert (lse.cpu() - lse_ref).abs().max().item() < 2e-2
 
 
+def test_attn_block_sparse_cold_paths(ops):
+    """The paths of attn_bs16 that random data never takes (round 6): a listed block of size 0 — as the FIRST block of a list (it would have set
+    the softmax reference: the rows go through the exact pass), in the middle and at the end —, one-block and odd-length lists, an empty list, and
+    rows whose later keys score so far above the first block's that the fixed-reference row sum overflows (2^90 and beyond: the per-row exact
+    recompute).  Against the oracle's masked fp32 attention."""
+    B, H, nq, nk = 1, 3, 6, 9
+    q, k, v = rnd((B, H, nq * 64, 128), 11), rnd((B, H, nk * 64, 128), 12), rnd((B, H, nk * 64, 128), 13)
+    vbs = np.array([0, 64, 17, 0, 64, 33, 64, 0, 5], dtype=np.int32)
+    bm = np.zeros((B, H, nq, nk), dtype=bool)
+    bm[0, 0, 0, [0, 1, 2]] = True            # size-0 block first
+    bm[0, 0, 1, [1, 3, 4]] = True            # size-0 block in the middle
+    bm[0, 0, 2, [2, 5, 7]] = True            # size-0 block last, odd length
+    bm[0, 0, 3, [4]] = True                  # one block
+    bm[0, 0, 4, :] = True                    # all nine (odd), three of them empty
+    # head 0, query block 5: empty list
+    bm[0, 1] = np.random.default_rng(3).random((nq, nk)) < 0.6
+    bm[0, 1, :, 1] = True
+    bm[0, 2] = bm[0, 1]
+    # head 2: overflow of the fixed reference — the first listed block (1) scores low, block 6 scores 16 384 raw units higher
+    q[0, 2] = 8.0
+    k[0, 2, 1 * 64:2 * 64] = -8.0
+    k[0, 2, 6 * 64:7 * 64] = 8.0
+    bm[0, 2, :, 6] = True
+    ref = torch.nan_to_num(V.block_sparse_attn(q, k, v, bm, vbs), nan=0.0)
+    idx, num = V.map_to_index(bm)
+    out, lse = ops.attn_block_sparse(q.to(DEV), k.to(DEV), v.to(DEV), torch.from_numpy(idx).to(DEV), torch.from_numpy(num).to(DEV),
+                                     torch.from_numpy(vbs).to(DEV), layout="bhsd", return_lse=True)
+    _attn_check(out, ref, "block sparse, cold paths")
+    assert (out[0, 0, 5 * 64:6 * 64] == 0).all()
+    # the overflow rows attend block 6 alone to fp32 precision: the mean of its V rows
+    want = v[0, 2, 6 * 64:7 * 64].float().mean(0)
+    assert (out[0, 2].float().cpu() - want).abs().max().item() < 2e-2
+
+
 @pytest.mark.parametrize("rows", [256, 384, 512])
 def test_attn_tile_lists_shared_kv_lists(ops, rows):
     """fvk_attn_tile_lists_bf16: every `rows` consecutive query rows share one list of 64-key blocks (sliding-tile windows).  Against the

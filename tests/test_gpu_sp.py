@@ -13,6 +13,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 import _guard  # noqa: E402
+import _mp  # noqa: E402
 _guard.maybe_install()   # (spawned workers import this module: FVK_GUARD_ALLOC=1 reaches them too)
 
 
@@ -38,7 +39,7 @@ def _worker(rank, world, port, fx_path, out_q):
         for case in fx["cases"]:
             outs.append(model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda()).cpu())
         if rank == 0:
-            out_q.put((outs, (model.sp.lay.G, model.sp.lay.U)))
+            out_q.put(_mp.ship((outs, (model.sp.lay.G, model.sp.lay.U))))
             out_q.close(); out_q.join_thread()  # flush before teardown: a crash in runtime shutdown must not truncate the message
         dist.barrier()
     finally:
@@ -60,7 +61,7 @@ def test_sp_forward_equals_sp1(world, golden_dir):
     procs = [ctx.Process(target=_worker, args=(r, world, port, fx_path, out_q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs, (G, U) = out_q.get(timeout=300)
+    outs, (G, U) = _mp.unship(out_q.get(timeout=300))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -95,7 +96,7 @@ def _worker_pipelined(rank, world, port, out_q, heads=6, lat_shape=(1, 16, 5, 18
     try:
         out = _pipelined_model_forward(True, heads, lat_shape)
         if rank == 0:
-            out_q.put(out)
+            out_q.put(_mp.ship(out))
             out_q.close(); out_q.join_thread()
         dist.barrier()
     finally:
@@ -122,7 +123,7 @@ def test_sp_pipelined_exchange_equals_sp1(world, heads, lat_shape, mode):
     procs = [ctx.Process(target=_worker_pipelined, args=(r, world, port, out_q, heads, lat_shape, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    out, overlap_kept, checked = out_q.get(timeout=300)
+    out, overlap_kept, checked = _mp.unship(out_q.get(timeout=300))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -138,7 +139,7 @@ def _worker_sparse(rank, world, port, fx_path, mode, out_q, quant=None):
     try:
         out = _sparse_forward(fx_path, mode, quant)
         if rank == 0:
-            out_q.put(out)
+            out_q.put(_mp.ship(out))
             out_q.close(); out_q.join_thread()
         dist.barrier()
     finally:
@@ -182,7 +183,7 @@ def test_sp_sparse_attention_equals_sp1(mode, world, golden_dir):
     procs = [ctx.Process(target=_worker_sparse, args=(r, world, port, fx_path, mode, out_q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = out_q.get(timeout=300)
+    out = _mp.unship(out_q.get(timeout=300))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -207,7 +208,7 @@ def test_sp_sparse_fp8_ragged_pad_rows_are_finite(mode, golden_dir):
     procs = [ctx.Process(target=_worker_sparse, args=(r, 2, port, fx_path, mode, out_q, "fp8")) for r in range(2)]
     for p in procs:
         p.start()
-    out = out_q.get(timeout=300)
+    out = _mp.unship(out_q.get(timeout=300))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -7,6 +7,8 @@ import socket
 
 import pytest
 import torch
+
+import _mp  # tensors across the queue by value (tests/_mp.py)
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -175,7 +177,7 @@ def _worker(rank, world, port, out_q):
         dec.enable_tiling(**g["tiles"], use_parallel_tiling=True)
         y = dec.decode(z.cuda()).cpu()
         if rank == world - 1:  # every rank holds the full video; report the last one's
-            out_q.put(y)
+            out_q.put(_mp.ship(y))
             out_q.close(); out_q.join_thread()
         dist.barrier()
     finally:
@@ -197,7 +199,7 @@ def test_tile_parallel_decode_across_ranks_equals_single_rank(ops, world):
     procs = [ctx.Process(target=_worker, args=(r, world, port, out_q)) for r in range(world)]
     for p in procs:
         p.start()
-    y = out_q.get(timeout=300)
+    y = _mp.unship(out_q.get(timeout=300))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -7,6 +7,8 @@ import socket
 
 import pytest
 import torch
+
+import _mp  # tensors across the queue by value (tests/_mp.py)
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -51,7 +53,7 @@ def _worker(rank, world, port, H, S, D, q, k, v, out_q, overlap=False):
         # one decision from per-rank measurements (the model's in-place attention kernel choice): every rank sees the same sums
         assert sp.sum_over_ranks([1.0 + rank, 10.0]) == [world * (world + 1) / 2, 10.0 * world]
         if rank == 0:
-            out_q.put((full, back.equal(x), (sp.lay.G, sp.lay.U)))
+            out_q.put(_mp.ship((full, back.equal(x), (sp.lay.G, sp.lay.U))))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -78,7 +80,7 @@ def test_sp_attention_equals_single_process(world, H, S, overlap):
     procs = [ctx.Process(target=_worker, args=(r, world, port, H, S, D, q, k, v, out_q, overlap)) for r in range(world)]
     for p in procs:
         p.start()
-    full, roundtrip_ok, (G, U) = out_q.get(timeout=120)
+    full, roundtrip_ok, (G, U) = _mp.unship(out_q.get(timeout=120))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -104,7 +106,7 @@ def test_sp_attention_world8(H, S):
     procs = [ctx.Process(target=_worker, args=(r, world, port, H, S, D, q, k, v, out_q, None if H == 12 else False)) for r in range(world)]
     for p in procs:
         p.start()
-    full, roundtrip_ok, (G, U) = out_q.get(timeout=240)
+    full, roundtrip_ok, (G, U) = _mp.unship(out_q.get(timeout=240))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -131,7 +133,7 @@ def _worker_packed_pipelined(rank, world, port, H, S, D, q, k, v, out_q):
         assert sp.pipelined_agrees(o, ref) and sp.overlap and sp._overlap_checked
         full = sp.all_gather_unpad(o.unsqueeze(0), S, dim=1)[0]
         if rank == 0:
-            out_q.put((full, (L.G, L.U)))
+            out_q.put(_mp.ship((full, (L.G, L.U))))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -152,7 +154,7 @@ def test_packed_pipelined_exchange_equals_single_process(world, H):
     procs = [ctx.Process(target=_worker_packed_pipelined, args=(r, world, port, H, S, D, q, k, v, out_q)) for r in range(world)]
     for p in procs:
         p.start()
-    out, (G, U) = out_q.get(timeout=240)
+    out, (G, U) = _mp.unship(out_q.get(timeout=240))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -234,7 +236,7 @@ def _vsa_worker(rank, world, port, H, raw, D, q, k, v, gate, topk, out_q):
         ol = sp.attention_blocks(sp.pack_rows(ql, kl, vl, gl), plan, _vsa_block_fn(meta, topk, S), head_dim=D)
         full = sp.all_gather_unpad(ol[None], S, dim=1)[0]
         if rank == 0:
-            out_q.put((full, (sp.lay.G, sp.lay.U), (plan.r0, plan.r1)))
+            out_q.put(_mp.ship((full, (sp.lay.G, sp.lay.U), (plan.r0, plan.r1))))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -264,7 +266,7 @@ def test_sp_video_sparse_attention_any_grid(world, H, raw):
     procs = [ctx.Process(target=_vsa_worker, args=(r, world, port, H, raw, D, q, k, v, gate, topk, out_q)) for r in range(world)]
     for p in procs:
         p.start()
-    full, (G, U), (r0, r1) = out_q.get(timeout=240)
+    full, (G, U), (r0, r1) = _mp.unship(out_q.get(timeout=240))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
