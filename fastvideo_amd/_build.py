@@ -16,7 +16,7 @@ SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.
 PROBE_DIR = os.path.join(HERE, "..", "scripts", "probes")
 PROBE_SOURCES = ["attn_pp.hip", "attn_vsa.hip"]
 PROBE_LIB = os.path.join(PROBE_DIR, "libfvk_probe.so")
-# round 5, scripts/coresidency_matrix.py only: the measurement build WITHOUT the two fences of round 4's co-residency bug (the register-file
+# round 5, scripts/coresidency/coresidency_matrix.py only: the measurement build WITHOUT the two fences of round 4's co-residency bug (the register-file
 # claim of the one-wave-per-SIMD kernels, the packed-fp32 ban in the small kernels' files) — the pre-fix state, rebuilt on purpose to study it
 BUG_LIB = os.path.join(PROBE_DIR, "libfvk_bug.so")
 # The files of the SMALL kernels (norm / RoPE / pack, gathers, quantisers, scheduler step, post-processing: few registers, so their waves can

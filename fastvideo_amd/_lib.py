@@ -15,8 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _PROBE_SEL = os.environ.get("FVK_PROBE_LIB", "")
 PROBE = _PROBE_SEL == "1" or _PROBE_SEL.startswith("bug")
 # "bug", "bug2", "bug_s<N>" (scripts/coresidency_*.py only): measurement builds WITHOUT round 4's two fences against the co-residency bug
-# (_build.BUG_LIB) — plain, with gemm_w1's MFMAs as compiler builtins (scripts/build_bug2.sh), with parts of gemm_w1's loop removed
-# (scripts/build_bug_strips.sh)
+# (_build.BUG_LIB) — plain, with gemm_w1's MFMAs as compiler builtins (scripts/coresidency/build_bug2.sh), with parts of gemm_w1's loop removed
+# (scripts/coresidency/build_bug_strips.sh)
 LIB_PATH = (os.path.join(os.path.dirname(HERE), "scripts", "probes", f"libfvk_{_PROBE_SEL}.so" if _PROBE_SEL.startswith("bug") else "libfvk_probe.so")
             if PROBE else os.path.join(HERE, "libfvk_amd.so"))
 ABI_VERSION = 7
@@ -126,7 +126,7 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
 
 
-_TRACE = os.environ.get("FVK_TRACE_CALLS") == "1"   # fault hunts (scripts/round6_visit.sh, guard-page runs): name every call, run it to completion
+_TRACE = os.environ.get("FVK_TRACE_CALLS") == "1"   # fault hunts (scripts/guard_sweep.sh): name every call, run it to completion
 
 
 def call(name: str, *args) -> None:

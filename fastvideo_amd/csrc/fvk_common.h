@@ -69,7 +69,7 @@ inline int fvk_config_lds(FvkLdsConfigured& c, const void* func, int bytes, cons
 }
 
 // A kernel that streams v_mfma_*_16x16x32 (or the 16x16x128 fp8 form) with ONE wave per SIMD must own that SIMD's whole register file.
-// Found in round 4 (scripts/pk_f32_mfma_probe.py, profiles/r04z_pk_f32_beside_mfma.log): while a gemm_w1 wave (408 of 512 registers) runs,
+// Found in round 4 (scripts/coresidency/pk_f32_mfma_probe.py, profiles/r04z_pk_f32_beside_mfma.log): while a gemm_w1 wave (408 of 512 registers) runs,
 // a wave of ANOTHER kernel that fits into the 104 left over and shares the SIMD gets wrong LOW halves out of its packed-fp32 VALU instructions
 // (v_pk_mul_f32 / v_pk_add_f32 with op_sel / neg modifiers: the RoPE arithmetic of rmsnorm_rope_kernel, 192 of 200 launches wrong beside a
 // gemm_w1 on another stream; never beside the vendor GEMM, never with the packed instructions compiled out, never once gemm_w1 claims all 512

@@ -48,7 +48,7 @@ static_assert(LDS_BYTES >= 2 * BUF, "epilogue staging must cover both buffers");
 
 using fvk::GemmArgs;
 
-// W1_STRIP (co-residency study only, scripts/build_bug_strips.sh; results are WRONG, the kernel only serves as an AGGRESSOR): bit 0 no
+// W1_STRIP (co-residency study only, scripts/coresidency/build_bug_strips.sh; results are WRONG, the kernel only serves as an AGGRESSOR): bit 0 no
 // LDS-DMA staging in the loop, bit 1 no fragment reads in the loop, bit 2 no workgroup barriers in the loop, bit 3 no MFMAs
 #ifndef W1_STRIP
 #define W1_STRIP 0

@@ -6,12 +6,12 @@ AGGRESSOR (an MFMA kernel of this library in one of its variants, or the vendor 
 on FIXED inputs; every victim output is compared with the one computed alone.  A cell = `wrong` of `iters` victim launches differ.
 Which aggressor property is needed?  gemm_w1's variants differ in ONE thing each:  gemm_impl 125 (VAR 15, shipped: 16x16x32, direct epilogue,
 persistent) | 61 (VAR 7: the same MFMAs, LDS-bounce epilogue, one workgroup per tile) | 29 (VAR 3: 32x32x16 MFMAs) | fp8 (16x16x128 f8f6f4).
-usage: FVK_PROBE_LIB=bug python scripts/coresidency_matrix.py [iters=120]"""
+usage: FVK_PROBE_LIB=bug python scripts/coresidency/coresidency_matrix.py [iters=120]"""
 import os as _os
-if _os.environ.get("FVK_PROBE_LIB") not in ("bug", "bug2"):   # bug2: gemm_w1's MFMAs as compiler builtins (scripts/build_bug2.sh)
+if _os.environ.get("FVK_PROBE_LIB") not in ("bug", "bug2"):   # bug2: gemm_w1's MFMAs as compiler builtins (scripts/coresidency/build_bug2.sh)
     _os.environ["FVK_PROBE_LIB"] = "bug"
 import json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fastvideo_amd import _lib, ops
 assert _lib.LIB_PATH.endswith(("libfvk_bug.so", "libfvk_bug2.so")), _lib.LIB_PATH

@@ -1,11 +1,11 @@
 """Round 5, co-residency bug, step 4: WHICH PART of gemm_w1 is the aggressor?  The synthetic victim of step 3 (packed RoPE forms on
 register values: no loads, 18 registers) and the real QK-norm / RoPE kernel run beside gemm_w1 from a bug library whose gemm_w1 main loop has parts
-removed (FVK_PROBE_LIB=bug_s<N>, scripts/build_bug_strips.sh: 1 no LDS-DMA, 2 no fragment reads, 4 no barriers, 8 no MFMAs; sums combine), and beside
-its no-epilogue timing variant (gemm_impl 253 = VAR 31).  usage: FVK_PROBE_LIB=bug_s8 python scripts/coresidency_strips.py [launches = 40]"""
+removed (FVK_PROBE_LIB=bug_s<N>, scripts/coresidency/build_bug_strips.sh: 1 no LDS-DMA, 2 no fragment reads, 4 no barriers, 8 no MFMAs; sums combine), and beside
+its no-epilogue timing variant (gemm_impl 253 = VAR 31).  usage: FVK_PROBE_LIB=bug_s8 python scripts/coresidency/coresidency_strips.py [launches = 40]"""
 import os as _os
 assert _os.environ.get("FVK_PROBE_LIB", "").startswith("bug"), "set FVK_PROBE_LIB=bug | bug_s<N>"
 import ctypes as C, json, os, sys
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # scripts/ (this file lives in scripts/coresidency/)
 sys.path.insert(0, os.path.dirname(HERE))
 import torch
 from fastvideo_amd import _lib, ops

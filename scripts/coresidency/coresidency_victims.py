@@ -1,17 +1,17 @@
 """Round 5, co-residency bug, step 3: SYNTHETIC victims beside the REAL aggressors.
 
-scripts/coresidency_matrix.py showed: only the kernels that do the RoPE rotation fail, only beside the bf16 gemm_w1 family (inline-asm MFMAs on AGPR
+scripts/coresidency/coresidency_matrix.py showed: only the kernels that do the RoPE rotation fail, only beside the bf16 gemm_w1 family (inline-asm MFMAs on AGPR
 accumulators; both MFMA shapes, both epilogues, 256 x 256 and 256 x 128 tiles) — not beside the fp8 form of the same kernel (builtin MFMAs), gemm_ph,
 the attention / conv kernels or the vendor GEMM, although the victim's 56 registers fit beside all of them.  The first synthetic victim (packed
 forms on register-resident values) stayed clean beside a synthetic MFMA stream.  Here the victims of scripts/probes/pk_victims.hip — the real
 kernel's instruction sequence rebuilt one feature at a time (values from registers | loaded from global memory | packed ops IN PLACE on the
 just-loaded pairs | the same with s_nop 7 after each s_waitcnt | scalar arithmetic | loads only) — run on stream B beside the real aggressors on
 stream A.  Loaded values are re-derivable from their addresses, so wrong DATA is told apart from wrong ARITHMETIC.
-usage: python scripts/coresidency_victims.py [launches per cell = 60]"""
+usage: python scripts/coresidency/coresidency_victims.py [launches per cell = 60]"""
 import os as _os
 _os.environ["FVK_PROBE_LIB"] = "bug"
 import ctypes as C, json, os, sys
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # scripts/ (this file lives in scripts/coresidency/)
 sys.path.insert(0, os.path.dirname(HERE))
 import torch
 from fastvideo_amd import _lib, ops

@@ -1,9 +1,9 @@
 """Do packed-fp32 VALU results go wrong when MFMA kernels run on the same CUs — in ONE process?  Stream A loops a large bf16 GEMM (torch /
 vendor kernel, or this library's), stream B loops the QK-norm + RoPE + pack pass (whose RoPE arithmetic hipcc compiles to v_pk_mul_f32 /
 v_pk_add_f32 with op_sel / neg modifiers) on FIXED inputs; every pack output is compared with the first.
-usage: python scripts/pk_f32_mfma_probe.py [iters=600]"""
+usage: python scripts/coresidency/pk_f32_mfma_probe.py [iters=600]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from fastvideo_amd import ops
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 600

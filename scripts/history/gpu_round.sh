@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box visit: parity tests, kernel A/B microbench, contract bench, rocprof kernel stats.  Everything lands in gpurun_out/<tag>/.
-# usage: scripts/gpu_round.sh <tag> [skip-list e.g. "pmc"]
+# usage: scripts/history/gpu_round.sh <tag> [skip-list e.g. "pmc"]
 set -u
 TAG=${1:-r1}
 SKIP=${2:-}

@@ -1,4 +1,4 @@
-"""profiles/<round>_bench_lines.md from one sweep directory (scripts/round2_sweep.sh): a table + the unedited JSON of every line.
+"""profiles/<round>_bench_lines.md from one sweep directory (scripts/history/round2_sweep.sh): a table + the unedited JSON of every line.
 usage: python scripts/make_bench_lines.py gpurun_out/r2sweep3 profiles/r02_bench_lines_final.md "title text" """
 import json
 import os
@@ -23,7 +23,7 @@ def last_json(path):
     return None
 
 
-out = [f"# {title}", "", f"Source: `{src}` (one box visit, `scripts/round2_sweep.sh`).  Boxes differ by a few %.", ""]
+out = [f"# {title}", "", f"Source: `{src}` (one box visit, `scripts/history/round2_sweep.sh`).  Boxes differ by a few %.", ""]
 py = os.path.join(src, "pytest_all.log")
 if os.path.exists(py):
     tail = [l for l in open(py).read().splitlines() if " passed" in l or " failed" in l]

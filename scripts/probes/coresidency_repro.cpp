@@ -2,7 +2,7 @@
 //   aggressor wave (one per SIMD, leaves register-file room): a bf16 MFMA stream WHILE its own LDS-DMA pieces (buffer_load ... lds, 16 B per lane)
 //                   are in flight — gemm_w1's cadence: one 1-KiB piece per 8 MFMAs, counted waits that leave 16 pieces flying, a barrier per 32 MFMAs
 //   victim wave   : packed-fp32 VALU on register values next to its scalar twin; disagreements are counted in-kernel
-// What scripts/coresidency_strips.py established with the real gemm_w1 (MFMAs + in-flight DMA necessary and sufficient, fp8 MFMAs harmless,
+// What scripts/coresidency/coresidency_strips.py established with the real gemm_w1 (MFMAs + in-flight DMA necessary and sufficient, fp8 MFMAs harmless,
 // barriers an amplifier) is re-run here with synthetic aggressors, one ingredient at a time, and with victims of one packed / 64-bit opcode each.
 //   hipcc --offload-arch=gfx950 -O3 coresidency_repro.cpp -o coresidency_repro ;  ./coresidency_repro [victim launches per cell = 30]
 #include <hip/hip_runtime.h>

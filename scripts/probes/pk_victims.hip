@@ -1,5 +1,5 @@
 // Round 5, co-residency bug: synthetic VICTIM kernels that can be launched on a torch stream beside the REAL aggressor (gemm_w1 of
-// scripts/probes/libfvk_bug.so) — scripts/coresidency_victims.py.  The first synthetic pair (coresidency_probe.cpp: packed forms on register
+// scripts/probes/libfvk_bug.so) — scripts/coresidency/coresidency_victims.py.  The first synthetic pair (coresidency_probe.cpp: packed forms on register
 // values) stayed clean beside a synthetic MFMA stream; the real victim's disassembly shows what it did not cover: the packed multiplies run IN
 // PLACE on register pairs that a global_load_dwordx4 has JUST written (s_waitcnt vmcnt(N) directly in front), with op_sel:[0,1]
 // op_sel_hi:[1,0] on the second source, followed by v_pk_add_f32 pairs with neg_lo / neg_hi.  Variants (one thing changes at a time):

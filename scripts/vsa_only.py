@@ -1,5 +1,5 @@
 """The shipped block-sparse (VSA) kernel alone at the contract geometry (cfg2: 624 blocks of 64, top-125, 12 heads) on the block selection a
-random-init model makes in its second layer — for PMC passes (scripts/vsa_pmc_r5.sh).  N_LAUNCH launches (default 3)."""
+random-init model makes in its second layer — for PMC passes (round 5; round 6: scripts/vsa_bs16_ab.py + scripts/vsa_pmc.sh).  N_LAUNCH launches (default 3)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
