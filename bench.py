@@ -651,7 +651,7 @@ def main():
             out["cfg_step"] = measure_cfg_step(model, cfg, latent, ctx)
         except Exception as ex:  # noqa: BLE001 - never hide the contract number
             out["cfg_step"] = {"error": repr(ex)[:300]}
-    if rank == 0 and not args.no_matrix_ceiling:
+    if world == 1 and not args.no_matrix_ceiling:   # (N > 1: the other ranks would leave the process group while rank 0 still measures)
         try:
             mc = measure_matrix_ceiling(local_rank)
             roof["sustained_matrix_rate_at_cap_tf"] = mc["normal_like_operands"]["tflops"]
