@@ -19,7 +19,7 @@ PROBE = _PROBE_SEL == "1" or _PROBE_SEL.startswith("bug")
 # (scripts/coresidency/build_bug_strips.sh)
 LIB_PATH = (os.path.join(os.path.dirname(HERE), "scripts", "probes", f"libfvk_{_PROBE_SEL}.so" if _PROBE_SEL.startswith("bug") else "libfvk_probe.so")
             if PROBE else os.path.join(HERE, "libfvk_amd.so"))
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -57,6 +57,8 @@ SIGNATURES = {
     "fvk_attn_dense_kernel_bf16": [C.POINTER(AttnArgs), i32, vp],
     "fvk_attn_dense_split_bf16": [C.POINTER(AttnArgs), i32, vp, vp, vp],
     "fvk_attn_block_sparse_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp],
+    "fvk_attn_block_sparse_ws_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp, i64, vp],
+    "fvk_attn_block_sparse_workspace_bytes": [C.POINTER(AttnArgs), i32, i32],
     "fvk_vsa_union_lists": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "fvk_attn_block_sparse_union_bf16": [C.POINTER(AttnArgs), vp, vp, i32, vp],
     "fvk_attn_tile_lists_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp, vp, vp],
@@ -84,7 +86,7 @@ SIGNATURES = {
     "fvk_vae_blend_f32": [vp, vp, i64, i64, i64, i32, i32, i32, i64, i64, i64, i64, i64, i64, vp],
     "fvk_vae_postprocess_u8": [vp, vp, i32, i32, i32, i64, vp],
 }
-_RESTYPES = {"fvk_last_error": C.c_char_p}
+_RESTYPES = {"fvk_last_error": C.c_char_p, "fvk_attn_block_sparse_workspace_bytes": C.c_long}
 
 _lib = None
 

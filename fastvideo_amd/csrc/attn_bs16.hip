@@ -357,9 +357,19 @@ __device__ __forceinline__ int slot_of(int h, int k) {
     return (t >= NSLOT ? t - NSLOT : t) * SLOT;
 }
 
-template <bool PLAIN_IDS = false, int AUX = 0, int ABL = 0>
+// SPLIT (the launch's last, partial round of workgroups): logical workgroup wg_base + x / parts walks PART x % parts of each of its four lists
+// (an even number of blocks per part, the last part the rest) and writes the part's result UN-merged — normalised O as fp32 rows + base-2 LSE,
+// the split-KV form of attn_w16 — for bs16_merge_parts_kernel below.  Row r of part p lives at (p * tail_rows + r), r = 256 * (workgroup -
+// wg_base) + 64 * wave + row.
+struct Bs16Split {
+    int wg_base, parts, tail_rows;
+    float* o_part;    // [parts][tail_rows][128]
+    float* lse_part;  // [parts][tail_rows]
+};
+
+template <bool PLAIN_IDS = false, int AUX = 0, int ABL = 0, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, const int32_t* __restrict__ q2k_idx, const int32_t* __restrict__ q2k_num,
-                                                           const int32_t* __restrict__ kv_block_sizes, int max_kv) {
+                                                           const int32_t* __restrict__ kv_block_sizes, int max_kv, Bs16Split sp) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     FVK_CLAIM_WHOLE_REGISTER_FILE();
@@ -371,7 +381,9 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
     const int nwg = (nqb + 3) >> 2;     // workgroups per head: four consecutive query blocks each
     // XCD-aware deal: hardware workgroup id x lands on XCD x % 8 (its own L2); XCD c gets the CONTIGUOUS logical ids [c*q + min(c, r), ...)
     const int nblk = gridDim.x, xq = nblk >> 3, xr = nblk & 7, xcd = blockIdx.x & 7;
-    const int bid = PLAIN_IDS ? (int)blockIdx.x : xcd * xq + (xcd < xr ? xcd : xr) + (int)(blockIdx.x >> 3);
+    const int lid = PLAIN_IDS ? (int)blockIdx.x : xcd * xq + (xcd < xr ? xcd : xr) + (int)(blockIdx.x >> 3);
+    const int bid = SPLIT ? sp.wg_base + lid / sp.parts : lid;
+    const int part = SPLIT ? lid % sp.parts : 0;
     const int qb_id = (bid % nwg) * 4 + wave;
     if (qb_id >= nqb) return;  // wave-uniform; no barrier anywhere in this kernel
     const int h = (bid / nwg) % a.H;
@@ -381,6 +393,12 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
     const int nkv = a.Skv >> 6;
     int n_real = __builtin_amdgcn_readfirstlane(q2k_num[meta]);
     n_real = n_real < 0 ? 0 : (n_real < max_kv ? n_real : max_kv);
+    if (SPLIT) {  // this wave's part of the list: blocks [part * per, part * per + per) with per even (iterations come in pairs)
+        const int per = ((n_real + sp.parts - 1) / sp.parts + 1) & ~1;
+        const int rest = n_real - part * per;
+        list += part * per;
+        n_real = rest < 0 ? 0 : (rest < per ? rest : per);
+    }
 
     const bf16_t* qp = (const bf16_t*)a.q + (long)b * a.q_bs + (long)h * a.q_hs;
     const bf16_t* kp = (const bf16_t*)a.k + (long)b * a.k_bs + (long)h * a.k_hs;
@@ -536,19 +554,31 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
     // ---- epilogue: normalise and store; a row whose fixed-reference sum left the safe range (NaN, infinite or >= 2^90) is redone by the exact
     // pass and stored again — per ROW.  Lane (l15, g) holds d = 16*db + 4*g + {0..3} of its query row.
     bool redo[4] = {false, false, false, false};
+    const long prow0 = SPLIT ? (long)part * sp.tail_rows + ((long)(bid - sp.wg_base) * 4 + wave) * 64 : 0;  // this wave's first row of its part
 #define FVK_BS_STORE_ROWS(ONLY_REDO)                                                                                 \
     _Pragma("unroll") for (int qb = 0; qb < 4; ++qb) {                                                               \
         const float l_tot = w.o[qb][8][0]; /* every row of block 8 holds the whole row sum */                        \
         const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;                                                          \
         if (!(ONLY_REDO)) redo[qb] = n_real > 0 && !(l_tot < L_LIMIT);                                               \
         if (!(ONLY_REDO) || redo[qb]) {                                                                              \
-            bf16_t* orow = op + (long)qrow[qb] * a.o_ss;                                                             \
-            _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                          \
-                bf16x4 v4;                                                                                           \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(w.o[qb][d][e] * inv);                 \
-                *reinterpret_cast<bf16x4*>(orow + d * 16 + g * 4) = v4;                                              \
+            if (SPLIT) {                                                                                             \
+                float* prow = sp.o_part + (prow0 + 16 * qb + l15) * 128;                                             \
+                _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                      \
+                    f32x4 v4;                                                                                        \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) v4[e] = w.o[qb][d][e] * inv;                       \
+                    *reinterpret_cast<f32x4*>(prow + d * 16 + g * 4) = v4;                                           \
+                }                                                                                                    \
+                /* an empty part (or one whose keys are all masked): weight 0 in the merge */                        \
+                if (g == 0) sp.lse_part[prow0 + 16 * qb + l15] = l_tot > 0.f ? w.m_run[qb] * w.c2 + log2f(l_tot) : -INFINITY; \
+            } else {                                                                                                 \
+                bf16_t* orow = op + (long)qrow[qb] * a.o_ss;                                                         \
+                _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                      \
+                    bf16x4 v4;                                                                                       \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(w.o[qb][d][e] * inv);             \
+                    *reinterpret_cast<bf16x4*>(orow + d * 16 + g * 4) = v4;                                          \
+                }                                                                                                    \
+                if (a.lse && g == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow[qb]] = w.m_run[qb] * w.c2 + log2f(l_tot); \
             }                                                                                                        \
-            if (a.lse && g == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow[qb]] = w.m_run[qb] * w.c2 + log2f(l_tot);   \
         }                                                                                                            \
     }
     FVK_BS_STORE_ROWS(false)
@@ -560,26 +590,86 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// out[b, row, h, :] = sum_p 2^(lse_p - max) o_part[p] / sum_p 2^(lse_p - max) over the parts of a SPLIT launch: one wave per row, two columns per
+// lane (attn_w16's merge of its split-KV form); HBM-bound, parts * 516 B read and 256 B written per row.
+__global__ __launch_bounds__(256) void bs16_merge_parts_kernel(fvk_attn_args a, Bs16Split sp) {
+    const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= sp.tail_rows) return;
+    const int lane = threadIdx.x & 63;
+    const int nqb = a.Sq >> 6, nwg = (nqb + 3) >> 2;
+    const int bid = sp.wg_base + (int)(r >> 8);
+    const int qb_id = (bid % nwg) * 4 + (int)((r >> 6) & 3);
+    if (qb_id >= nqb) return;  // (a head's last workgroup may hold fewer than four lists)
+    const int h = (bid / nwg) % a.H, b = bid / (nwg * a.H);
+    const int qrow = qb_id * 64 + (int)(r & 63);
+    float mx = -INFINITY;
+    for (int p = 0; p < sp.parts; ++p) mx = fmaxf(mx, sp.lse_part[(long)p * sp.tail_rows + r]);
+    float acc0 = 0.f, acc1 = 0.f, wsum = 0.f;
+    for (int p = 0; p < sp.parts; ++p) {
+        const float wgt = exp2f(sp.lse_part[(long)p * sp.tail_rows + r] - mx);  // an empty part: 2^(-inf) = 0 (all empty: NaN, skipped)
+        if (wgt > 0.f) {
+            const float2 v = *reinterpret_cast<const float2*>(sp.o_part + ((long)p * sp.tail_rows + r) * 128 + lane * 2);
+            acc0 += wgt * v.x;
+            acc1 += wgt * v.y;
+            wsum += wgt;
+        }
+    }
+    const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+    bf16x2 o2;
+    o2[0] = (bf16_t)(acc0 * inv);
+    o2[1] = (bf16_t)(acc1 * inv);
+    *reinterpret_cast<bf16x2*>((bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs + (long)qrow * a.o_ss + lane * 2) = o2;
+    if (a.lse && lane == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow] = mx + log2f(wsum);
+}
+
+// The launch plan of the 64-row list kernel: `full` workgroups (whole rounds of one workgroup per CU) run whole lists; the `tail` workgroups of
+// the last, partial round are cut into `parts` list parts each so that they fill the chip too (cfg2: 1 872 workgroups = 7.31 rounds of 256 -> 7
+// rounds + 80 workgroups x 3 parts, i.e. 7.4 rounds instead of 8).  parts = 1: no split.
+struct Bs16Plan { long full, tail; int parts; long ws_bytes; };
+Bs16Plan bs16_plan(const fvk_attn_args* a, int max_kv) {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    const long nblk = (((long)(a->Sq / 64) + 3) / 4) * a->H * a->B;
+    Bs16Plan p{nblk, 0, 1, 0};
+    const long tail = nblk % cus;
+    int parts = tail > 0 ? (int)(cus / tail) : 1;
+    if (parts > 4) parts = 4;
+    if (parts > max_kv / 16) parts = max_kv / 16;  // a part shorter than ~16 blocks is mostly prologue
+    if (parts >= 2) {
+        p.full = nblk - tail; p.tail = tail; p.parts = parts;
+        p.ws_bytes = (long)parts * tail * 256 * (128 + 1) * 4;
+    }
+    return p;
+}
+
 }  // namespace
 
-// called by fvk_attn_block_sparse_bf16 (attn_fwd.hip) after its argument checks; variant 1 (measurement build) = hardware workgroup order
+// called by fvk_attn_block_sparse_ws_bf16 (attn_fwd.hip) after its argument checks; variant 1 (measurement build) = hardware workgroup order.
+// ws / ws_bytes: optional device workspace for the split last round (fvk_attn_bs16_workspace_bytes); null or too small = every list whole.
+long fvk_attn_bs16_workspace_bytes(const fvk_attn_args* a, int max_kv) { return bs16_plan(a, max_kv).ws_bytes; }
+
 int fvk_attn_bs16_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
-                         int variant, hipStream_t s) {
+                         int variant, void* ws, long ws_bytes, hipStream_t s) {
     const long nwg = ((long)(a->Sq / 64) + 3) / 4;
     const long nblk = nwg * a->H * a->B;
-    FVK_CHECK(nblk < 0x7fffffffL, FVK_ERR_ARG, "fvk_attn_block_sparse_bf16: grid too large");
+    FVK_CHECK(nblk < 0x7fffffffL / 4, FVK_ERR_ARG, "fvk_attn_block_sparse_bf16: grid too large");
 #if FVK_VARIANTS
 #define FVK_BS16_VARIANT(N, ...)                                                                                                          \
     if (variant == N) {                                                                                                                   \
         static FvkLdsConfigured configured_v;                                                                                             \
         if (int rc = fvk_config_lds(configured_v, (const void*)attn_bs16_kernel<__VA_ARGS__>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16)")) return rc; \
-        hipLaunchKernelGGL((attn_bs16_kernel<__VA_ARGS__>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num, kv_block_sizes, max_kv); \
+        hipLaunchKernelGGL((attn_bs16_kernel<__VA_ARGS__>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num, kv_block_sizes, max_kv, Bs16Split{}); \
         FVK_LAUNCH_CHECK();                                                                                                               \
         return FVK_OK;                                                                                                                    \
     }
     FVK_BS16_VARIANT(1, true, 0)    // hardware workgroup order
     FVK_BS16_VARIANT(2, false, 2)   // LDS-DMA pieces with the nt policy (aux = 2)
     FVK_BS16_VARIANT(3, false, 1)   // ... with sc0 (aux = 1)
+    FVK_BS16_VARIANT(4, false, 0)   // every list whole (no split last round)
     FVK_BS16_VARIANT(11, false, 0, 1)  // timing ablations (wrong results): half the LDS-DMA pieces
     FVK_BS16_VARIANT(12, false, 0, 2)  // no softmax VALU
     FVK_BS16_VARIANT(14, false, 0, 4)  // no counted waits
@@ -588,9 +678,25 @@ int fvk_attn_bs16_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const i
 #undef FVK_BS16_VARIANT
 #endif
     (void)variant;
-    static FvkLdsConfigured configured;
-    if (int rc = fvk_config_lds(configured, (const void*)attn_bs16_kernel<false>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16)")) return rc;
-    hipLaunchKernelGGL((attn_bs16_kernel<false>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num, kv_block_sizes, max_kv);
-    FVK_LAUNCH_CHECK();
+    Bs16Plan plan = bs16_plan(a, max_kv);
+    if (plan.parts < 2 || !ws || ws_bytes < plan.ws_bytes) plan = Bs16Plan{nblk, 0, 1, 0};
+    static FvkLdsConfigured configured, configured_split;
+    if (plan.full > 0) {
+        if (int rc = fvk_config_lds(configured, (const void*)attn_bs16_kernel<false>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16)")) return rc;
+        hipLaunchKernelGGL((attn_bs16_kernel<false>), dim3((unsigned)plan.full), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num, kv_block_sizes, max_kv, Bs16Split{});
+        FVK_LAUNCH_CHECK();
+    }
+    if (plan.parts >= 2) {
+        Bs16Split sp;
+        sp.wg_base = (int)plan.full; sp.parts = plan.parts; sp.tail_rows = (int)(plan.tail * 256);
+        sp.o_part = (float*)ws;
+        sp.lse_part = sp.o_part + (long)plan.parts * sp.tail_rows * 128;
+        if (int rc = fvk_config_lds(configured_split, (const void*)attn_bs16_kernel<false, 0, 0, true>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16, split)")) return rc;
+        hipLaunchKernelGGL((attn_bs16_kernel<false, 0, 0, true>), dim3((unsigned)(plan.tail * plan.parts)), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num,
+                           kv_block_sizes, max_kv, sp);
+        FVK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bs16_merge_parts_kernel, dim3((unsigned)((sp.tail_rows + 3) / 4)), dim3(256), 0, s, *a, sp);
+        FVK_LAUNCH_CHECK();
+    }
     return FVK_OK;
 }

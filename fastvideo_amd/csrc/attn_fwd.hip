@@ -34,7 +34,8 @@ int fvk_attn_w64_lists_launch(const fvk_attn_args* a, const fvk_pp2_lists* la, h
 int fvk_attn_vsa_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
                         hipStream_t s);  // attn_vsa.hip: 64-row lists, key-split, register-staged prefetch
 int fvk_attn_bs16_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
-                         int variant, hipStream_t s);  // attn_bs16.hip (round 6): 64-row lists, one wave per list, attn_w16's in-wave pipeline
+                         int variant, void* ws, long ws_bytes, hipStream_t s);  // attn_bs16.hip (round 6): 64-row lists, one wave per list, attn_w16's in-wave pipeline
+long fvk_attn_bs16_workspace_bytes(const fvk_attn_args* a, int max_kv);
 
 namespace {
 
@@ -646,10 +647,26 @@ extern "C" int fvk_attn_dense_split_bf16(const fvk_attn_args* a, int n_split, fl
     return fvk_attn_w16_split_launch(a, n_split, o_part, lse_part, (hipStream_t)stream);
 }
 
+extern "C" long fvk_attn_block_sparse_workspace_bytes(const fvk_attn_args* a, int max_kv, int q_block) {
+    if (!a || q_block != 64 || a->Sq < 64 || a->H <= 0 || a->B <= 0 || max_kv <= 0) return 0;
+#if FVK_VARIANTS
+    if (fvk::tunable(fvk::TUNE_ATTN_IMPL) != 0) return 0;  // the A/B kernels and variants run every list whole
+#endif
+    return fvk_attn_bs16_workspace_bytes(a, max_kv);
+}
+
 extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
                                           const int32_t* kv_block_sizes, int max_kv, int q_block, void* stream) {
+    return fvk_attn_block_sparse_ws_bf16(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, q_block, nullptr, 0, stream);
+}
+
+extern "C" int fvk_attn_block_sparse_ws_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
+                                             const int32_t* kv_block_sizes, int max_kv, int q_block, void* workspace, long workspace_bytes,
+                                             void* stream) {
     int rc = check_common(a, "fvk_attn_block_sparse_bf16");
     if (rc) return rc;
+    FVK_CHECK(workspace_bytes >= 0 && (workspace || workspace_bytes == 0) && ((uintptr_t)workspace & 15) == 0, FVK_ERR_ARG,
+              "fvk_attn_block_sparse_ws_bf16: workspace must be 16-byte aligned device memory of workspace_bytes >= 0 bytes");
     FVK_CHECK(q2k_idx && q2k_num && kv_block_sizes && max_kv > 0, FVK_ERR_ARG, "fvk_attn_block_sparse_bf16: null index arrays");
     FVK_CHECK(q_block == 64 || q_block == 128, FVK_ERR_ARG, "fvk_attn_block_sparse_bf16: q_block=%d (64 or 128 query rows per list)", q_block);
     FVK_CHECK(a->Sq % q_block == 0 && a->Skv % 64 == 0, FVK_ERR_ARG,
@@ -677,8 +694,8 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     // ids, 50 = the former one-list 4-wave workgroups, two per CU
 #if FVK_VARIANTS
     const int impl = fvk::tunable(fvk::TUNE_ATTN_IMPL);
-    if (impl == 0 || (impl >= 56 && impl <= 58) || (impl >= 66 && impl <= 72))   // 57 / 58: nt / sc0 cache policy of the pieces; 66.. timing ablations
-        return fvk_attn_bs16_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, impl ? impl - 55 : 0, (hipStream_t)stream);
+    if (impl == 0 || (impl >= 56 && impl <= 59) || (impl >= 66 && impl <= 72))   // 57 / 58: nt / sc0 cache policy of the pieces; 59: no split last round; 66.. timing ablations
+        return fvk_attn_bs16_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, impl ? impl - 55 : 0, workspace, workspace_bytes, (hipStream_t)stream);
     if (impl == 50) return launch<2, MODE_BLOCKS, 128, 2>(a, ma, (hipStream_t)stream);
     // Shipped: two lists per workgroup, 2 compute + 2 loader waves each, one-stage-ahead LDS-DMA.  Two alternatives were built to attack what
     // looked like its limits and are kept for A/B because BOTH land on the same ~23 B / clock / CU of K / V^T ingest (2.55-2.60 ms at cfg2):
@@ -690,7 +707,7 @@ extern "C" int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t*
     if (impl == 54 && max_kv <= 2048) return fvk_attn_vsa_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, (hipStream_t)stream);
     return launch<2, MODE_BLOCKS, 128, 2, 2>(a, ma, (hipStream_t)stream);  // 55 (and every other value)
 #else
-    return fvk_attn_bs16_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, 0, (hipStream_t)stream);
+    return fvk_attn_bs16_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, 0, workspace, workspace_bytes, (hipStream_t)stream);
 #endif
 }
 

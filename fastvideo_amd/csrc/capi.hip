@@ -15,7 +15,7 @@ void fvk_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* fvk_last_error(void) { return g_err; }
-extern "C" int fvk_abi_version(void) { return 7; }  // 7: + fvk_gemm_vt_bf16 (round 5's entry point, numbered in round 6), fvk_mfma_sustained_probe_bf16; 6: + fvk_qkv_norm_rope_pack2_bf16, dense kernel id 3 (attn_pp2 at any key length); 5: + fvk_attn_dense_kernel_bf16, fvk_attn_dense_split_bf16, fvk_qkvg_norm_rope_pack_bf16, fvk_is_probe_build
+extern "C" int fvk_abi_version(void) { return 8; }  // 8: + fvk_attn_block_sparse_ws_bf16, fvk_attn_block_sparse_workspace_bytes (split last round of the 64-row list kernel); 7: + fvk_gemm_vt_bf16 (round 5's entry point, numbered in round 6), fvk_mfma_sustained_probe_bf16; 6: + fvk_qkv_norm_rope_pack2_bf16, dense kernel id 3 (attn_pp2 at any key length); 5: + fvk_attn_dense_kernel_bf16, fvk_attn_dense_split_bf16, fvk_qkvg_norm_rope_pack_bf16, fvk_is_probe_build
 extern "C" int fvk_is_probe_build(void) { return FVK_VARIANTS; }
 
 extern "C" int fvk_device_arch(char* buf, int len) {

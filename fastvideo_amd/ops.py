@@ -478,12 +478,15 @@ def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, retur
     return (o, lse) if return_lse else o
 
 
-def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, layout="bhsd", return_lse=False, q_block=64, pair_union=False):
+def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, layout="bhsd", return_lse=False, q_block=64, pair_union=False,
+                      split_last_round=True):
     """q2k_idx int32 [B,H,nq,max_kv] ascending block lists, q2k_num [B,H,nq], kv_block_sizes [nkv].
     pair_union (64-row lists, max_kv <= 2048): the two lists of neighbouring query blocks are merged (fvk_vsa_union_lists) and walked as one by
     their workgroup — a KV tile both selected is fetched once (fvk_attn_block_sparse_union_bf16); bit-identical output.  OFF by default: the
     walk fetches ~30 % fewer tiles on the selections the model makes but takes one step per tile of the UNION, both halves in lockstep, and the
-    kernel is step-bound, not ingest-bound — 3.2 vs 2.65 ms per layer at cfg2 (profiles/r04u_vsa_union_ab.log)."""
+    kernel is step-bound, not ingest-bound — 3.2 vs 2.65 ms per layer at cfg2 (profiles/r04u_vsa_union_ab.log).
+    split_last_round (64-row lists): the workgroups of the launch's last, partly empty round walk their lists in 2-4 parts that are merged
+    afterwards (fvk_attn_block_sparse_ws_bf16); False = every list whole."""
     scale = q.shape[-1]**-0.5 if scale is None else scale
     vt = _vt_of(v, layout)
     o = torch.empty_like(q)
@@ -502,8 +505,21 @@ def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, lay
         _lib.call("fvk_vsa_union_lists", _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), _p(u_idx), _p(u_num), B * H, nq, max_kv, _stream())
         _lib.call("fvk_attn_block_sparse_union_bf16", C.byref(a), _p(u_idx), _p(u_num), 2 * max_kv, _stream())
         return (o, lse) if return_lse else o
-    _lib.call("fvk_attn_block_sparse_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), max_kv, int(q_block), _stream())
+    # the split last round of the 64-row list kernel (include/fvk_amd.h: fvk_attn_block_sparse_ws_bf16) wants a workspace; one buffer per
+    # (device, size), kept — a captured HIP graph replays with the address it was captured with
+    ws_bytes = int(_lib.load().fvk_attn_block_sparse_workspace_bytes(C.byref(a), max_kv, int(q_block))) if split_last_round else 0
+    ws = None
+    if ws_bytes > 0:
+        key = (q.device.index, ws_bytes)
+        ws = _BS_WORKSPACES.get(key)
+        if ws is None:
+            ws = _BS_WORKSPACES[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
+    _lib.call("fvk_attn_block_sparse_ws_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), max_kv, int(q_block),
+              _p(ws) if ws is not None else None, ws_bytes, _stream())
     return (o, lse) if return_lse else o
+
+
+_BS_WORKSPACES = {}
 
 
 def attn_tile_lists(q, k, v, q2k_idx, q2k_num, kv_block_sizes, rows_per_list, q_rows_valid=None, scale=None, layout="bhsd", vt=None,

@@ -27,7 +27,7 @@ extern "C" {
 #define FVK_ERR_LAUNCH (-2)  /* hipLaunch / hip runtime error                  */
 
 const char* fvk_last_error(void);
-int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3, 6 = round 4, 7 = round 5's fvk_gemm_vt_bf16 + round 6's fvk_mfma_sustained_probe_bf16) */
+int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3, 6 = round 4, 7 = round 5's fvk_gemm_vt_bf16 + round 6's fvk_mfma_sustained_probe_bf16, 8 = fvk_attn_block_sparse_ws_bf16 / _workspace_bytes) */
 int fvk_device_arch(char* buf, int len);   /* gcnArchName of the current device ("gfx950...") */
 int fvk_is_probe_build(void);              /* 0: the product library; 1: the measurement build (scripts/probes/libfvk_probe.so) */
 /* Integer knobs for within-process A/B measurements (scripts/microbench.py); 0 = shipped configuration.
@@ -232,6 +232,17 @@ int fvk_attn_dense_split_bf16(const fvk_attn_args* a, int n_split, float* o_part
  * streams are addressed through 32-bit buffer descriptors. */
 int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num,
                                const int32_t* kv_block_sizes, int max_kv, int q_block, void* stream);
+/* The same call with a device WORKSPACE (q_block 64; round 6): the launch runs one 4-list workgroup per CU, so a list count that is not a
+ * multiple of 4 x CUs leaves the last round partly empty (Wan2.1-1.3B at 81f x 480p: 1 872 workgroups = 7.31 rounds of 256).  With a workspace of
+ * fvk_attn_block_sparse_workspace_bytes(a, max_kv, q_block) bytes (0 = no split planned; 16-byte aligned, overwritten) the workgroups of the
+ * last round walk their lists in 2-4 PARTS (whole blocks, an even count per part) on as many workgroups, each part's result is written un-merged
+ * (normalised O as fp32 rows + base-2 LSE) and merged as fvk_attn_dense_split_bf16 does: o = sum_p 2^(lse_p - max) o_p / sum_p 2^(lse_p - max).
+ * The rows of split lists agree with the unsplit call to rounding (a part's softmax reference is the row maximum of ITS first block), every
+ * other row is bit-identical.  workspace NULL / too small: exactly fvk_attn_block_sparse_bf16.  No reference counterpart (flash-attn's
+ * split-KV decode is the same idea). */
+long fvk_attn_block_sparse_workspace_bytes(const fvk_attn_args* a, int max_kv, int q_block);
+int fvk_attn_block_sparse_ws_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes,
+                                  int max_kv, int q_block, void* workspace, long workspace_bytes, void* stream);
 /* The same attention for 64-row lists with the two lists of a workgroup's neighbouring query blocks (2p, 2p + 1) walked as ONE merged list
  * (round 4): fvk_vsa_union_lists merges the ascending lists of fvk_map_to_index into u_idx [B*H, ceil(nq/2), 2*max_kv] packed entries
  * (block id | valid keys << 22 | halves << 29) + u_num [B*H, ceil(nq/2)]; fvk_attn_block_sparse_union_bf16 walks them — a KV tile both blocks

@@ -1,5 +1,5 @@
 """Block-sparse (VSA) kernel at the cfg2 geometry (624 blocks, top-125, 12 heads, real block sizes) on the model's second-layer block selection
-and on uniformly random lists: attn_bs16 (round 6, shipped: "attn_impl" 0) vs attn_bs16 on hardware workgroup ids (56) vs the round-1 kernel (55,
+and on uniformly random lists: attn_bs16 (round 6, shipped: "attn_impl" 0, with the split last round) vs every list whole (59) vs attn_bs16 on hardware workgroup ids (56) vs the round-1 kernel (55,
 with "vsa_impl" 2 = on XCD-contiguous ids), interleaved; outputs compared with each other and with exact fp32 attention on sampled query blocks.
 PMC=1: N_LAUNCH launches of ONE variant (ATTN_IMPL) for rocprofv3 --pmc passes."""
 import os as _os
@@ -30,7 +30,7 @@ del model, sd
 q, k, v = (torch.randn((1, S_pad, 12, 128), generator=g, device=dev).bfloat16() for _ in range(3))
 mask_rand = ops.topk_mask(torch.randn((1, 12, n, n), generator=g, device=dev), topk)
 lists = {"model_layer1": ops.map_to_index(mask_model), "uniform_random": ops.map_to_index(mask_rand)}
-VARIANTS = {"bs16 (shipped)": (0, 0), "bs16, hardware ids": (56, 0), "bs16, nt pieces": (57, 0), "bs16, sc0 pieces": (58, 0), "round-1 kernel": (55, 0),
+VARIANTS = {"bs16 (shipped)": (0, 0), "bs16, every list whole (no split last round)": (59, 0), "bs16, hardware ids": (56, 0), "bs16, nt pieces": (57, 0), "bs16, sc0 pieces": (58, 0), "round-1 kernel": (55, 0),
             "round-1 kernel, XCD-contiguous ids": (55, 2)}
 
 
@@ -85,7 +85,9 @@ for name, (idx, num) in lists.items():
     e_old = max((old[0, i * 64:(i + 1) * 64, h].float() - ref[(h, i)]).abs().max().item() for (h, i) in blocks)
     d = (new.float() - old.float()).abs()
     res[name] = {"ms": t, "tflops_real_pairs": {vn: round(4 * pairs * 64 * 64 * 128 / (min(v_) * 1e-3) / 1e12, 1) for vn, v_ in t.items()},
-                 "bs16_ids_bit_identical": bool(torch.equal(outs["bs16 (shipped)"], outs["bs16, hardware ids"])),
+                 "bs16_ids_bit_identical": bool(torch.equal(outs["bs16, every list whole (no split last round)"], outs["bs16, hardware ids"])),
+                 "split_vs_whole_max_abs": round((new.float() - outs["bs16, every list whole (no split last round)"].float()).abs().max().item(), 6),
+                 "split_vs_whole_rows_changed": int(((new.float() - outs["bs16, every list whole (no split last round)"].float()).abs().amax(-1) > 0).sum()),
                  "bs16_vs_round1_max_abs": round(d.max().item(), 6), "bs16_vs_round1_mean_abs": float(f"{d.mean().item():.3g}"),
                  "finite": bool(torch.isfinite(new.float()).all()),
                  "max_abs_err_vs_exact_fp32_on_sampled_blocks": {"bs16": round(e_new, 6), "round-1 kernel": round(e_old, 6)}}

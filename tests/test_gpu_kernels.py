@@ -521,6 +521,64 @@ def test_attn_block_sparse_cold_paths(ops):
     assert (out[0, 2].float().cpu() - want).abs().max().item() < 2e-2
 
 
+def test_attn_block_sparse_split_last_round(ops):
+    """fvk_attn_block_sparse_ws_bf16 (round 6): the workgroups of the launch's last, partly empty round walk their lists in 2-4 PARTS that are
+    merged by LSE weights.  Small grid (every workgroup is "last round": 4 parts): lists of every length class — empty, shorter than the part
+    count, odd, full —, ragged blocks, a size-0 block where a part starts, a spiked key inside one part (that part's exact pass); against the
+    oracle's masked fp32 attention, the un-split call, and the merged LSE."""
+    B, H, nq, nk = 1, 2, 8, 80
+    q, k, v = rnd((B, H, nq * 64, 128), 21), rnd((B, H, nk * 64, 128), 22), rnd((B, H, nk * 64, 128), 23)
+    rng = np.random.default_rng(5)
+    vbs = rng.integers(1, 65, nk).astype(np.int32)
+    vbs[rng.random(nk) < 0.6] = 64
+    bm = rng.random((B, H, nq, nk)) < 0.7
+    bm[0, 0, 0, :] = False                       # empty list
+    bm[0, 0, 1, :] = False; bm[0, 0, 1, [3, 50, 77]] = True   # 3 blocks: fewer than the parts x 2
+    bm[0, 0, 2, :] = True                        # all 80
+    bm[0, 0, 3, :] = False; bm[0, 0, 3, :41] = True           # odd
+    idx, num = V.map_to_index(bm)
+    # list (0, 1, 0): its second part starts with a size-0 block (per = ceil(n / 4) rounded up to even)
+    n010 = int(num[0, 1, 0]); per = ((n010 + 3) // 4 + 1) & ~1
+    vbs[idx[0, 1, 0, per]] = 0
+    # list (0, 1, 5): one key of its LAST part scores 2^100 above the rest
+    last = int(idx[0, 1, 5, int(num[0, 1, 5]) - 1])
+    k[0, 1, last * 64 + 3] = q[0, 1, 5 * 64 + 9] * 6
+    ref = torch.nan_to_num(V.block_sparse_attn(q, k, v, bm, vbs), nan=0.0)
+    dv = lambda t: torch.from_numpy(t).to(DEV)
+    args = (q.to(DEV), k.to(DEV), v.to(DEV), dv(idx), dv(num), dv(vbs))
+    o1, l1 = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True, split_last_round=False)
+    o4, l4 = ops.attn_block_sparse(*args, layout="bhsd", return_lse=True)
+    _attn_check(o1, ref, "block sparse, whole lists")
+    _attn_check(o4, ref, "block sparse, split last round")
+    assert (o4[0, 0, :64] == 0).all()
+    assert (o4.float() - o1.float()).abs().max().item() < 4e-2
+    fin = torch.isfinite(l1)
+    assert (torch.isfinite(l4) == fin).all() and (l4[fin] - l1[fin]).abs().max().item() < 1e-2
+
+
+def test_attn_block_sparse_split_last_round_full_rounds_bit_identical(ops):
+    """A grid of one full round + a tail (260 workgroups on 256 CUs): the lists of the full round are bit-identical to the un-split call, the
+    four workgroups of the tail (split in 4 parts) agree to rounding."""
+    B, H, nq, nk = 1, 2, 520, 70
+    g = torch.Generator().manual_seed(7)
+    q, k, v = (torch.randn((B, H, n * 64, 128), generator=g).to(torch.bfloat16).to(DEV) for n in (nq, nk, nk))
+    rng = np.random.default_rng(9)
+    bm = rng.random((B, H, nq, nk)) < 0.6
+    bm[..., 0] = True
+    vbs = np.full(nk, 64, dtype=np.int32); vbs[-1] = 40
+    idx, num = V.map_to_index(bm)
+    dv = lambda t: torch.from_numpy(t).to(DEV)
+    o1 = ops.attn_block_sparse(q, k, v, dv(idx), dv(num), dv(vbs), layout="bhsd", split_last_round=False)
+    o4 = ops.attn_block_sparse(q, k, v, dv(idx), dv(num), dv(vbs), layout="bhsd")
+    assert torch.isfinite(o4).all()
+    d = (o4.float() - o1.float()).abs().amax(dim=-1).view(-1)            # per (head, row), flat = workgroup order
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    total_wg = H * (nq // 4)
+    full_rows = (total_wg - total_wg % cus) * 256
+    assert total_wg % cus != 0 and d[:full_rows].max().item() == 0.0
+    assert 0.0 < d[full_rows:].max().item() < 2e-2
+
+
 @pytest.mark.parametrize("rows", [256, 384, 512])
 def test_attn_tile_lists_shared_kv_lists(ops, rows):
     """fvk_attn_tile_lists_bf16: every `rows` consecutive query rows share one list of 64-key blocks (sliding-tile windows).  Against the
