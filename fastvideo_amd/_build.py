@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfvk_amd.so")
-SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.hip", "gemm_w1.hip", "gemm_w1n.hip", "fp8.hip", "attn_fwd.hip", "attn_bs16.hip", "attn_pp2.hip", "attn_w16.hip", "attn_w64.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_conv3w.hip", "vae_post.hip", "sched_step.hip", "mfma_probe.hip"]
+SOURCES = ["capi.hip", "norm_mod.hip", "gemm_bf16.hip", "gemm_pp.hip", "gemm_ph.hip", "gemm_w1.hip", "gemm_w1n.hip", "fp8.hip", "attn_fwd.hip", "attn_bs16.hip", "attn_pp2.hip", "attn_w16.hip", "attn_w64.hip", "vsa_misc.hip", "vae_conv.hip", "vae_conv3.hip", "vae_conv3w.hip", "vae_convout.hip", "vae_post.hip", "sched_step.hip", "mfma_probe.hip"]
 # measurement build (scripts/probes/libfvk_probe.so): the same sources with -DFVK_PROBE_BUILD (variant dispatch + fvk_set_tunable knobs
 # compiled in) plus the experiment kernels that never shipped.  Nothing in the product path loads it (fastvideo_amd/_lib.py: FVK_PROBE_LIB=1).
 PROBE_DIR = os.path.join(HERE, "..", "scripts", "probes")

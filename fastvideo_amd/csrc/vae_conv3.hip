@@ -500,7 +500,13 @@ int fvk_vae_conv3_launch(const void* in, const void* w, const void* bias, void* 
     a.residual = (const bf16_t*)residual; a.out_f32 = out_f32;
     a.out_fs = out_fs; a.res_fs = res_fs; a.plane_stride = plane_stride;
     a.T = T; a.H = H; a.W = W; a.Hin = Hin; a.Win = Win; a.Cin = Cin; a.Cout = Cout; a.KT = KT; a.ring = ring; a.ring_start = ring_start;
-    if (epilogue == EPI_FINAL && !ups && Cout <= 32) return launch3<1, EPI_FINAL, false, 1>(a, s);  // conv_out: one 32-channel block per wave
+    // conv_out (96 -> 3 channels, 3 time taps): the rolling three-frame kernel of vae_convout.hip (round 6: every input frame fetched once, the
+    // time taps on the MFMA's N axis); "vae_conv_impl" 3 / 4 (measurement build) keep this file's padded-N kernel for A/B
+    if (epilogue == EPI_FINAL && !ups && (!FVK_VARIANTS || (fvk_vae_conv_tunable() != 3 && fvk_vae_conv_tunable() != 4))) {
+        int rc = FVK_OK;
+        if (fvk_vae_convout_launch(a, s, &rc)) return rc;
+    }
+    if (epilogue == EPI_FINAL && !ups && Cout <= 32) return launch3<1, EPI_FINAL, false, 1>(a, s);  // (other shapes) one 32-channel block per wave
     // bf16-output convs (upsampling or not): the one-wave-per-SIMD kernel on 16x16x32 MFMAs (vae_conv3w.hip, round 4); "vae_conv_impl" 3 (measurement
     // build) keeps this file's 8-wave kernel for A/B and the <= 1-ulp comparison tests
     if (!FVK_VARIANTS || fvk_vae_conv_tunable() != 3) {

@@ -26,3 +26,5 @@ constexpr unsigned OOB = 0xFFFFFF00u;  // a buffer offset past every descriptor'
 
 // vae_conv3w.hip: true if it served the launch (non-upsampling, bf16-output 3x3 convs); false = not eligible, the caller runs vae_conv3.hip's kernel
 bool fvk_vae_conv3w_launch(fvkc3::Conv3Args a, int epilogue, hipStream_t s, int* rc);
+// vae_convout.hip: true if it served the launch (conv_out: EPI_FINAL, 3 time taps, <= 3 output channels, <= 96 input channels)
+bool fvk_vae_convout_launch(fvkc3::Conv3Args a, hipStream_t s, int* rc);

@@ -100,6 +100,30 @@ def test_conv_final_epilogue_fp32_planar_clamp(ops):
     assert (got[:, :2] == 7).all() and (got[:, 2 + T:] == 7).all()
 
 
+@pytest.mark.parametrize("T,H,W,start", [(1, 16, 32, 0), (2, 17, 33, 2), (5, 50, 70, 3), (7, 9, 100, 6), (16, 48, 64, 11)])
+def test_conv_out_rolling_three_frames(ops, T, H, W, start):
+    """conv_out (96 -> 3 channels, vae_convout.hip, round 6): every input frame multiplied once by the three time taps' weight rows, the running
+    sums of three output frames in three lane groups.  Ring with wrap-around, one to sixteen frames (every residue of T mod 3), ragged tiles,
+    one tile and several; vs torch conv3d in fp32, and the same frames computed in passes of other lengths are BIT-identical."""
+    Cin = 96
+    w, b, x = rnd((3, Cin, 3, 3, 3), 1, 2 * (27 * Cin)**-0.5), rnd((3,), 2, 0.1), rnd((Cin, T + 2, H, W), 3)
+    ref = conv_ref(x.bfloat16().float(), w.bfloat16().float(), b.bfloat16().float(), 3, 3).clamp(-1, 1)
+    ring = T + 3
+    buf = torch.zeros((ring, H, W, Cin), dtype=torch.bfloat16, device="cuda")
+    frames = cl(x)
+    for l in range(T + 2):
+        buf[(start + l) % ring] = frames[l]
+    wf, bf = flat_w(w), b.cuda().bfloat16()
+    out = torch.full((3, T, H, W), 7.0, device="cuda")
+    ops.vae_conv(buf, wf, bf, T=T, H=H, W=W, kt=3, ks=3, ring_start=start, out_f32=out, plane_stride=T * H * W)
+    torch.testing.assert_close(out.cpu(), ref, atol=5e-3, rtol=0)
+    if T >= 5:  # the same output frames in two passes (3 frames, then the rest)
+        out2 = torch.full((3, T, H, W), 7.0, device="cuda")
+        ops.vae_conv(buf, wf, bf, T=3, H=H, W=W, kt=3, ks=3, ring_start=start, out_f32=out2, plane_stride=T * H * W)
+        ops.vae_conv(buf, wf, bf, T=T - 3, H=H, W=W, kt=3, ks=3, ring_start=(start + 3) % ring, out_f32=out2[:, 3:], plane_stride=T * H * W)
+        assert torch.equal(out2, out)
+
+
 @pytest.mark.parametrize("C,silu", [(96, True), (192, True), (384, False), (32, True), (128, False)])
 def test_rmsnorm_silu_into_ring(ops, C, silu):
     T, HW, ring, slot0 = 3, 77, 5, 3
