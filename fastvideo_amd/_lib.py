@@ -59,7 +59,6 @@ SIGNATURES = {
     "fvk_attn_block_sparse_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp],
     "fvk_attn_block_sparse_ws_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp, i64, vp],
     "fvk_attn_block_sparse_workspace_bytes": [C.POINTER(AttnArgs), i32, i32],
-    "fvk_vsa_sparse_combine_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, vp, vp, vp, i64, i64, i64, vp, i64, vp],
     "fvk_vsa_union_lists": [vp, vp, vp, vp, vp, i32, i32, i32, vp],
     "fvk_attn_block_sparse_union_bf16": [C.POINTER(AttnArgs), vp, vp, i32, vp],
     "fvk_attn_tile_lists_bf16": [C.POINTER(AttnArgs), vp, vp, vp, i32, i32, vp, vp, vp],

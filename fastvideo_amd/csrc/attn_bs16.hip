@@ -367,33 +367,9 @@ struct Bs16Split {
     float* lse_part;  // [parts][tail_rows]
 };
 
-// COMBINE (fvk_vsa_sparse_combine_bf16): the VSA combine pass folded into the store — out = bf16(bf16(out_c * gate) + bf16(o)) (or out_c + o without
-// a gate), out_c the query block's coarse-branch row, gate and out addressed at the row's TOKEN (token_of_row: tile-major row -> token, negative =
-// a padding row, dropped; null: row = token).  ref: fastvideo_kernel/ops.py:128-131, video_sparse_attn.py:331-342.  Same arithmetic and rounding
-// points as vsa_combine_kernel (vsa_misc.hip) on the bf16-rounded sparse output: bit-identical to the two-pass form.
-struct Bs16Combine {
-    const bf16_t* out_c;          // [B, H, Sq / 64, 128]
-    const bf16_t* gate;           // or null
-    const int32_t* token_of_row;  // [Sq] or null
-    long g_bs, g_ss, g_hs;        // gate strides (elements); a.o / a.o_* address the combined output
-};
-__device__ __forceinline__ bf16x4 bs16_combine4(const Bs16Combine& cb, const bf16_t* oc_row, const bf16_t* g_row, int col, bf16x4 os) {
-    const bf16x4 oc = *reinterpret_cast<const bf16x4*>(oc_row + col);
-    bf16x4 r;
-    if (cb.gate) {
-        const bf16x4 gt = *reinterpret_cast<const bf16x4*>(g_row + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = (bf16_t)(bf16_round_opaque((float)oc[e] * (float)gt[e]) + (float)os[e]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = (bf16_t)((float)oc[e] + (float)os[e]);
-    }
-    return r;
-}
-
-template <bool PLAIN_IDS = false, int AUX = 0, int ABL = 0, bool SPLIT = false, bool COMBINE = false>
+template <bool PLAIN_IDS = false, int AUX = 0, int ABL = 0, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, const int32_t* __restrict__ q2k_idx, const int32_t* __restrict__ q2k_num,
-                                                           const int32_t* __restrict__ kv_block_sizes, int max_kv, Bs16Split sp, Bs16Combine cb) {
+                                                           const int32_t* __restrict__ kv_block_sizes, int max_kv, Bs16Split sp) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
     FVK_CLAIM_WHOLE_REGISTER_FILE();
@@ -595,16 +571,11 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
                 /* an empty part (or one whose keys are all masked): weight 0 in the merge */                        \
                 if (g == 0) sp.lse_part[prow0 + 16 * qb + l15] = l_tot > 0.f ? w.m_run[qb] * w.c2 + log2f(l_tot) : -INFINITY; \
             } else {                                                                                                 \
-                const int tok = (COMBINE && cb.token_of_row) ? cb.token_of_row[qrow[qb]] : qrow[qb];                 \
-                bf16_t* orow = op + (long)tok * a.o_ss;                                                              \
-                const bf16_t* grow = COMBINE ? cb.gate + (long)b * cb.g_bs + (long)h * cb.g_hs + (long)tok * cb.g_ss : nullptr; \
-                if (!COMBINE || tok >= 0) {                                                                          \
-                    _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                  \
-                        bf16x4 v4;                                                                                   \
-                        _Pragma("unroll") for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(w.o[qb][d][e] * inv);         \
-                        if (COMBINE) v4 = bs16_combine4(cb, cb.out_c + meta * 128, grow, d * 16 + g * 4, v4);        \
-                        *reinterpret_cast<bf16x4*>(orow + d * 16 + g * 4) = v4;                                      \
-                    }                                                                                                \
+                bf16_t* orow = op + (long)qrow[qb] * a.o_ss;                                                         \
+                _Pragma("unroll") for (int d = 0; d < 8; ++d) {                                                      \
+                    bf16x4 v4;                                                                                       \
+                    _Pragma("unroll") for (int e = 0; e < 4; ++e) v4[e] = (bf16_t)(w.o[qb][d][e] * inv);             \
+                    *reinterpret_cast<bf16x4*>(orow + d * 16 + g * 4) = v4;                                          \
                 }                                                                                                    \
                 if (a.lse && g == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow[qb]] = w.m_run[qb] * w.c2 + log2f(l_tot); \
             }                                                                                                        \
@@ -621,8 +592,7 @@ __global__ __launch_bounds__(256, 1) void attn_bs16_kernel(fvk_attn_args a, cons
 
 // out[b, row, h, :] = sum_p 2^(lse_p - max) o_part[p] / sum_p 2^(lse_p - max) over the parts of a SPLIT launch: one wave per row, two columns per
 // lane (attn_w16's merge of its split-KV form); HBM-bound, parts * 516 B read and 256 B written per row.
-template <bool COMBINE>
-__global__ __launch_bounds__(256) void bs16_merge_parts_kernel(fvk_attn_args a, Bs16Split sp, Bs16Combine cb) {
+__global__ __launch_bounds__(256) void bs16_merge_parts_kernel(fvk_attn_args a, Bs16Split sp) {
     const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= sp.tail_rows) return;
     const int lane = threadIdx.x & 63;
@@ -648,22 +618,7 @@ __global__ __launch_bounds__(256) void bs16_merge_parts_kernel(fvk_attn_args a, 
     bf16x2 o2;
     o2[0] = (bf16_t)(acc0 * inv);
     o2[1] = (bf16_t)(acc1 * inv);
-    int tok = qrow;
-    if (COMBINE) {
-        if (cb.token_of_row) tok = cb.token_of_row[qrow];
-        if (tok >= 0) {
-            const bf16x2 oc = *reinterpret_cast<const bf16x2*>(cb.out_c + (((long)b * a.H + h) * nqb + qb_id) * 128 + lane * 2);
-            if (cb.gate) {
-                const bf16x2 gt = *reinterpret_cast<const bf16x2*>(cb.gate + (long)b * cb.g_bs + (long)h * cb.g_hs + (long)tok * cb.g_ss + lane * 2);
-#pragma unroll
-                for (int e = 0; e < 2; ++e) o2[e] = (bf16_t)(bf16_round_opaque((float)oc[e] * (float)gt[e]) + (float)o2[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < 2; ++e) o2[e] = (bf16_t)((float)oc[e] + (float)o2[e]);
-            }
-        }
-    }
-    if (tok >= 0) *reinterpret_cast<bf16x2*>((bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs + (long)tok * a.o_ss + lane * 2) = o2;
+    *reinterpret_cast<bf16x2*>((bf16_t*)a.o + (long)b * a.o_bs + (long)h * a.o_hs + (long)qrow * a.o_ss + lane * 2) = o2;
     if (a.lse && lane == 0) a.lse[((long)b * a.H + h) * a.Sq + qrow] = mx + log2f(wsum);
 }
 
@@ -697,43 +652,6 @@ Bs16Plan bs16_plan(const fvk_attn_args* a, int max_kv) {
 // ws / ws_bytes: optional device workspace for the split last round (fvk_attn_bs16_workspace_bytes); null or too small = every list whole.
 long fvk_attn_bs16_workspace_bytes(const fvk_attn_args* a, int max_kv) { return bs16_plan(a, max_kv).ws_bytes; }
 
-template <bool COMBINE>
-int bs16_launch_plan(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv, void* ws,
-                     long ws_bytes, const Bs16Combine& cb, hipStream_t s) {
-    const long nblk = (((long)(a->Sq / 64) + 3) / 4) * a->H * a->B;
-    Bs16Plan plan = bs16_plan(a, max_kv);
-    if (plan.parts < 2 || !ws || ws_bytes < plan.ws_bytes) plan = Bs16Plan{nblk, 0, 1, 0};
-    static FvkLdsConfigured configured, configured_split;
-    if (plan.full > 0) {
-        if (int rc = fvk_config_lds(configured, (const void*)attn_bs16_kernel<false, 0, 0, false, COMBINE>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16)")) return rc;
-        hipLaunchKernelGGL((attn_bs16_kernel<false, 0, 0, false, COMBINE>), dim3((unsigned)plan.full), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num,
-                           kv_block_sizes, max_kv, Bs16Split{}, cb);
-        FVK_LAUNCH_CHECK();
-    }
-    if (plan.parts >= 2) {
-        Bs16Split sp;
-        sp.wg_base = (int)plan.full; sp.parts = plan.parts; sp.tail_rows = (int)(plan.tail * 256);
-        sp.o_part = (float*)ws;
-        sp.lse_part = sp.o_part + (long)plan.parts * sp.tail_rows * 128;
-        if (int rc = fvk_config_lds(configured_split, (const void*)attn_bs16_kernel<false, 0, 0, true>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16, split)")) return rc;
-        hipLaunchKernelGGL((attn_bs16_kernel<false, 0, 0, true>), dim3((unsigned)(plan.tail * plan.parts)), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num,
-                           kv_block_sizes, max_kv, sp, Bs16Combine{});
-        FVK_LAUNCH_CHECK();
-        hipLaunchKernelGGL(bs16_merge_parts_kernel<COMBINE>, dim3((unsigned)((sp.tail_rows + 3) / 4)), dim3(256), 0, s, *a, sp, cb);
-        FVK_LAUNCH_CHECK();
-    }
-    return FVK_OK;
-}
-
-// the VSA sparse branch with the combine pass in its store (fvk_vsa_sparse_combine_bf16, attn_fwd.hip)
-int fvk_attn_bs16_combine_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
-                                 const void* out_c, const void* gate, const int32_t* token_of_row, long g_bs, long g_ss, long g_hs, void* ws,
-                                 long ws_bytes, hipStream_t s) {
-    FVK_CHECK((((long)(a->Sq / 64) + 3) / 4) * a->H * a->B < 0x7fffffffL / 4, FVK_ERR_ARG, "fvk_vsa_sparse_combine_bf16: grid too large");
-    Bs16Combine cb{(const bf16_t*)out_c, (const bf16_t*)gate, token_of_row, g_bs, g_ss, g_hs};
-    return bs16_launch_plan<true>(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, ws, ws_bytes, cb, s);
-}
-
 int fvk_attn_bs16_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
                          int variant, void* ws, long ws_bytes, hipStream_t s) {
     const long nwg = ((long)(a->Sq / 64) + 3) / 4;
@@ -744,7 +662,7 @@ int fvk_attn_bs16_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const i
     if (variant == N) {                                                                                                                   \
         static FvkLdsConfigured configured_v;                                                                                             \
         if (int rc = fvk_config_lds(configured_v, (const void*)attn_bs16_kernel<__VA_ARGS__>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16)")) return rc; \
-        hipLaunchKernelGGL((attn_bs16_kernel<__VA_ARGS__>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num, kv_block_sizes, max_kv, Bs16Split{}, Bs16Combine{}); \
+        hipLaunchKernelGGL((attn_bs16_kernel<__VA_ARGS__>), dim3((unsigned)nblk), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num, kv_block_sizes, max_kv, Bs16Split{}); \
         FVK_LAUNCH_CHECK();                                                                                                               \
         return FVK_OK;                                                                                                                    \
     }
@@ -760,5 +678,25 @@ int fvk_attn_bs16_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const i
 #undef FVK_BS16_VARIANT
 #endif
     (void)variant;
-    return bs16_launch_plan<false>(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, ws, ws_bytes, Bs16Combine{}, s);
+    Bs16Plan plan = bs16_plan(a, max_kv);
+    if (plan.parts < 2 || !ws || ws_bytes < plan.ws_bytes) plan = Bs16Plan{nblk, 0, 1, 0};
+    static FvkLdsConfigured configured, configured_split;
+    if (plan.full > 0) {
+        if (int rc = fvk_config_lds(configured, (const void*)attn_bs16_kernel<false>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16)")) return rc;
+        hipLaunchKernelGGL((attn_bs16_kernel<false>), dim3((unsigned)plan.full), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num, kv_block_sizes, max_kv, Bs16Split{});
+        FVK_LAUNCH_CHECK();
+    }
+    if (plan.parts >= 2) {
+        Bs16Split sp;
+        sp.wg_base = (int)plan.full; sp.parts = plan.parts; sp.tail_rows = (int)(plan.tail * 256);
+        sp.o_part = (float*)ws;
+        sp.lse_part = sp.o_part + (long)plan.parts * sp.tail_rows * 128;
+        if (int rc = fvk_config_lds(configured_split, (const void*)attn_bs16_kernel<false, 0, 0, true>, LDS_BYTES, "fvk_attn_block_sparse_bf16 (bs16, split)")) return rc;
+        hipLaunchKernelGGL((attn_bs16_kernel<false, 0, 0, true>), dim3((unsigned)(plan.tail * plan.parts)), dim3(256), LDS_BYTES, s, *a, q2k_idx, q2k_num,
+                           kv_block_sizes, max_kv, sp);
+        FVK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(bs16_merge_parts_kernel, dim3((unsigned)((sp.tail_rows + 3) / 4)), dim3(256), 0, s, *a, sp);
+        FVK_LAUNCH_CHECK();
+    }
+    return FVK_OK;
 }

@@ -36,9 +36,6 @@ int fvk_attn_vsa_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const in
 int fvk_attn_bs16_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
                          int variant, void* ws, long ws_bytes, hipStream_t s);  // attn_bs16.hip (round 6): 64-row lists, one wave per list, attn_w16's in-wave pipeline
 long fvk_attn_bs16_workspace_bytes(const fvk_attn_args* a, int max_kv);
-int fvk_attn_bs16_combine_launch(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes, int max_kv,
-                                 const void* out_c, const void* gate, const int32_t* token_of_row, long g_bs, long g_ss, long g_hs, void* ws,
-                                 long ws_bytes, hipStream_t s);
 
 namespace {
 
@@ -712,23 +709,6 @@ extern "C" int fvk_attn_block_sparse_ws_bf16(const fvk_attn_args* a, const int32
 #else
     return fvk_attn_bs16_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, 0, workspace, workspace_bytes, (hipStream_t)stream);
 #endif
-}
-
-extern "C" int fvk_vsa_sparse_combine_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes,
-                                           int max_kv, const void* out_c, const void* gate, const int32_t* token_of_row, long g_bs, long g_ss,
-                                           long g_hs, void* workspace, long workspace_bytes, void* stream) {
-    int rc = check_common(a, "fvk_vsa_sparse_combine_bf16");
-    if (rc) return rc;
-    FVK_CHECK(q2k_idx && q2k_num && kv_block_sizes && max_kv > 0 && out_c, FVK_ERR_ARG, "fvk_vsa_sparse_combine_bf16: null pointer");
-    FVK_CHECK(a->Sq % 64 == 0 && a->Skv % 64 == 0, FVK_ERR_ARG, "fvk_vsa_sparse_combine_bf16: Sq=%d and Skv=%d must be whole 64-token blocks", a->Sq, a->Skv);
-    FVK_CHECK(!a->lse, FVK_ERR_ARG, "fvk_vsa_sparse_combine_bf16: no LSE output (forward of the combined result only)");
-    FVK_CHECK(!gate || (((g_bs | g_ss | g_hs) % 4 == 0) && ((uintptr_t)gate & 7) == 0), FVK_ERR_ARG,
-              "fvk_vsa_sparse_combine_bf16: gate strides / pointer must keep 8-byte alignment");
-    FVK_CHECK(((a->o_bs | a->o_ss | a->o_hs) % 4 == 0), FVK_ERR_ARG, "fvk_vsa_sparse_combine_bf16: output strides must keep 8-byte alignment");
-    FVK_CHECK(workspace_bytes >= 0 && (workspace || workspace_bytes == 0) && ((uintptr_t)workspace & 15) == 0, FVK_ERR_ARG,
-              "fvk_vsa_sparse_combine_bf16: workspace must be 16-byte aligned device memory of workspace_bytes >= 0 bytes");
-    return fvk_attn_bs16_combine_launch(a, q2k_idx, q2k_num, kv_block_sizes, max_kv, out_c, gate, token_of_row, g_bs, g_ss, g_hs, workspace,
-                                        workspace_bytes, (hipStream_t)stream);
 }
 
 extern "C" int fvk_attn_block_sparse_union_bf16(const fvk_attn_args* a, const int32_t* u_idx, const int32_t* u_num, int max_u, void* stream) {

@@ -140,9 +140,6 @@ def _expand_block_lists(idx, num, vbs, block_elements):
     return idx_s.contiguous(), num_s.contiguous(), sizes.contiguous()
 
 
-FUSE_SPARSE_COMBINE = True   # measurement switch (scripts/vsa_step_ab.py): False = sparse kernel + combine pass as two launches
-
-
 def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=False, block_elements=64, token_of_row=None, n_tokens=None):
     """The VSA composition (fastvideo_kernel/ops.py:108-128) on tensors of either layout: "bhsd" (the package API) or "bshd" (what the model
     host holds — strides go to the kernels, nothing is transposed or copied).  ``block_elements`` 64 (Wan: tile (4,4,4)) runs the 64-row
@@ -164,11 +161,6 @@ def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=Fa
     # sparse branch (ops.py:120-128): exact top-k mask -> ascending index lists -> block-sparse attention
     mask = ops.topk_mask(scores, min(int(topk), kv_num_blocks))
     idx, num = ops.map_to_index(mask)
-    if FUSE_SPARSE_COMBINE and block_elements == 64 and return_intermediates in (False, "mask"):
-        # the combine pass rides in the sparse kernel's store (fvk_vsa_sparse_combine_bf16, bit-identical to the two calls below);
-        # return_intermediates="mask" (the model host's vsa_trace): the same path, the block selection returned beside the result
-        out = ops.vsa_sparse_combine(q, k, v, idx, num, vbs, out_c, gate, layout=layout, token_of_row=token_of_row, n_tokens=n_tokens)
-        return (out, dict(mask=mask)) if return_intermediates else out
     if block_elements == 64:
         out_s = ops.attn_block_sparse(q, k, v, idx, num, vbs, layout=layout)
     else:
@@ -177,8 +169,6 @@ def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=Fa
     # token_of_row (model host only): gate arrives in TOKEN order and the result is returned in token order — tile(gate) and untile(out)
     # folded into the combine pass
     out = ops.vsa_combine(out_c, out_s, gate, block_elements, layout=layout, token_of_row=token_of_row, n_tokens=n_tokens)
-    if return_intermediates == "mask":
-        return out, dict(mask=mask)
     if return_intermediates:
         return out, dict(q_c=q_c, k_c=k_c, v_c=v_c, scores=scores, mask=mask, q2k_idx=idx, q2k_num=num, out_c=out_c,
                          out_s=out_s)

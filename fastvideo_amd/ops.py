@@ -507,63 +507,19 @@ def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, lay
         return (o, lse) if return_lse else o
     # the split last round of the 64-row list kernel (include/fvk_amd.h: fvk_attn_block_sparse_ws_bf16) wants a workspace; one buffer per
     # (device, size), kept — a captured HIP graph replays with the address it was captured with
-    ws, ws_bytes = _bs_workspace(a, max_kv, q.device) if (split_last_round and q_block == 64) else (None, 0)
+    ws_bytes = int(_lib.load().fvk_attn_block_sparse_workspace_bytes(C.byref(a), max_kv, int(q_block))) if split_last_round else 0
+    ws = None
+    if ws_bytes > 0:
+        key = (q.device.index, ws_bytes)
+        ws = _BS_WORKSPACES.get(key)
+        if ws is None:
+            ws = _BS_WORKSPACES[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=q.device)
     _lib.call("fvk_attn_block_sparse_ws_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), max_kv, int(q_block),
               _p(ws) if ws is not None else None, ws_bytes, _stream())
     return (o, lse) if return_lse else o
 
 
 _BS_WORKSPACES = {}
-
-
-def _bs_workspace(a, max_kv, device):
-    ws_bytes = int(_lib.load().fvk_attn_block_sparse_workspace_bytes(C.byref(a), max_kv, 64))
-    if ws_bytes <= 0:
-        return None, 0
-    key = (device.index, ws_bytes)
-    ws = _BS_WORKSPACES.get(key)
-    if ws is None:
-        ws = _BS_WORKSPACES[key] = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
-    return ws, ws_bytes
-
-
-def vsa_sparse_combine(q, k, v, q2k_idx, q2k_num, kv_block_sizes, out_c, gate=None, scale=None, layout="bhsd", token_of_row=None, n_tokens=None):
-    """The VSA sparse branch (64-row lists) with the combine pass in its store (fvk_vsa_sparse_combine_bf16): bit-identical to
-    ``vsa_combine(out_c, attn_block_sparse(...), gate, 64, ...)`` without the sparse output's round trip.  Arguments as those two calls."""
-    scale = q.shape[-1]**-0.5 if scale is None else scale
-    _chk(out_c, BF16, "out_c")
-    out_c = out_c.contiguous()
-    vt = _vt_of(v, layout)
-    if layout == "bhsd":
-        B, H, S, D = q.shape
-        st = lambda t: (t.stride(0), t.stride(2), t.stride(1))
-    else:
-        B, S, H, D = q.shape
-        st = lambda t: (t.stride(0), t.stride(1), t.stride(2))
-    if tuple(out_c.shape) != (B, H, S // 64, D):
-        raise RuntimeError(f"vsa_sparse_combine: out_c {tuple(out_c.shape)} != {(B, H, S // 64, D)}")
-    rows = S
-    if token_of_row is not None:
-        token_of_row = _chk(token_of_row, torch.int32, "token_of_row").contiguous()
-        if token_of_row.numel() != S or n_tokens is None:
-            raise RuntimeError("vsa_sparse_combine: token_of_row needs one entry per tile-major row and n_tokens")
-        rows = int(n_tokens)
-    out = torch.empty((B, H, rows, D) if layout == "bhsd" else (B, rows, H, D), dtype=BF16, device=q.device)
-    if gate is not None:
-        _chk(gate, BF16, "gate")
-        if gate.stride(-1) != 1 or gate.shape != out.shape:
-            raise RuntimeError("vsa_sparse_combine: the gate must match the output shape with a unit head_dim stride")
-    a = _attn_args(q, k, vt, out, scale, layout, None)
-    a.Sq = S  # (the output has n_tokens rows; the query axis keeps its padded length)
-    q2k_idx = _chk(q2k_idx, torch.int32, "q2k_idx").contiguous()
-    q2k_num = _chk(q2k_num, torch.int32, "q2k_num").contiguous()
-    kv_block_sizes = _chk(kv_block_sizes, torch.int32, "kv_block_sizes").contiguous()
-    max_kv = q2k_idx.shape[-1]
-    ws, ws_bytes = _bs_workspace(a, max_kv, q.device)
-    g_st = st(gate) if gate is not None else (0, 0, 0)
-    _lib.call("fvk_vsa_sparse_combine_bf16", C.byref(a), _p(q2k_idx), _p(q2k_num), _p(kv_block_sizes), max_kv, _p(out_c), _p(gate),
-              _p(token_of_row), *g_st, _p(ws), ws_bytes, _stream())
-    return out
 
 
 def attn_tile_lists(q, k, v, q2k_idx, q2k_num, kv_block_sizes, rows_per_list, q_rows_valid=None, scale=None, layout="bhsd", vt=None,

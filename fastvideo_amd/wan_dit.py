@@ -294,7 +294,7 @@ class WanTransformer3DModelHip:
             if self.vsa_trace is None:
                 o = kernel_api.video_sparse_attn_bshd(tq, tk, tv, vbs, vbs, m["topk"], 64, tg)
             else:  # tests: keep every layer's block selection so that an oracle can be evaluated with the SAME selection
-                o, inter = kernel_api._vsa_forward(tq, tk, tv, vbs, vbs, m["topk"], tg, "bshd", "mask")
+                o, inter = kernel_api._vsa_forward(tq, tk, tv, vbs, vbs, m["topk"], tg, "bshd", True)
                 self.vsa_trace.append(inter["mask"])
             o = ops.gather_rows(o, S, m["untile_combined_index"], None)
             if q.shape[0] != S:
@@ -348,7 +348,7 @@ class WanTransformer3DModelHip:
         ops.gather_rows(rows[:, 2 * d:3 * d].view(1, S, H, D), m["S_pad"], m["tile_partition_indices"], m["non_pad_index"], out=tv)
         gate = rows[:, 3 * d:4 * d].view(1, S, H, D) if has_gate else None
         vbs = m["variable_block_sizes"]
-        want = "mask" if self.vsa_trace is not None else False  # (the traced forward runs the SAME kernels)
+        want = self.vsa_trace is not None
         res = kernel_api._vsa_forward(tq, tk, tv, vbs, vbs, m["topk"], gate, "bshd", want, 64, token_of_row=m["token_of_row"], n_tokens=S)
         if want:  # tests: keep every layer's block selection so that an oracle can be evaluated with the SAME selection
             res, inter = res
@@ -424,7 +424,7 @@ class WanTransformer3DModelHip:
             vbs = m["variable_block_sizes"]
             b0, b1 = plan.r0 // 64, plan.r1 // 64
             g4 = r4[:, 3].unsqueeze(0) if NS == 4 else None
-            want = "mask" if self.vsa_trace is not None else False
+            want = self.vsa_trace is not None
             res = kernel_api._vsa_forward(tq[:, plan.r0:plan.r1], tk, tv, vbs, vbs[b0:b1], m["topk"], g4, "bshd", want, 64,
                                           token_of_row=m["token_of_row"][plan.r0:plan.r1], n_tokens=n)
             if want:

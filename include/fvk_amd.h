@@ -27,7 +27,7 @@ extern "C" {
 #define FVK_ERR_LAUNCH (-2)  /* hipLaunch / hip runtime error                  */
 
 const char* fvk_last_error(void);
-int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3, 6 = round 4, 7 = round 5's fvk_gemm_vt_bf16 + round 6's fvk_mfma_sustained_probe_bf16, 8 = fvk_attn_block_sparse_ws_bf16 / _workspace_bytes, fvk_vsa_sparse_combine_bf16) */
+int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3, 6 = round 4, 7 = round 5's fvk_gemm_vt_bf16 + round 6's fvk_mfma_sustained_probe_bf16, 8 = fvk_attn_block_sparse_ws_bf16 / _workspace_bytes) */
 int fvk_device_arch(char* buf, int len);   /* gcnArchName of the current device ("gfx950...") */
 int fvk_is_probe_build(void);              /* 0: the product library; 1: the measurement build (scripts/probes/libfvk_probe.so) */
 /* Integer knobs for within-process A/B measurements (scripts/microbench.py); 0 = shipped configuration.
@@ -243,17 +243,6 @@ int fvk_attn_block_sparse_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, c
 long fvk_attn_block_sparse_workspace_bytes(const fvk_attn_args* a, int max_kv, int q_block);
 int fvk_attn_block_sparse_ws_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes,
                                   int max_kv, int q_block, void* workspace, long workspace_bytes, void* stream);
-/* The VSA sparse branch with the COMBINE pass in its store (64-row lists; round 6): what fvk_attn_block_sparse_ws_bf16 followed by
- * fvk_vsa_combine_(scatter_)bf16 computes, bit-identical, without the sparse output's round trip through HBM:
- *     out[token(r)] = bf16( bf16( out_c[block(r)] * gate[token(r)] ) + bf16( o_sparse[r] ) )       (gate NULL: out_c + o_sparse)
- * ref: fastvideo_kernel/ops.py:128-131 (`final = out_c * gate + out_s`), video_sparse_attn.py:331-342 (untile).
- * out_c bf16 [B, H, Sq / 64, 128] contiguous (the coarse branch); gate bf16 at gate + b g_bs + token g_ss + h g_hs (elements, unit head_dim
- * stride); token_of_row int32 [Sq] or NULL: tile-major row r holds token token_of_row[r] (negative: a padding row, nothing is stored) — the gate
- * is read and the result written at the TOKEN's row: a->o with a->o_bs / o_ss / o_hs addresses the combined output ([B, n_tokens, H, 128] in the
- * model host).  a->lse must be NULL.  workspace as fvk_attn_block_sparse_ws_bf16 (same size query, q_block 64). */
-int fvk_vsa_sparse_combine_bf16(const fvk_attn_args* a, const int32_t* q2k_idx, const int32_t* q2k_num, const int32_t* kv_block_sizes,
-                                int max_kv, const void* out_c, const void* gate, const int32_t* token_of_row, long g_bs, long g_ss,
-                                long g_hs, void* workspace, long workspace_bytes, void* stream);
 /* The same attention for 64-row lists with the two lists of a workgroup's neighbouring query blocks (2p, 2p + 1) walked as ONE merged list
  * (round 4): fvk_vsa_union_lists merges the ascending lists of fvk_map_to_index into u_idx [B*H, ceil(nq/2), 2*max_kv] packed entries
  * (block id | valid keys << 22 | halves << 29) + u_num [B*H, ceil(nq/2)]; fvk_attn_block_sparse_union_bf16 walks them — a KV tile both blocks

@@ -773,46 +773,6 @@ def test_video_sparse_attn_composite(ops):
         _attn_check(out[:, :, valid_rows], ref.float()[:, :, valid_rows], "vsa composite")
 
 
-@pytest.mark.parametrize("layout,with_gate,scatter,nq", [("bhsd", True, False, 24), ("bshd", True, True, 24), ("bshd", False, True, 9),
-                                                         ("bshd", True, True, 520), ("bhsd", False, False, 520)])
-def test_vsa_sparse_combine_fused_equals_two_passes(ops, layout, with_gate, scatter, nq):
-    """fvk_vsa_sparse_combine_bf16 (round 6): the combine pass in the sparse kernel's store (and in the merge of its split last round) is
-    BIT-identical to attn_block_sparse + vsa_combine — both layouts, with / without the compress gate, with the token-order scatter (padding rows
-    dropped, gate read at the token's row), on grids of less than a round (every workgroup split) and of one round plus a tail (nq = 520)."""
-    B, H, nk = 1, 2, 40
-    g = torch.Generator().manual_seed(nq)
-    mk = lambda n: torch.randn((B, H, n * 64, 128), generator=g).to(torch.bfloat16).to(DEV)
-    q, k, v = mk(nq), mk(nk), mk(nk)
-    if layout == "bshd":
-        q, k, v = (t.transpose(1, 2).contiguous() for t in (q, k, v))
-    rng = np.random.default_rng(nq)
-    bm = rng.random((B, H, nq, nk)) < 0.5
-    bm[..., 0] = True
-    bm[0, 1, nq - 1, :] = False  # an empty list: out = out_c * gate alone
-    vbs = np.full(nk, 64, dtype=np.int32); vbs[3] = 17; vbs[-1] = 40
-    idx, num = V.map_to_index(bm)
-    dv = lambda t: torch.from_numpy(t).to(DEV)
-    out_c = torch.randn((B, H, nq, 128), generator=g).to(torch.bfloat16).to(DEV)
-    S = nq * 64
-    tok = n_tok = None
-    if scatter:  # a permutation with ~6 % padding rows
-        perm = rng.permutation(S).astype(np.int32)
-        pad = rng.random(S) < 0.06
-        n_tok = int((~pad).sum())
-        t_of_r = np.full(S, -1, dtype=np.int32)
-        t_of_r[perm[~pad[perm]]] = np.arange(n_tok, dtype=np.int32)
-        tok = dv(t_of_r)
-    rows = n_tok if scatter else S
-    gate = None
-    if with_gate:
-        gate = torch.randn((B, H, rows, 128) if layout == "bhsd" else (B, rows, H, 128), generator=g).to(torch.bfloat16).to(DEV)
-    o_s = ops.attn_block_sparse(q, k, v, dv(idx), dv(num), dv(vbs), layout=layout)
-    two = ops.vsa_combine(out_c, o_s, gate, 64, layout=layout, token_of_row=tok, n_tokens=n_tok)
-    one = ops.vsa_sparse_combine(q, k, v, dv(idx), dv(num), dv(vbs), out_c, gate, layout=layout, token_of_row=tok, n_tokens=n_tok)
-    assert one.shape == two.shape and torch.isfinite(one.float()).all()
-    assert torch.equal(one, two)
-
-
 # ------------------------------------------------------------------ glue
 def test_patchify_unpatchify_time_silu(ops):
     lat = rnd((2, 16, 3, 10, 14), 1)
