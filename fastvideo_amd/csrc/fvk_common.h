@@ -101,6 +101,14 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 __device__ __forceinline__ float bf16_round(float f) { return (float)(bf16_t)f; }
+// The same rounding, opaque to the optimiser.  bf16(bf16(a * b) + c) written with plain casts may be narrowed to bf16 operations and then CONTRACTED
+// to one fused multiply-add (a single rounding) — seen in round 6 when the VSA combine arithmetic was tried inside attn_bs16's epilogue (one-ulp
+// differences against vsa_combine_kernel, commit f214e3e; profiles/r06g_vsa_step_ab_fused_combine_and_split.log).
+__device__ __forceinline__ float bf16_round_opaque(float f) {
+    float r = (float)(bf16_t)f;
+    asm volatile("" : "+v"(r));
+    return r;
+}
 
 // tanh-approximate GELU in fp32, same formula as at::gelu(approximate="tanh"):
 // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715*x^3)))

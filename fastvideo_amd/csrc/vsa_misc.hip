@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void vsa_combine_kernel(const bf16_t* out_c, c
         if (gate) {
             const bf16x8 g = ld_bf16x8(gate + goff);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(bf16_round((float)oc[j] * (float)g[j]) + (float)os[j]);
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)(bf16_round_opaque((float)oc[j] * (float)g[j]) + (float)os[j]);
         } else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (bf16_t)((float)oc[j] + (float)os[j]);
