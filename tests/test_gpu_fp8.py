@@ -30,7 +30,10 @@ def test_quantize_matches_reference_golden_bit_exact(ops, rowwise):
     assert torch.equal(s.cpu(), g["s_row" if rowwise else "s_tensor"])
 
 
-@pytest.mark.parametrize("M,K,rowwise", [(1000, 1536, False), (1000, 1536, True), (32760, 8960, False), (3, 64, True)])
+@pytest.mark.parametrize("M,K,rowwise", [(1000, 1536, False), (1000, 1536, True), (32760, 8960, False), (3, 64, True),
+                                         # round 6: the one-pass rowwise kernel (a wave keeps its row in registers) at each register tier — up to 2048,
+                                         # 9216 and 18432 columns — a ragged last chunk per tier, and past it (the two-kernel form)
+                                         (700, 8960, True), (5, 2048, True), (9, 2056, True), (50, 18432, True), (10, 20480, True)])
 def test_quantize_bit_exact_vs_oracle(ops, M, K, rowwise):
     from oracle import fp8_oracle as O
     x = (rnd((M, K), 1) * torch.logspace(-2, 1, M).unsqueeze(1)).bfloat16()
