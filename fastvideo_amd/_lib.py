@@ -67,6 +67,7 @@ SIGNATURES = {
     "fvk_gather_rows_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, vp],
     "fvk_gather_rows_strided_bf16": [vp, vp, vp, vp, i32, i32, i32, i64, i64, i64, i64, vp],
     "fvk_block_mean_bf16": [vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, vp],
+    "fvk_block_mean_gather_bf16": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i64, i64, i64, vp],
     "fvk_topk_mask": [vp, i32, vp, i32, i32, i32, vp],
     "fvk_map_to_index": [vp, vp, vp, i32, i32, vp],
     "fvk_softmax_rows_bf16": [vp, vp, i32, i32, vp],

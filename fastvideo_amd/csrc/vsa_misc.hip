@@ -62,15 +62,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* src, bf1
 }
 
 // one workgroup per (block, head, batch): fp32 sum of `block` rows of D=128, / vbs, -> bf16.
+// src_rows (optional, int32 [n_blocks * block]): row p of the tile-major order is row src_rows[p] of x (negative: a padding row = zeros) — the
+// tile gather folded in (same rows, same summation order: bit-identical to the mean of the gathered copy).
 __global__ __launch_bounds__(256) void block_mean_kernel(const bf16_t* x, bf16_t* out, const int32_t* vbs, int H, int n_blocks,
-                                                         int block, long x_bs, long x_ss, long x_hs) {
+                                                         int block, long x_bs, long x_ss, long x_hs, const int32_t* src_rows) {
     __shared__ float part[16][128];
     const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int ch = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const bf16_t* base = x + b * x_bs + h * x_hs + (long)blk * block * x_ss + ch * 8;
+    const bf16_t* base = x + b * x_bs + h * x_hs + (src_rows ? 0L : (long)blk * block * x_ss) + ch * 8;
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int r = rg; r < block; r += 16) {
-        bf16x8 v = ld_bf16x8(base + (long)r * x_ss);
+        const int sr = src_rows ? src_rows[blk * block + r] : r;
+        if (sr < 0) continue;
+        bf16x8 v = ld_bf16x8(base + (long)sr * x_ss);
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
     }
@@ -419,7 +423,18 @@ extern "C" int fvk_block_mean_bf16(const void* x, void* out, const int32_t* vbs,
     FVK_CHECK(D == 128 && block > 0, FVK_ERR_ARG, "fvk_block_mean_bf16: D=%d must be 128", D);
     if (B <= 0 || H <= 0 || n_blocks <= 0) return FVK_OK;
     hipLaunchKernelGGL(block_mean_kernel, dim3(n_blocks, H, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out,
-                       vbs, H, n_blocks, block, x_bs, x_ss, x_hs);
+                       vbs, H, n_blocks, block, x_bs, x_ss, x_hs, (const int32_t*)nullptr);
+    FVK_LAUNCH_CHECK();
+    return FVK_OK;
+}
+
+extern "C" int fvk_block_mean_gather_bf16(const void* x, void* out, const int32_t* vbs, const int32_t* src_rows, int B, int H, int n_blocks,
+                                          int block, int D, long x_bs, long x_ss, long x_hs, void* stream) {
+    FVK_CHECK(x && out && vbs && src_rows, FVK_ERR_ARG, "fvk_block_mean_gather_bf16: null pointer");
+    FVK_CHECK(D == 128 && block > 0, FVK_ERR_ARG, "fvk_block_mean_gather_bf16: D=%d must be 128", D);
+    if (B <= 0 || H <= 0 || n_blocks <= 0) return FVK_OK;
+    hipLaunchKernelGGL(block_mean_kernel, dim3(n_blocks, H, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)out,
+                       vbs, H, n_blocks, block, x_bs, x_ss, x_hs, src_rows);
     FVK_LAUNCH_CHECK();
     return FVK_OK;
 }

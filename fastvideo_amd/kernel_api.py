@@ -140,7 +140,8 @@ def _expand_block_lists(idx, num, vbs, block_elements):
     return idx_s.contiguous(), num_s.contiguous(), sizes.contiguous()
 
 
-def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=False, block_elements=64, token_of_row=None, n_tokens=None):
+def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=False, block_elements=64, token_of_row=None, n_tokens=None,
+                 v_src_rows=None):
     """The VSA composition (fastvideo_kernel/ops.py:108-128) on tensors of either layout: "bhsd" (the package API) or "bshd" (what the model
     host holds — strides go to the kernels, nothing is transposed or copied).  ``block_elements`` 64 (Wan: tile (4,4,4)) runs the 64-row
     list kernel; 128 / 256 (the reference's Blackwell CuTe paths, ops.py:125-128) run the 128-row list kernel over expanded lists."""
@@ -154,7 +155,16 @@ def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=Fa
     # compression branch (ops.py:108-118): block means, coarse scores (bf16, /sqrt(D)), coarse attention
     q_c = ops.block_mean(q, qvbs, block_elements, layout=layout)
     k_c = ops.block_mean(k, vbs, block_elements, layout=layout)
-    v_c = ops.block_mean(v, vbs, block_elements, layout=layout)
+    # v_src_rows (model host, 64-token blocks, "bshd"): v arrives in TOKEN order [B, S, H, D]; tile-major key row p is token v_src_rows[p] (int32,
+    # a multiple of 128 entries, negative = padding) — tile(v) folded into the block means and into the V^T layout pass, no gathered copy
+    vt = None
+    if v_src_rows is not None:
+        if block_elements != 64 or layout != "bshd":
+            raise ValueError("_vsa_forward: v_src_rows serves the 64-token-block bshd path only")
+        v_c = ops.block_mean(v, vbs, block_elements, layout=layout, src_rows=v_src_rows)
+        vt = ops.v_transpose(v, src_rows=v_src_rows)
+    else:
+        v_c = ops.block_mean(v, vbs, block_elements, layout=layout)
     scores = ops.gemm_batched(q_c.view(batch * heads, q_num_blocks, dim), k_c.view(batch * heads, kv_num_blocks, dim),
                               epilogue=ops.EPI_DIV, scalar=dim**0.5).view(batch, heads, q_num_blocks, kv_num_blocks)
     out_c = ops.attn_dense(q_c, k_c, v_c, scale=dim**-0.5, layout="bhsd")
@@ -162,7 +172,7 @@ def _vsa_forward(q, k, v, vbs, qvbs, topk, gate, layout, return_intermediates=Fa
     mask = ops.topk_mask(scores, min(int(topk), kv_num_blocks))
     idx, num = ops.map_to_index(mask)
     if block_elements == 64:
-        out_s = ops.attn_block_sparse(q, k, v, idx, num, vbs, layout=layout)
+        out_s = ops.attn_block_sparse(q, k, v, idx, num, vbs, layout=layout, vt=vt)
     else:
         idx_s, num_s, sizes = _expand_block_lists(idx, num, vbs, block_elements)
         out_s = ops.attn_block_sparse(q, k, v, idx_s, num_s, sizes, layout=layout, q_block=128)

@@ -479,16 +479,17 @@ def attn_dense(q, k, v=None, vt=None, scale=None, layout="bshd", out=None, retur
 
 
 def attn_block_sparse(q, k, v, q2k_idx, q2k_num, kv_block_sizes, scale=None, layout="bhsd", return_lse=False, q_block=64, pair_union=False,
-                      split_last_round=True):
+                      split_last_round=True, vt=None):
     """q2k_idx int32 [B,H,nq,max_kv] ascending block lists, q2k_num [B,H,nq], kv_block_sizes [nkv].
     pair_union (64-row lists, max_kv <= 2048): the two lists of neighbouring query blocks are merged (fvk_vsa_union_lists) and walked as one by
     their workgroup — a KV tile both selected is fetched once (fvk_attn_block_sparse_union_bf16); bit-identical output.  OFF by default: the
     walk fetches ~30 % fewer tiles on the selections the model makes but takes one step per tile of the UNION, both halves in lockstep, and the
     kernel is step-bound, not ingest-bound — 3.2 vs 2.65 ms per layer at cfg2 (profiles/r04u_vsa_union_ab.log).
     split_last_round (64-row lists): the workgroups of the launch's last, partly empty round walk their lists in 2-4 parts that are merged
-    afterwards (fvk_attn_block_sparse_ws_bf16); False = every list whole."""
+    afterwards (fvk_attn_block_sparse_ws_bf16); False = every list whole.  vt: a ready V^T (v_transpose's layout; v is then ignored)."""
     scale = q.shape[-1]**-0.5 if scale is None else scale
-    vt = _vt_of(v, layout)
+    if vt is None:
+        vt = _vt_of(v, layout)
     o = torch.empty_like(q)
     B, H = (q.shape[0], q.shape[2]) if layout == "bshd" else (q.shape[0], q.shape[1])
     Sq = q.shape[1] if layout == "bshd" else q.shape[2]
@@ -767,18 +768,29 @@ def gather_rows(src, n_dst_rows, src_index=None, dst_index=None, zero_init=False
     return out
 
 
-def block_mean(x, vbs, block=64, layout="bhsd"):
-    """x [B,H,S_pad,D] (or bshd) -> [B,H,Nblk,D]."""
+def block_mean(x, vbs, block=64, layout="bhsd", src_rows=None):
+    """x [B,H,S_pad,D] (or bshd) -> [B,H,Nblk,D].  src_rows (int32 [Nblk * block]): tile-major row p is row src_rows[p] of x (negative: a
+    padding row) — x is then in TOKEN order and the tile gather is folded in (fvk_block_mean_gather_bf16, bit-identical)."""
     _chk(x, BF16, "x")
+    if x.stride(-1) != 1:
+        raise RuntimeError("block_mean: head_dim must be the unit-stride dimension")
     if layout == "bhsd":
         B, H, S, D = x.shape
         bs, hs, ss = x.stride(0), x.stride(1), x.stride(2)
     else:
         B, S, H, D = x.shape
         bs, ss, hs = x.stride(0), x.stride(1), x.stride(2)
+    vbs = _chk(vbs, torch.int32, "vbs").contiguous()
+    if src_rows is not None:
+        src_rows = _chk(src_rows, torch.int32, "src_rows").contiguous()
+        nb = vbs.numel()
+        if src_rows.numel() < nb * block:
+            raise RuntimeError(f"block_mean: src_rows holds {src_rows.numel()} entries, {nb} blocks of {block} rows need {nb * block}")
+        out = torch.empty((B, H, nb, D), dtype=BF16, device=x.device)
+        _lib.call("fvk_block_mean_gather_bf16", _p(x), _p(out), _p(vbs), _p(src_rows), B, H, nb, block, D, bs, ss, hs, _stream())
+        return out
     nb = S // block
     out = torch.empty((B, H, nb, D), dtype=BF16, device=x.device)
-    vbs = _chk(vbs, torch.int32, "vbs").contiguous()
     _lib.call("fvk_block_mean_bf16", _p(x), _p(out), _p(vbs), B, H, nb, block, D, bs, ss, hs, _stream())
     return out
 

@@ -64,7 +64,8 @@ class WanTransformer3DModelHip:
         # sliding-tile list form: "grouped" (shipped) = queries packed by window class on 256-row workgroups; "tile" = one list per 384-token
         # tile (256-row workgroups + a 128-row remainder); "block128" = one list per 128-row query block on the 4-wave kernel (A/B, tests)
         self.sta_lists = "grouped"
-        self.vsa_fold = True  # single GPU: tile(q), tile(k), tile(gate), untile(out) folded into the neighbouring kernels (V keeps its gather)
+        self.vsa_fold = True  # single GPU: tile(q), tile(k), tile(gate), untile(out) folded into the neighbouring kernels
+        self.vsa_fold_v = True  # ... and tile(v) into V's block means and V^T pass (False: a gathered copy of V, the form until round 6)
         self.sta_fold = True  # single GPU: no gather passes at all (q / k scattered by the norm pass, V^T gathered, output scattered)
         self.attn_events = None  # set to a list to collect (start, end, Sq, Skv, heads) HIP-event pairs
         # Dense self-attention on long key axes has two kernels that agree to rounding (fvk_attn_dense_kernel_bf16: attn_w16 / attn_w64); which
@@ -164,6 +165,9 @@ class WanTransformer3DModelHip:
             tok = torch.full((m["S_pad"],), -1, dtype=torch.int32)
             tok[row.long()] = torch.arange(n_tok, dtype=torch.int32)
             m["row_of_token"], m["token_of_row"] = row.to(self.device), tok.to(self.device)
+            tok128 = torch.full(((m["S_pad"] + 127) // 128 * 128,), -1, dtype=torch.int32)  # v_transpose walks whole 128-key tiles
+            tok128[:m["S_pad"]] = tok
+            m["token_of_row_128"] = tok128.to(self.device)
             self._vsa_cache[grid] = m
         return m
 
@@ -332,9 +336,10 @@ class WanTransformer3DModelHip:
         return o[0]
 
     def _vsa_fused(self, rows, b, cos, sin, S, grid):
-        """Video-sparse self-attention of one sample (single GPU) with ONE gather left (V): the QK-norm / RoPE pass scatters q and k into
-        the tile-major padded layout, the combine pass reads the compress gate in token order and writes the result in token order
-        (tile(q), tile(k), tile(gate) and untile(out) folded away; ref video_sparse_attn.py:254-342).  rows [S, 4d] -> o [S, H, D]."""
+        """Video-sparse self-attention of one sample (single GPU) with NO gather pass: the QK-norm / RoPE pass scatters q and k into the
+        tile-major padded layout, V's block means and its V^T layout pass read the token-order rows through the tile map (round 6; a gathered
+        copy of V until then), the combine pass reads the compress gate in token order and writes the result in token order (tile(q), tile(k),
+        tile(v), tile(gate) and untile(out) folded away; ref video_sparse_attn.py:254-342).  rows [S, 4d] -> o [S, H, D]."""
         d, H, D = self.d, self.H, self.D
         m = self._vsa_meta(grid)
         has_gate = rows.shape[1] >= 4 * d
@@ -345,11 +350,15 @@ class WanTransformer3DModelHip:
         if self.attn_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        ops.gather_rows(rows[:, 2 * d:3 * d].view(1, S, H, D), m["S_pad"], m["tile_partition_indices"], m["non_pad_index"], out=tv)
+        v_tok = rows[:, 2 * d:3 * d].view(1, S, H, D)
+        v_map = m["token_of_row_128"] if self.vsa_fold_v else None
+        if v_map is None:  # A/B: the gathered copy
+            ops.gather_rows(v_tok, m["S_pad"], m["tile_partition_indices"], m["non_pad_index"], out=tv)
         gate = rows[:, 3 * d:4 * d].view(1, S, H, D) if has_gate else None
         vbs = m["variable_block_sizes"]
         want = self.vsa_trace is not None
-        res = kernel_api._vsa_forward(tq, tk, tv, vbs, vbs, m["topk"], gate, "bshd", want, 64, token_of_row=m["token_of_row"], n_tokens=S)
+        res = kernel_api._vsa_forward(tq, tk, tv if v_map is None else v_tok, vbs, vbs, m["topk"], gate, "bshd", want, 64,
+                                      token_of_row=m["token_of_row"], n_tokens=S, v_src_rows=v_map)
         if want:  # tests: keep every layer's block selection so that an oracle can be evaluated with the SAME selection
             res, inter = res
             self.vsa_trace.append(inter["mask"])

@@ -27,7 +27,7 @@ extern "C" {
 #define FVK_ERR_LAUNCH (-2)  /* hipLaunch / hip runtime error                  */
 
 const char* fvk_last_error(void);
-int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3, 6 = round 4, 7 = round 5's fvk_gemm_vt_bf16 + round 6's fvk_mfma_sustained_probe_bf16, 8 = fvk_attn_block_sparse_ws_bf16 / _workspace_bytes) */
+int fvk_abi_version(void);                 /* bumps when a signature changes or entry points are added (5 = round 3, 6 = round 4, 7 = round 5's fvk_gemm_vt_bf16 + round 6's fvk_mfma_sustained_probe_bf16, 8 = fvk_attn_block_sparse_ws_bf16 / _workspace_bytes, fvk_block_mean_gather_bf16) */
 int fvk_device_arch(char* buf, int len);   /* gcnArchName of the current device ("gfx950...") */
 int fvk_is_probe_build(void);              /* 0: the product library; 1: the measurement build (scripts/probes/libfvk_probe.so) */
 /* Integer knobs for within-process A/B measurements (scripts/microbench.py); 0 = shipped configuration.
@@ -298,6 +298,10 @@ int fvk_gather_rows_strided_bf16(const void* src, void* dst, const int32_t* src_
 /* x [B,S_pad,H,D] with strides -> out [B,H,Nblk,D] bf16 = bf16(fp32 sum over 64 rows / vbs[blk]). */
 int fvk_block_mean_bf16(const void* x, void* out, const int32_t* vbs, int B, int H, int n_blocks, int block, int D,
                         long x_bs, long x_ss, long x_hs, void* stream);
+/* the same means over rows GATHERED on the fly (round 6): tile-major row p is row src_rows[p] of x (int32 [n_blocks * block]; negative = a
+ * padding row, i.e. zeros) — tile() of video_sparse_attn.py:254-281 folded in; bit-identical to fvk_block_mean_bf16 on the gathered copy. */
+int fvk_block_mean_gather_bf16(const void* x, void* out, const int32_t* vbs, const int32_t* src_rows, int B, int H, int n_blocks, int block,
+                               int D, long x_bs, long x_ss, long x_hs, void* stream);
 /* scores bf16 or fp32 [rows, n] -> mask uint8 [rows, n] with exactly min(topk,n) ones per row (bisection + first-come ties). */
 int fvk_topk_mask(const void* scores, int scores_is_fp32, uint8_t* mask, int rows, int n, int topk, void* stream);
 /* mask uint8 [rows, n] -> idx int32 [rows, n] (ascending, tail zero), num int32 [rows]. */

@@ -743,6 +743,32 @@ def test_block_mean(ops):
     close(got, ref, atol=1e-2, rtol=1e-2, what="block mean")
 
 
+def test_block_mean_with_the_tile_gather_folded_in(ops):
+    """fvk_block_mean_gather_bf16 (round 6): the block means of a token-order tensor through the tile map == the means of the gathered copy, bit
+    for bit (ragged tiles: padding rows are zeros in the copy and skipped here); and _vsa_forward with v in token order (v_src_rows) == with the
+    tile-major copy."""
+    from fastvideo_amd import kernel_api as KA
+    lat = (8, 20, 14)  # dit (8,10,7) -> 12 ragged tiles
+    md = V.build_metadata(lat)
+    S, B, H = md["total_seq_length"], 1, 3
+    wide = rnd((B, S, 4 * H * 128), 5).to(DEV)                      # the model host's fused q | k | v | gate rows
+    x = wide[:, :, 2 * H * 128:3 * H * 128].view(B, S, H, 128)      # a strided token-order view (row stride 4 d)
+    vbs = torch.from_numpy(md["variable_block_sizes"]).to(DEV)
+    nb = vbs.numel()
+    perm, npi = (torch.from_numpy(md[k_]).int().to(DEV) for k_ in ("tile_partition_indices", "non_pad_index"))
+    tiled = ops.gather_rows(x, nb * 64, perm, npi, zero_init=True)
+    tok = torch.full(((nb * 64 + 127) // 128 * 128,), -1, dtype=torch.int32)
+    tok[npi.cpu().long()] = perm.cpu()
+    tok = tok.to(DEV)
+    assert torch.equal(ops.block_mean(x, vbs, 64, layout="bshd", src_rows=tok), ops.block_mean(tiled, vbs, 64, layout="bshd"))
+    assert torch.equal(ops.v_transpose(x, src_rows=tok)[..., :nb * 64], ops.v_transpose(tiled)[..., :nb * 64])
+    q, k, gate = (ops.gather_rows(rnd((B, S, H, 128), s_).to(DEV), nb * 64, perm, npi, zero_init=True) for s_ in (1, 2, 4))
+    topk = V.compute_topk(0.5, nb)
+    a = KA._vsa_forward(q, k, tiled, vbs, vbs, topk, gate, "bshd")
+    b_ = KA._vsa_forward(q, k, x, vbs, vbs, topk, gate, "bshd", v_src_rows=tok)
+    assert torch.equal(a, b_)
+
+
 def test_video_sparse_attn_composite(ops):
     from fastvideo_amd import kernel_api as KA
     lat = (8, 20, 14)  # dit (8,10,7) -> tiles (2,3,2)=12 blocks, ragged

@@ -92,7 +92,9 @@ def test_wan_tiny_vsa_matches_oracle(tiny):
     _cmp(y, ref2, "vsa model, oracle with the device's block selection")
     # the shipped single-GPU path folds tile(q), tile(k) and untile(out) into the neighbouring kernels: the same values reach the same
     # kernels as with the explicit gathers -> bit-identical output
-    assert model.vsa_fold
+    assert model.vsa_fold and model.vsa_fold_v
+    model.vsa_fold_v = False  # round 6: tile(v) folded into V's block means and its V^T pass vs a gathered copy of V
+    assert torch.equal(model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda()), y)
     model.vsa_fold = False
     assert torch.equal(model(case["latent"].cuda(), case["ctx"].cuda(), case["timestep"].cuda()), y)
 
