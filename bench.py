@@ -362,7 +362,7 @@ def measure_vae(latent_shape, steps, warmup, frames_per_pass=4):
     ev, ops.VAE_CONV_EVENTS = ops.VAE_CONV_EVENTS, None
     groups = {}
     for taps, cin, cout, fl, e0, e1 in ev:
-        k = "vae_conv3w_kernel + conv_out's vae_conv3_kernel (3x3 spatial taps, halo slabs in LDS; one wave per SIMD, 16x16x32 MFMAs)" if taps.endswith("3x3") else "vae_conv_kernel (1x1 / temporal taps)"
+        k = "vae_conv3w_kernel + conv_out's vae_convout_kernel (3x3 spatial taps, halo slabs in LDS; one wave per SIMD, 16x16x32 MFMAs; conv_out: the three time taps on the N axis, every input frame fetched once)" if taps.endswith("3x3") else "vae_conv_kernel (1x1 / temporal taps)"
         gsum = groups.setdefault(k, [0.0, 0.0, 0])
         gsum[0] += fl
         gsum[1] += e0.elapsed_time(e1)
