@@ -568,7 +568,7 @@ def main():
     else:
         # sparse modes: the algorithmic work is the selected fraction of the dense score matrix (VSA: top-k of the 64-token blocks
         # + the coarse branch, negligible; STA: the window's share of key tokens); the timed region is the whole attention
-        # (tile gather + coarse stage + block-sparse kernel + untile)
+        # (coarse stage + block-sparse kernel + combine; the tile / untile gathers are folded into the neighbouring passes)
         if args.attention == "vsa":
             m = next(iter(v for k_, v in model._vsa_cache.items() if not (isinstance(k_, tuple) and k_ and isinstance(k_[0], str))))
             dens = m["topk"] / m["variable_block_sizes"].numel() * (m["S_pad"] / Skv)**2
@@ -578,7 +578,8 @@ def main():
         if args.attention == "sta":  # single GPU: no gather passes (wan_dit._sta_fused); queries packed by window class on 256-row workgroups
             kname = f"sta self-attention (V^T gather-transpose + attn_pp2_kernel over KV block lists, output rows scattered), density {dens:.3f} of dense"
         else:
-            kname = f"{args.attention} self-attention (gather + attn_fwd_kernel block-sparse + untile), density {dens:.3f} of dense"
+            kname = (f"{args.attention} self-attention (coarse stage + attn_bs16_kernel over 64-row block lists, its last round split + merged, + combine pass; "
+                     f"tile / untile folded into the neighbouring passes), density {dens:.3f} of dense")
     achieved = flops_launch / (mean_ms * 1e-3) / 1e12
     traffic, traffic_src, gui_cycles = None, None, None
     if args.attention == "dense" and args.config == "cfg2" and world == 1:
